@@ -1,0 +1,208 @@
+"""Factories with the reference's entry-point names (im2mesh/config.py:12-75,
+im2mesh/metaavatar_render/config.py:147-302): ``load_config``, ``get_model``, ``method_dict``.
+
+The reference's yaml files are data and are not shipped; the model-relevant keys of the three
+config families it uses are restated in ``builtin_config``.  A user's own yaml (with recursive
+``inherit_from``) loads through ``load_config`` exactly like in the reference.
+"""
+import copy
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import nets
+from .renderer import MetaAvatarRender
+
+_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+_SKIN_KW = {"d_in": 3, "d_out": 25, "d_hidden": 128, "n_layers": 4, "skip_in": [], "cond_in": [], "multires": 0,
+            "bias": 1.0, "geometric_init": False, "weight_norm": True}
+_SDF_KW = {"in_features": 3, "num_hidden_layers": 5, "hierarchical_pose": True, "hyper_in_ch": 144, "use_FiLM": True}
+_DEFAULT = {
+    "method": "metaavatar_render",
+    "model": {"decoder": "hyper_bvp", "skinning_decoder": "deformer_mlp", "decoder_kwargs": _SDF_KW,
+              "skinning_decoder_kwargs": _SKIN_KW, "renderer": "mlp", "latent_dim": 128, "train_cameras": False,
+              "train_smpl": False, "geo_pose_encoder": "latent", "color_pose_encoder": "latent",
+              "cano_view_dirs": True, "n_steps": 64, "near_surface_samples": 16, "far_surface_samples": 16,
+              "render_last_pt": False},
+    "training": {"train_skinning_net": True, "pose_input_noise": True, "view_input_noise": True,
+                 "nv_noise_type": "rotation"},
+}
+_IDR = {"mode": "idr", "d_in": 9, "d_out": 3, "d_hidden": 256, "n_layers": 5, "weight_norm": True, "multires": 0,
+        "multires_view": 4, "skips": [3], "squeeze_out": True}
+_NOVIEW = {"mode": "no_view_dir", "d_in": 6, "d_out": 3, "d_hidden": 256, "n_layers": 5, "weight_norm": True,
+           "multires": 0, "multires_view": 0, "skips": [3], "squeeze_out": True}
+
+
+def builtin_config(name, n_steps=64, near=16, far=16):
+    """Model keys of configs/arah-zju/ZJUMOCAP-377-mono_4gpus.yaml:30-45 ('zju377_mono'),
+    configs/arah-zju/ZJUMOCAP-313_4gpus.yaml:30-45 ('zju313') and configs/arah-h36m/H36M_S9_4gpus.yaml:29-44
+    ('h36m')."""
+    cfg = copy.deepcopy(_DEFAULT)
+    if name == "zju377_mono":
+        cfg["model"].update(renderer_kwargs=dict(_NOVIEW), cano_view_dirs=False)
+    elif name == "zju313":
+        cfg["model"].update(renderer_kwargs=dict(_IDR), cano_view_dirs=False)
+    elif name == "h36m":
+        cfg["model"].update(renderer_kwargs=dict(_IDR), cano_view_dirs=True)
+    else:
+        raise KeyError(name)
+    cfg["model"].update(n_steps=n_steps, near_surface_samples=near, far_surface_samples=far)
+    return cfg
+
+
+def _merge(dst, src):
+    for k, v in src.items():
+        if isinstance(v, dict):
+            _merge(dst.setdefault(k, {}), v)
+        else:
+            dst[k] = v
+
+
+def load_config(path, default_path=None):
+    """yaml + recursive ``inherit_from`` + defaults (reference im2mesh/config.py:12-56)."""
+    import yaml
+    with open(path, "r") as f:
+        special = yaml.safe_load(f)
+    parent = special.get("inherit_from")
+    if parent is not None:
+        cfg = load_config(parent, default_path)
+    elif default_path is not None:
+        with open(default_path, "r") as f:
+            cfg = yaml.safe_load(f)
+    else:
+        cfg = {}
+    _merge(cfg, special)
+    return cfg
+
+
+def _color_feature_dim(cfg):
+    enc = cfg["model"]["color_pose_encoder"]
+    extra = {None: 0, "leap": 144, "root": 12, "latent": cfg["model"]["latent_dim"],
+             "hybrid": 12 + cfg["model"]["latent_dim"]}
+    if enc not in extra:
+        raise ValueError("Unsupported rendering network pose encoder %r" % enc)
+    return 256 + extra[enc]
+
+
+def get_render_model(cfg, mode="test", low_vram=False, checkpoint_path=None, n_data_points=None, **kwargs):
+    """metaavatar_render.config.get_model: returns the bare MetaAvatarRender module."""
+    m = cfg["model"]
+    sdf_decoder = nets.decoder_dict[m["decoder"]](**m["decoder_kwargs"])
+    skinning = nets.SkinningModel(nets.decoder_dict[m["skinning_decoder"]](**m["skinning_decoder_kwargs"]))
+    color = nets.RenderingNetwork(d_feature=_color_feature_dim(cfg), pose_encoder=m["color_pose_encoder"],
+                                  **m["renderer_kwargs"])
+    deviation = nets.SingleVarianceNetwork(1e-3)
+    if m.get("train_cameras") and mode in ("train", "val"):
+        raise NotImplementedError("train_cameras needs the dataset's camera files")
+    if m.get("train_smpl") and mode in ("train", "val"):
+        raise NotImplementedError("train_smpl needs body_models/misc/*.npz (not redistributable)")
+    train_latent = m["color_pose_encoder"] in ("hybrid", "latent")
+    train_geo_latent = m["geo_pose_encoder"] in ("latent",)
+    ckpt = None
+    if checkpoint_path is not None:
+        ckpt = torch.load(checkpoint_path, map_location="cpu")
+    model_kwargs = {}
+    if train_latent or train_geo_latent:
+        if ckpt is not None:
+            n_data_points = ckpt["state_dict"]["model.latent.weight"].size(0)   # config.py:253-257
+        if n_data_points is None:
+            raise ValueError("need n_data_points or a checkpoint to size the latent embedding")
+        model_kwargs.update(n_data_points=n_data_points, frames=[])
+    t = cfg.get("training", {})
+    model = MetaAvatarRender(sdf_decoder=sdf_decoder, skinning_model=skinning, color_decoder=color,
+                             deviation_decoder=deviation, train_cameras=False, train_smpl=False,
+                             train_latent_code=train_latent, train_geo_latent_code=train_geo_latent,
+                             cano_view_dirs=m["cano_view_dirs"], near_surface_samples=m["near_surface_samples"],
+                             far_surface_samples=m["far_surface_samples"], n_steps=m["n_steps"],
+                             train_skinning_net=t.get("train_skinning_net", False),
+                             render_last_pt=m["render_last_pt"], pose_input_noise=t.get("pose_input_noise", False),
+                             view_input_noise=t.get("view_input_noise", False),
+                             nv_noise_type=t.get("nv_noise_type", "rotation"), low_vram=low_vram, **model_kwargs)
+    if ckpt is not None:   # Lightning prefixes the module with 'model.' (config.py:291-300)
+        sd = {k[6:]: v for k, v in ckpt["state_dict"].items() if k.startswith("model.")}
+        model.load_state_dict(sd, strict=False)
+    return model
+
+
+class LightningModel(nn.Module):
+    """Minimal stand-in for the reference's Lightning harness (lightning_model.py:101-653): holds
+    ``model`` under the same attribute so that checkpoints keep the 'model.' prefix; the harness itself
+    (dataset composition, metrics, image writing) is the caller and out of scope."""
+
+    def __init__(self, model, cfg, val_size=None):
+        super().__init__()
+        self.model = model
+        self.cfg = cfg
+        self.val_size = val_size
+
+    def forward(self, inputs, gen_cano_mesh=False, eval=True):
+        return self.model(inputs, gen_cano_mesh=gen_cano_mesh, eval=eval)
+
+    def test_step(self, inputs):
+        with torch.no_grad():
+            return self.model(inputs, gen_cano_mesh=False, eval=True)
+
+
+class _Method:
+    class config:   # noqa: N801  (mirrors ``method_dict[method].config.get_model``)
+        get_model = staticmethod(get_render_model)
+
+    class lightning_model:   # noqa: N801
+        LightningModel = LightningModel
+
+
+method_dict = {"metaavatar_render": _Method}
+
+
+def get_model(cfg, dataset=None, val_size=None, mode="train", low_vram=False, checkpoint_path=None, **kwargs):
+    """im2mesh.config.get_model (reference im2mesh/config.py:60-75)."""
+    method = method_dict[cfg["method"]]
+    model = method.config.get_model(cfg, dataset=dataset, mode=mode, low_vram=low_vram,
+                                    checkpoint_path=checkpoint_path, **kwargs)
+    return method.lightning_model.LightningModel(model=model, cfg=cfg, val_size=val_size)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic weights (no reference checkpoint is redistributable)
+# ---------------------------------------------------------------------------------------------
+def synthetic_state_dict(cfg, asset_path=None):
+    """State-dict entries (reference names) that turn a freshly built model into the synthetic subject:
+    fitted SIREN in the ``hypo_params_init`` buffers, fixed FiLM vectors in the mapping network's last
+    bias, fitted skinning MLP, seeded colour MLP / latent codes / beta."""
+    path = asset_path or os.path.join(_ASSETS, "synthetic_weights.npz")
+    a = np.load(path)
+    t = lambda k: torch.from_numpy(np.asarray(a[k], dtype=np.float32))
+    sd = {}
+    for i in range(7):
+        flat = torch.cat([t("sdf_w%d" % i).reshape(-1), t("sdf_b%d" % i).reshape(-1)]).reshape(1, -1)
+        key = ("sdf_decoder.net.layers.%d.hyper_linear.hypo_params_init" % i) if i < 6 else \
+            "sdf_decoder.net.layers.6.hypo_params_init"
+        sd[key] = flat
+    sd["sdf_decoder.net.mapping_network.network.6.bias"] = torch.cat([t("film_freq").reshape(-1),
+                                                                       t("film_phase").reshape(-1)])
+    sd["sdf_decoder.net.mapping_network.network.6.weight"] = torch.zeros(6 * 256 * 2, 256)
+    tag = cfg["model"]["renderer_kwargs"]["mode"]
+    for k in a.files:
+        if k.startswith("skin."):
+            sd["skinning_model.skinning_decoder_fwd." + k[5:]] = t(k)
+        if k.startswith("color_%s." % tag):
+            sd["color_decoder." + k[len("color_%s." % tag):]] = t(k)
+    sd["latent.weight"] = t("latent")
+    sd["deviation_decoder.variance"] = t("variance").reshape(())
+    return sd
+
+
+def build_synthetic_model(name="zju377_mono", n_steps=64, near=16, far=16, device="cpu", seed=0):
+    """Builtin config + synthetic weights; deterministic (the hyper heads are seeded but irrelevant:
+    their last layer is zero, so the emitted SDF MLP equals the fitted one for every pose)."""
+    cfg = builtin_config(name, n_steps, near, far)
+    gen = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    model = get_render_model(cfg, mode="test", n_data_points=4)
+    torch.random.set_rng_state(gen)
+    missing = model.load_state_dict(synthetic_state_dict(cfg), strict=False)
+    assert not missing.unexpected_keys, missing.unexpected_keys
+    return model.to(device).eval(), cfg

@@ -1,0 +1,474 @@
+// mlp.hpp -- workgroup-cooperative MLP evaluation on the CDNA4 matrix cores (gfx950).
+//
+// Geometry (one "tile" = 64 points = 64 MFMA columns):
+//   * workgroup = 512 threads = 8 wave64; every wave sees all 64 points (4 N-tiles of 16) and owns
+//     a slice of the layer's output channels (M-tiles of 16): 2 M-tiles for a 256-wide layer,
+//     1 for a 128-wide one.  8 independent f32x4 accumulators per wave hide the 40-cycle
+//     dependent latency of v_mfma_f32_16x16x4_f32 (issue 32 cycles).
+//   * arithmetic is exact fp32 (v_mfma_f32_16x16x4_f32 == fmaf chain): root finding needs
+//     |residual| < 1e-5 m and sin(30 x) amplifies input error, so no bf16/fp16 inputs here.
+//   * activations live in LDS as act[point][K] (row stride K+4 floats); B fragments are
+//     ds_read_b128: lane (j = lane&15, g = lane>>4) reads act[n*16+j][kc*16 + 4g .. +3].
+//   * weights stream from L2 in a layout packed once per frame so that the matching A fragment
+//     (W[mt*16 + j][kc*16 + 4g .. +3]) is one coalesced 1 KiB global_load_dwordx4 per wave:
+//         packed[((mt*KC + kc)*64 + lane)*4 + t]
+//     MFMA step t multiplies A.t by B.t: lane group g supplies k = kc*16 + 4g + t on both
+//     sides, so the k-permutation inside a 16-chunk is consistent and harmless.
+//   * accumulator ownership: acc[m][n][r] = out[channel (mt0+m)*16 + 4g + r][point n*16 + j].
+//     Epilogues (bias, FiLM, sin/softplus/relu, derivative factors) are lane-local, and a layer's
+//     output is written back IN PLACE after a barrier (all waves have finished reading it).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace arah {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kThreads = 512;
+constexpr int kWaves = 8;
+constexpr int kTile = 64;     // points per tile
+constexpr int kNT = 4;        // N-tiles (16 points each) per wave
+
+__device__ __forceinline__ void zero_acc(f32x4& a) { a = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// acc[m][n] += Wp(rows of M-tiles mt0..mt0+MT-1, KC 16-chunks) * act(64 points)
+template <int KC, int MT>
+__device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, const float* act, int ld,
+                                         f32x4 (&acc)[MT][kNT], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const float* bptr = act + j * ld + 4 * g;
+    const f32x4* aptr = reinterpret_cast<const f32x4*>(wp) + (size_t)mt0 * KC * 64 + lane;
+    f32x4 a_cur[MT], a_nxt[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) a_cur[m] = aptr[(m * KC) * 64];
+#pragma unroll 1
+    for (int kc = 0; kc < KC; ++kc) {
+        const int kn = (kc + 1 < KC) ? kc + 1 : kc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_nxt[m] = aptr[(m * KC + kn) * 64];
+        f32x4 b[kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) b[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kc * 16);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < kNT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][t], b[n][t], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+    }
+}
+
+// One 16x16 output tile (M-tile mt, N-tile nt): used for narrow output layers split over waves.
+template <int KC>
+__device__ __forceinline__ f32x4 gemm_one(const float* __restrict__ wp, int mt, int nt, const float* act, int ld,
+                                          int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const float* bptr = act + (nt * 16 + j) * ld + 4 * g;
+    const f32x4* aptr = reinterpret_cast<const f32x4*>(wp) + (size_t)mt * KC * 64 + lane;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int kc = 0; kc < KC; ++kc) {
+        const f32x4 a = aptr[kc * 64];
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bptr + kc * 16);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], b[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], b[3], acc1, 0, 0, 0);
+    }
+    return acc0 + acc1;
+}
+
+// ------------------------------------------------------------------------------------------
+// SDF network: FiLM-SIREN 3 -> 256 x6 -> 1
+// ------------------------------------------------------------------------------------------
+struct SdfNet {
+    const float* w0;       // [256][4]
+    const float* wp[5];    // packed 256x256
+    const float* wpT[5];   // packed transposed
+    const float* w6;       // [256]
+    const float* bias;     // [6][256]
+    const float* freq;     // [6][256]
+    const float* phase;    // [6][256]
+    const float* b6;       // [1]
+};
+
+constexpr int kSdfLd = 260;   // 256 + 4
+constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
+
+// sin/cos with a 3-term Cody-Waite reduction by pi/2 (exact product for |q| < 512) and the
+// classic single-precision minimax kernels on [-pi/4, pi/4]; ~1-2 ulp for |x| < 800, which covers
+// every SIREN pre-activation (|30 z| is O(10..100)); larger arguments take the libm path.
+__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
+    if (fabsf(x) > 500.0f) {
+        sincosf(x, &s, &c);
+        return;
+    }
+    const float q = rintf(x * 0.63661977236758134308f);
+    float r = fmaf(q, -1.57073974609375f, x);
+    r = fmaf(q, -5.657970905303955078125e-05f, r);
+    r = fmaf(q, -9.920936294705029468e-10f, r);
+    const float r2 = r * r;
+    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    ps = fmaf(ps, r2, -1.6666654611e-1f);
+    ps = fmaf(ps * r2, r, r);
+    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    pc = fmaf(pc, r2, 4.166664568298827e-2f);
+    pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
+    const int qi = (int)q;
+    const float ss = (qi & 1) ? pc : ps;
+    const float cc = (qi & 1) ? ps : pc;
+    s = (qi & 2) ? -ss : ss;
+    c = ((qi + 1) & 2) ? -cc : cc;
+}
+
+// h = sin(30 (f (v + b) + phi)),   dh/dv = 30 f cos(.)
+__device__ __forceinline__ void film_sine(const f32x4 v, const f32x4 b, const f32x4 f, const f32x4 p, f32x4& h,
+                                          f32x4& d, bool want_d) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float z = 30.0f * (f[r] * (v[r] + b[r]) + p[r]);
+        float s, c;
+        sincos_cw(z, s, c);
+        if (want_d) d[r] = c * (30.0f * f[r]);
+        h[r] = s;
+    }
+}
+
+// Forward trunk on a 64-point tile.  xin: LDS [64][4] normalised coords.  act: LDS [64][ld], receives h6.
+// GRAD: dact factors of layers 1..5 go to `spill` (global, this workgroup's private slab of
+// 5*8*8*64 f32x4), layer 6's stay in `dlast`.
+template <bool GRAD>
+__device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
+                                          f32x4 (&dlast)[kSdfMT][kNT], int wave, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const int mt0 = wave * kSdfMT;
+    // layer 1: K = 3 on the vector ALU, same accumulator ownership as the MFMA layers
+    {
+        f32x4 x[kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) x[n] = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            f32x4 w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + ch0);
+            const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + ch0);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(net.phase + ch0);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) {
+                f32x4 v, h, d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = w[r][0] * x[n][0] + w[r][1] * x[n][1] + w[r][2] * x[n][2];
+                film_sine(v, b, f, p, h, d, GRAD);
+                *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+                if (GRAD) spill[((0 * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane] = d;
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 1; k < 6; ++k) {
+        f32x4 acc[kSdfMT][kNT];
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<16, kSdfMT>(net.wp[k - 1], mt0, act, ld, acc, lane);
+        __syncthreads();   // everyone is done reading the layer input
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 256 + ch0);
+            const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0);
+            const f32x4 p = *reinterpret_cast<const f32x4*>(net.phase + k * 256 + ch0);
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) {
+                f32x4 h, d;
+                film_sine(acc[m][n], b, f, p, h, d, GRAD);
+                *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+                if (GRAD) {
+                    if (k < 5) spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane] = d;
+                    else dlast[m][n] = d;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// sdf[pt] = w6 . h6[pt] + b6  -> out[pt*ostride]; 8 threads per point.
+__device__ __forceinline__ void sdf_head(const SdfNet& net, const float* act, int ld, float* out, int ostride,
+                                         int tid) {
+    const int pt = tid >> 3, part = tid & 7;
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int ch = part + 8 * i;
+        s += net.w6[ch] * act[pt * ld + ch];
+    }
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    if (part == 0) out[pt * ostride] = s + net.b6[0];
+}
+
+// Reverse sweep for d sdf / d x on the tile (needs sdf_trunk<true> first).
+// bwd: LDS [64][ld] scratch (must not alias the feature buffer).  grad -> out[pt*ostride + 1..3].
+__device__ __forceinline__ void sdf_backward(const SdfNet& net, float* bwd, int ld, const f32x4* spill,
+                                             const f32x4 (&dlast)[kSdfMT][kNT], float* out, int ostride, int wave,
+                                             int lane, int tid) {
+    const int j = lane & 15, g = lane >> 4;
+    const int mt0 = wave * kSdfMT;
+#pragma unroll
+    for (int m = 0; m < kSdfMT; ++m) {
+        const int ch0 = (mt0 + m) * 16 + 4 * g;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(net.w6 + ch0);
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) *reinterpret_cast<f32x4*>(bwd + (n * 16 + j) * ld + ch0) = dlast[m][n] * w;
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 4; k >= 0; --k) {   // g_k+1 (layer index k, 0-based) = W_{k+2}^T u_{k+2}
+        f32x4 acc[kSdfMT][kNT];
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<16, kSdfMT>(net.wpT[k], mt0, bwd, ld, acc, lane);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) {
+                const f32x4 d = spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane];
+                *reinterpret_cast<f32x4*>(bwd + (n * 16 + j) * ld + ch0) = acc[m][n] * d;
+            }
+        }
+        __syncthreads();
+    }
+    // grad_c = sum_ch w0[ch][c] * u1[pt][ch]
+    const int pt = tid >> 3, part = tid & 7;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int ch = part + 8 * i;
+        const float u = bwd[pt * ld + ch];
+        const f32x4 w = *reinterpret_cast<const f32x4*>(net.w0 + ch * 4);
+        gx += w[0] * u;
+        gy += w[1] * u;
+        gz += w[2] * u;
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        gx += __shfl_xor(gx, o);
+        gy += __shfl_xor(gy, o);
+        gz += __shfl_xor(gz, o);
+    }
+    if (part == 0) {
+        out[pt * ostride + 1] = gx;
+        out[pt * ostride + 2] = gy;
+        out[pt * ostride + 3] = gz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// skinning network: 3 -> 128 x4 -> 25, Softplus(beta = 100)
+// ------------------------------------------------------------------------------------------
+struct SkinNet {
+    const float* w0;      // [128][4]
+    const float* wp[3];   // packed 128x128
+    const float* w4p;     // packed [32][128]
+    const float* bias;    // [4][128] + [32]
+};
+
+constexpr int kSkinLd = 132;
+constexpr int kLogitLd = 33;
+
+__device__ __forceinline__ float softplus100(float x) {
+    const float bx = 100.0f * x;
+    return bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
+}
+
+// xin LDS [64][4] normalised coords -> logits LDS [64][kLogitLd] (25 valid, un-scaled)
+__device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, float* act, float* logits, int wave,
+                                         int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const int ld = kSkinLd;
+    {
+        const int ch0 = wave * 16 + 4 * g;
+        f32x4 w[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + ch0);
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = softplus100(w[r][0] * x[0] + w[r][1] * x[1] + w[r][2] * x[2] + b[r]);
+            *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 1; k < 4; ++k) {
+        f32x4 acc[1][kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
+        gemm_acc<8, 1>(net.wp[k - 1], wave, act, ld, acc, lane);
+        __syncthreads();
+        const int ch0 = wave * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = softplus100(acc[0][n][r] + b[r]);
+            *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+        }
+        __syncthreads();
+    }
+    {   // output layer 128 -> 25 (padded 32): wave w computes M-tile (w & 1) of N-tile (w >> 1)
+        const int mt = wave & 1, nt = wave >> 1;
+        const f32x4 acc = gemm_one<8>(net.w4p, mt, nt, act, ld, lane);
+        const int ch0 = mt * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + 4 * 128 + ch0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) logits[(nt * 16 + j) * kLogitLd + ch0 + r] = acc[r] + b[r];
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// colour network: [feat(256), x(3), n(3), (PE4(view) 27)] -> 256 -> 256 -> 128 -> (+in) 256 -> 256 -> 3
+// ------------------------------------------------------------------------------------------
+struct ColNet {
+    const float* w0p;
+    const float* w1p;
+    const float* w2p;
+    const float* w3ap;
+    const float* w3bp;
+    const float* w4p;
+    const float* w5;     // [3][256]
+    const float* bias;   // b0'[256] b1[256] b2[128] b3'[256] b4[256] b5[4]
+};
+
+template <bool IDR>
+struct ColDims {
+    static constexpr int kExtra = IDR ? 33 : 6;
+    static constexpr int kIn = 256 + kExtra;
+    static constexpr int kKC0 = (kIn + 15) / 16;       // 19 / 17
+    static constexpr int kInPad = kKC0 * 16;           // 304 / 272
+    static constexpr int kLdA = kInPad + 4;
+};
+
+template <int MT>
+__device__ __forceinline__ void relu_store(const f32x4 (&acc)[MT][kNT], const float* bias, float* dst, int ld,
+                                           int mt0, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ch0 = (mt0 + m) * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[m][n][r] + b[r], 0.f);
+            *reinterpret_cast<f32x4*>(dst + (n * 16 + j) * ld + ch0) = h;
+        }
+    }
+}
+
+// A: LDS [64][kLdA] full input (feature in cols 0..255, extras after, zero padded); B: LDS [64][260].
+// rgb (after sigmoid) -> out[pt*ostride + 0..2].  Needs a barrier between the writers of A and the call.
+template <bool IDR>
+__device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, float* B, float* out, int ostride,
+                                          int wave, int lane, int tid) {
+    typedef ColDims<IDR> D;
+    constexpr int ldB = kSdfLd;
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<D::kKC0, 2>(net.w0p, wave * 2, A, D::kLdA, acc, lane);
+        relu_store<2>(acc, net.bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<16, 2>(net.w1p, wave * 2, B, ldB, acc, lane);
+        __syncthreads();
+        relu_store<2>(acc, net.bias + 256, B, ldB, wave * 2, lane);
+    }
+    __syncthreads();
+    {
+        f32x4 acc[1][kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
+        gemm_acc<16, 1>(net.w2p, wave, B, ldB, acc, lane);
+        __syncthreads();
+        relu_store<1>(acc, net.bias + 512, B, ldB, wave, lane);   // cols 0..127
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<D::kKC0, 2>(net.w3ap, wave * 2, A, D::kLdA, acc, lane);
+        gemm_acc<8, 2>(net.w3bp, wave * 2, B, ldB, acc, lane);
+        __syncthreads();
+        relu_store<2>(acc, net.bias + 640, B, ldB, wave * 2, lane);
+    }
+    __syncthreads();
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<16, 2>(net.w4p, wave * 2, B, ldB, acc, lane);
+        __syncthreads();
+        relu_store<2>(acc, net.bias + 896, B, ldB, wave * 2, lane);
+    }
+    __syncthreads();
+    {
+        const int pt = tid >> 3, part = tid & 7;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int ch = part + 8 * i;
+            const float h = B[pt * ldB + ch];
+            c0 += net.w5[ch] * h;
+            c1 += net.w5[256 + ch] * h;
+            c2 += net.w5[512 + ch] * h;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            c0 += __shfl_xor(c0, o);
+            c1 += __shfl_xor(c1, o);
+            c2 += __shfl_xor(c2, o);
+        }
+        if (part == 0) {
+            out[pt * ostride + 0] = 1.0f / (1.0f + expf(-(c0 + net.bias[1152 + 0])));
+            out[pt * ostride + 1] = 1.0f / (1.0f + expf(-(c1 + net.bias[1152 + 1])));
+            out[pt * ostride + 2] = 1.0f / (1.0f + expf(-(c2 + net.bias[1152 + 2])));
+        }
+    }
+}
+
+}  // namespace arah

@@ -1,0 +1,371 @@
+"""ctypes binding of the C ABI in include/arah_hip.h (libarah_hip.so, built by __graft_entry__.build()).
+
+Only raw device pointers, sizes and the current HIP stream cross the boundary; torch is used for
+device memory and streams.  There is NO fallback: if the shared library is missing or no GPU is
+present, every entry point raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libarah_hip.so")
+
+ARAH_MAX_STEPS = 128
+COLOR_NO_VIEW_DIR = 0
+COLOR_IDR = 1
+
+_ERRORS = {-1: "ARAH_E_BADARG", -2: "ARAH_E_SHAPE", -3: "ARAH_E_WORKSPACE", -4: "ARAH_E_LAUNCH",
+           -5: "ARAH_E_SAMPLING"}
+
+_fp = C.c_void_p  # device float*
+
+
+class ArahNets(C.Structure):
+    _fields_ = [("sdf_w", _fp * 7), ("sdf_b", _fp * 7), ("film_freq", _fp), ("film_phase", _fp),
+                ("skin_w", _fp * 5), ("skin_b", _fp * 5), ("col_w", _fp * 6), ("col_b", _fp * 6),
+                ("pose_vec", _fp), ("col_mode", C.c_int32), ("n_pose", C.c_int32), ("beta", C.c_float)]
+
+
+class ArahBody(C.Structure):
+    _fields_ = [("verts", _fp), ("vert_weights", _fp), ("bones", _fp), ("trans", C.c_float * 3),
+                ("center", C.c_float * 3), ("coord_min", C.c_float), ("coord_max", C.c_float),
+                ("n_verts", C.c_int32)]
+
+
+class ArahSampling(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("n_near", C.c_int32), ("n_far", C.c_int32),
+                ("cano_view_dirs", C.c_int32), ("render_last_pt", C.c_int32),
+                ("lin_steps", _fp), ("lin_near", _fp), ("lin_far", _fp)]
+
+
+class ArahFrame(C.Structure):
+    _fields_ = [("sdf_w0", _fp), ("sdf_wp", _fp * 5), ("sdf_wpT", _fp * 5), ("sdf_w6", _fp), ("sdf_b6", _fp),
+                ("sdf_bias", _fp), ("sdf_freq", _fp), ("sdf_phase", _fp),
+                ("skin_w0", _fp), ("skin_wp", _fp * 3), ("skin_w4p", _fp), ("skin_bias", _fp),
+                ("col_w0p", _fp), ("col_w1p", _fp), ("col_w2p", _fp), ("col_w3ap", _fp), ("col_w3bp", _fp),
+                ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
+                ("verts4", _fp), ("vert_weights", _fp), ("bones", _fp),
+                ("beta", C.c_float), ("trans", C.c_float * 3), ("center", C.c_float * 3),
+                ("coord_min", C.c_float), ("coord_max", C.c_float), ("n_verts", C.c_int32),
+                ("col_mode", C.c_int32)]
+
+
+class ArahCounters(C.Structure):
+    _fields_ = [("n_sdf_fwd", C.c_uint64), ("n_sdf_grad", C.c_uint64), ("n_skin_fwd", C.c_uint64),
+                ("n_skin_jac", C.c_uint64), ("n_col", C.c_uint64), ("n_knn", C.c_uint64),
+                ("reserved", C.c_uint64 * 2)]
+
+
+EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
+           "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
+           "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_trace", "arah_sample_canonicalize",
+           "arah_shade_composite", "arah_render", "arah_dominant_kernel"]
+
+_lib = None
+
+
+def load_library():
+    """dlopen libarah_hip.so (after torch, so that it binds to the HIP runtime torch already loaded)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libarah_hip.so is not built (%s): run `python -c 'import __graft_entry__ as g; "
+                           "g.build()'` -- there is no CPU fallback for the hot path" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.arah_frame_bytes.restype = C.c_size_t
+    lib.arah_workspace_bytes.restype = C.c_size_t
+    lib.arah_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
+    lib.arah_dominant_kernel.restype = C.c_char_p
+    for name in EXPORTS:
+        getattr(lib, name)  # AttributeError if the symbol is missing
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (%d)" % (what, _ERRORS.get(rc, "?"), rc))
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return C.c_void_p(t.data_ptr())
+
+
+def _f32(t):
+    return t.detach().to(dtype=torch.float32).contiguous()
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("arah_release_amd needs a HIP device (MI355X / gfx950); none is visible and there "
+                           "is no CPU fallback")
+
+
+class Workspace:
+    """Caller-owned scratch of the C ABI (grows on demand, never shrinks)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def ensure(self, n_rays, n_steps):
+        need = load_library().arah_workspace_bytes(int(n_rays), int(n_steps))
+        if self.buf is None or self.buf.numel() < need:
+            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+            load_library().arah_counters_reset(_ptr(self.buf), _stream())
+        return self.buf
+
+    def reset_counters(self):
+        _check(load_library().arah_counters_reset(_ptr(self.buf), _stream()), "arah_counters_reset")
+
+    def counters(self):
+        out = ArahCounters()
+        _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream()), "arah_counters_read")
+        return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn")}
+
+
+class Frame:
+    """Packed per-frame state on the device (MFMA-ordered weights, padded vertices)."""
+
+    def __init__(self, sdf_layers, film_freq, film_phase, skin_layers, color_layers, color_mode, pose_vec, beta,
+                 verts, vert_weights, bones, trans, center, coord_min, coord_max):
+        require_gpu()
+        lib = load_library()
+        dev = verts.device
+        keep = []  # tensors referenced by raw pointers must outlive the call
+
+        def own(t):
+            t = _f32(t)
+            keep.append(t)
+            return t
+
+        nets = ArahNets()
+        if color_layers is None:   # tracer-only use: the colour MLP is never evaluated
+            color_mode, pose_vec = COLOR_NO_VIEW_DIR, None
+            dims = [(256, 262), (256, 256), (128, 256), (256, 390), (256, 256), (3, 256)]
+            color_layers = [(torch.zeros(d, device=dev), torch.zeros(d[0], device=dev)) for d in dims]
+        if len(sdf_layers) != 7 or len(skin_layers) != 5 or len(color_layers) != 6:
+            raise ValueError("unsupported network depth (ARAH_E_SHAPE)")
+        shapes_sdf = [(256, 3)] + [(256, 256)] * 5 + [(1, 256)]
+        for i, (w, b) in enumerate(sdf_layers):
+            if tuple(w.shape) != shapes_sdf[i]:
+                raise ValueError("SDF layer %d has shape %s, expected %s" % (i, tuple(w.shape), shapes_sdf[i]))
+            nets.sdf_w[i] = _ptr(own(w)).value
+            nets.sdf_b[i] = _ptr(own(b)).value
+        nets.film_freq = _ptr(own(film_freq.reshape(-1)))
+        nets.film_phase = _ptr(own(film_phase.reshape(-1)))
+        shapes_skin = [(128, 3)] + [(128, 128)] * 3 + [(25, 128)]
+        for i, (w, b) in enumerate(skin_layers):
+            if tuple(w.shape) != shapes_skin[i]:
+                raise ValueError("skinning layer %d has shape %s, expected %s" % (i, tuple(w.shape), shapes_skin[i]))
+            nets.skin_w[i] = _ptr(own(w)).value
+            nets.skin_b[i] = _ptr(own(b)).value
+        n_pose = 0 if pose_vec is None else int(pose_vec.numel())
+        in_dim = (33 if color_mode == COLOR_IDR else 6) + 256 + n_pose
+        shapes_col = [(256, in_dim), (256, 256), (128, 256), (256, in_dim + 128), (256, 256), (3, 256)]
+        for i, (w, b) in enumerate(color_layers):
+            if tuple(w.shape) != shapes_col[i]:
+                raise ValueError("colour layer %d has shape %s, expected %s" % (i, tuple(w.shape), shapes_col[i]))
+            nets.col_w[i] = _ptr(own(w)).value
+            nets.col_b[i] = _ptr(own(b)).value
+        nets.pose_vec = _ptr(own(pose_vec.reshape(-1))) if n_pose else None
+        nets.col_mode = int(color_mode)
+        nets.n_pose = n_pose
+        nets.beta = float(beta)
+        body = ArahBody()
+        self.verts, self.vert_weights, self.bones = own(verts), own(vert_weights), own(bones.reshape(24, 16))
+        body.verts, body.vert_weights, body.bones = _ptr(self.verts), _ptr(self.vert_weights), _ptr(self.bones)
+        for i in range(3):
+            body.trans[i] = float(trans[i])
+            body.center[i] = float(center[i])
+        body.coord_min, body.coord_max = float(coord_min), float(coord_max)
+        body.n_verts = int(verts.shape[0])
+        nbytes = lib.arah_frame_bytes(C.byref(nets), C.byref(body))
+        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.handle = ArahFrame()
+        _check(lib.arah_prepare_frame(C.byref(nets), C.byref(body), _ptr(self.buf), C.c_size_t(nbytes),
+                                      C.byref(self.handle), _stream()), "arah_prepare_frame")
+        # the pack kernels read `keep` asynchronously on the current stream; hold the raw tensors
+        # until the frame is dropped (cheap: a few MB)
+        self._keep = keep
+        self.device = dev
+        self.color_mode = int(color_mode)
+
+
+class Sampling:
+    """ArahSampling + the device linspace tables (bit-identical to torch.linspace on the CPU)."""
+
+    def __init__(self, device, n_steps=64, n_near=16, n_far=16, cano_view_dirs=True, render_last_pt=False):
+        if n_steps < n_near + n_far + 1 or n_steps > ARAH_MAX_STEPS:
+            raise ValueError("need n_near + n_far + 1 <= n_steps <= %d (ARAH_E_SAMPLING)" % ARAH_MAX_STEPS)
+        self.lin_steps = torch.linspace(0.0, 1.0, n_steps, dtype=torch.float32).to(device)
+        self.lin_near = torch.linspace(0.0, 1.0, n_near + 1, dtype=torch.float32).to(device)
+        self.lin_far = torch.linspace(0.0, 1.0, max(n_far, 1), dtype=torch.float32).to(device)
+        s = ArahSampling()
+        s.n_steps, s.n_near, s.n_far = int(n_steps), int(n_near), int(n_far)
+        s.cano_view_dirs, s.render_last_pt = int(bool(cano_view_dirs)), int(bool(render_last_pt))
+        s.lin_steps, s.lin_near, s.lin_far = _ptr(self.lin_steps), _ptr(self.lin_near), _ptr(self.lin_far)
+        self.handle = s
+        self.n_steps, self.n_near, self.n_far = n_steps, n_near, n_far
+
+
+# ------------------------------------------------------------------------------------------------
+# thin functional wrappers (allocate outputs with torch, call the C ABI on the current stream)
+# ------------------------------------------------------------------------------------------------
+def sdf_eval(frame, ws, x_norm, want_feat=False, want_grad=False):
+    lib = load_library()
+    x = _f32(x_norm)
+    n = x.shape[0]
+    buf = ws.ensure(1, 1)
+    sdf = torch.empty(n, device=x.device)
+    feat = torch.empty(n, 256, device=x.device) if want_feat else None
+    grad = torch.empty(n, 3, device=x.device) if want_grad else None
+    _check(lib.arah_sdf_eval(C.byref(frame.handle), _ptr(x), C.c_int32(n), _ptr(sdf), _ptr(feat), _ptr(grad),
+                             _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_sdf_eval")
+    return sdf, feat, grad
+
+
+def skin_lbs(frame, ws, x_hat):
+    lib = load_library()
+    x = _f32(x_hat)
+    n = x.shape[0]
+    buf = ws.ensure(1, 1)
+    w = torch.empty(n, 24, device=x.device)
+    xb = torch.empty(n, 3, device=x.device)
+    T = torch.empty(n, 4, 4, device=x.device)
+    _check(lib.arah_skin_lbs(C.byref(frame.handle), _ptr(x), C.c_int32(n), _ptr(w), _ptr(xb), _ptr(T), _ptr(buf),
+                             C.c_size_t(buf.numel()), _stream()), "arah_skin_lbs")
+    return w, xb, T
+
+
+def skin_jacobian(frame, ws, x_hat):
+    lib = load_library()
+    x = _f32(x_hat)
+    n = x.shape[0]
+    buf = ws.ensure(1, 1)
+    jac = torch.empty(n, 3, 3, device=x.device)
+    _check(lib.arah_skin_jacobian(C.byref(frame.handle), _ptr(x), C.c_int32(n), _ptr(jac), _ptr(buf),
+                                  C.c_size_t(buf.numel()), _stream()), "arah_skin_jacobian")
+    return jac
+
+
+def color_eval(frame, ws, x_norm, normal, view, feat):
+    lib = load_library()
+    x, nr, ft = _f32(x_norm), _f32(normal), _f32(feat)
+    vw = _f32(view) if view is not None else None
+    n = x.shape[0]
+    buf = ws.ensure(1, 1)
+    rgb = torch.empty(n, 3, device=x.device)
+    _check(lib.arah_color_eval(C.byref(frame.handle), _ptr(x), _ptr(nr), _ptr(vw), _ptr(ft), C.c_int32(n), _ptr(rgb),
+                               _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_color_eval")
+    return rgb
+
+
+def nearest_inverse_lbs(frame, ws, pts):
+    lib = load_library()
+    p = _f32(pts)
+    n = p.shape[0]
+    buf = ws.ensure(1, 1)
+    idx = torch.empty(n, dtype=torch.int32, device=p.device)
+    x0 = torch.empty(n, 3, device=p.device)
+    T0 = torch.empty(n, 4, 4, device=p.device)
+    _check(lib.arah_nearest_inverse_lbs(C.byref(frame.handle), _ptr(p), C.c_int32(n), _ptr(idx), _ptr(x0), _ptr(T0),
+                                        _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_nearest_inverse_lbs")
+    return idx, x0, T0
+
+
+def broyden3_lbs(frame, ws, tgt, x0, T0):
+    lib = load_library()
+    tgt, x0, T0 = _f32(tgt), _f32(x0), _f32(T0)
+    n = tgt.shape[0]
+    buf = ws.ensure(n, 1)
+    x = torch.empty(n, 3, device=tgt.device)
+    T = torch.empty(n, 4, 4, device=tgt.device)
+    err = torch.empty(n, device=tgt.device)
+    conv = torch.empty(n, dtype=torch.uint8, device=tgt.device)
+    _check(lib.arah_broyden3_lbs(C.byref(frame.handle), _ptr(tgt), _ptr(x0), _ptr(T0), C.c_int32(n), _ptr(x), _ptr(T),
+                                 _ptr(err), _ptr(conv), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
+           "arah_broyden3_lbs")
+    return x, T, err, conv.bool()
+
+
+def trace(frame, ws, cam_loc, dirs, near_far):
+    """cam_loc (B,3), dirs (B*N,3) flat, near_far (B*N,2) -> x_norm, T, conv, start, end."""
+    lib = load_library()
+    cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
+    n = d.shape[0]
+    buf = ws.ensure(n, 1)
+    dev = d.device
+    xn = torch.empty(n, 3, device=dev)
+    T = torch.empty(n, 4, 4, device=dev)
+    conv = torch.empty(n, dtype=torch.uint8, device=dev)
+    start = torch.empty(n, device=dev)
+    end = torch.empty(n, device=dev)
+    _check(lib.arah_trace(C.byref(frame.handle), _ptr(cam), C.c_int32(n // cam.shape[0]), _ptr(d), _ptr(nf),
+                          C.c_int32(n), _ptr(xn), _ptr(T), _ptr(conv), _ptr(start), _ptr(end), _ptr(buf),
+                          C.c_size_t(buf.numel()), _stream()), "arah_trace")
+    return xn, T, conv, start, end
+
+
+def sample_canonicalize(frame, ws, sampling, cam_loc, dirs, near_far, conv, start, end):
+    lib = load_library()
+    cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
+    n, S = d.shape[0], sampling.n_steps
+    buf = ws.ensure(n, S)
+    dev = d.device
+    z = torch.empty(n, S, device=dev)
+    pts = torch.empty(n, S, 3, device=dev)
+    T = torch.empty(n, S, 4, 4, device=dev)
+    mask = torch.empty(n, S, dtype=torch.uint8, device=dev)
+    _check(lib.arah_sample_canonicalize(C.byref(frame.handle), C.byref(sampling.handle), _ptr(cam),
+                                        C.c_int32(n // cam.shape[0]), _ptr(d), _ptr(nf), _ptr(conv.contiguous()),
+                                        _ptr(_f32(start)), _ptr(_f32(end)), C.c_int32(n), _ptr(z), _ptr(pts), _ptr(T),
+                                        _ptr(mask), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
+           "arah_sample_canonicalize")
+    return z, pts, T, mask
+
+
+def shade_composite(frame, ws, sampling, dirs, z, pts, T, mask):
+    lib = load_library()
+    d = _f32(dirs)
+    n, S = d.shape[0], sampling.n_steps
+    buf = ws.ensure(n, S)
+    dev = d.device
+    rgb = torch.empty(n, 3, device=dev)
+    acc = torch.empty(n, device=dev)
+    vol = torch.empty(n, dtype=torch.uint8, device=dev)
+    _check(lib.arah_shade_composite(C.byref(frame.handle), C.byref(sampling.handle), _ptr(d), _ptr(_f32(z)),
+                                    _ptr(_f32(pts)), _ptr(_f32(T)), _ptr(mask.contiguous()), C.c_int32(n), _ptr(rgb),
+                                    _ptr(acc), _ptr(vol), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
+           "arah_shade_composite")
+    return rgb, acc, vol
+
+
+def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):
+    """Whole eval forward. pose34: host (3,4) world->camera. Returns rgb, points_cam, vol_mask, acc, dists, conv."""
+    lib = load_library()
+    cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
+    n, S = d.shape[0], sampling.n_steps
+    buf = ws.ensure(n, S)
+    dev = d.device
+    rgb = torch.empty(n, 3, device=dev)
+    pcam = torch.empty(n, 3, device=dev)
+    vol = torch.empty(n, dtype=torch.uint8, device=dev)
+    acc = torch.empty(n, device=dev)
+    dists = torch.empty(n, device=dev)
+    conv = torch.empty(n, dtype=torch.uint8, device=dev)
+    h_pose = (C.c_float * 12)(*[float(v) for v in pose34.reshape(-1)[:12]])
+    _check(lib.arah_render(C.byref(frame.handle), C.byref(sampling.handle), _ptr(cam), C.c_int32(n // cam.shape[0]),
+                           _ptr(d), _ptr(nf), h_pose, C.c_int32(n), _ptr(rgb), _ptr(pcam), _ptr(vol), _ptr(acc),
+                           _ptr(dists), _ptr(conv), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_render")
+    return rgb, pcam, vol, acc, dists, conv

@@ -1,0 +1,430 @@
+"""Host-side (PyTorch) parameter containers of the ARAH hot path.
+
+These modules own the learnable parameters under the *same state-dict names* as
+the reference so that its Lightning checkpoints load unchanged
+(reference: im2mesh/metaavatar_render/config.py:291-300 strips the ``model.``
+prefix and calls ``load_state_dict(strict=False)``):
+
+    sdf_decoder.net.layers.{0..5}.hyper_linear.hypo_params.net.{0,1}.net.{0,1}.{weight,bias}
+    sdf_decoder.net.layers.{0..5}.hyper_linear.hypo_params.net.2.{weight,bias}
+    sdf_decoder.net.layers.{0..5}.hyper_linear.hypo_params_init
+    sdf_decoder.net.layers.6.hypo_params...            (last, sine-free layer)
+    sdf_decoder.net.mapping_network.network.{0,2,4,6}.{weight,bias}
+    sdf_decoder.pose_encoder.layer_0 / .layers.{0..23}.{0,2}
+    skinning_model.skinning_decoder_fwd.lin{0..4}.{weight_g,weight_v,bias}
+    color_decoder.lin{0..5}.{weight_g,weight_v,bias}
+    deviation_decoder.variance,  latent.weight
+
+What is evaluated per *sample* (SDF MLP, skinning MLP, colour MLP) runs in the
+HIP kernels (csrc/); the modules here are evaluated once per frame (the
+hypernetwork that emits the SDF MLP, reference siren_modules.py:280-316 and
+hyperlayers.py:270-285,497-510) or only export folded weight tensors.
+The torch ``forward`` of the per-sample networks is kept because the training
+path differentiates through them with autograd.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+# SMPL kinematic tree (parent of each of the 24 joints); data, same table as
+# reference siren_modules.py:204-205.
+SMPL_PARENTS = (-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21)
+
+
+# --------------------------------------------------------------------------------------
+# emitted (per-frame) SDF network
+# --------------------------------------------------------------------------------------
+class Sine(nn.Module):
+    """sin(30 x) (reference siren_modules.py:31-37)."""
+
+    def forward(self, x):
+        return torch.sin(30.0 * x)
+
+
+class EmittedLinear(nn.Module):
+    """x @ W^T + b with W (1,out,in), b (1,1,out) emitted by the hypernetwork
+    (reference hyperlayers.py:368-388)."""
+
+    def __init__(self, weights, biases):
+        super().__init__()
+        self.weights = weights
+        self.biases = biases
+
+    def forward(self, x):
+        return torch.matmul(x, self.weights.transpose(-1, -2)) + self.biases
+
+
+class EmittedFiLMLinear(EmittedLinear):
+    """freq * (x @ W^T + b) + phase (reference hyperlayers.py:391-415)."""
+
+    def __init__(self, weights, biases, freq, phase_shift):
+        super().__init__(weights, biases)
+        self.freq = freq
+        self.phase_shift = phase_shift
+
+    def forward(self, x):
+        return self.freq * super().forward(x) + self.phase_shift
+
+
+# --------------------------------------------------------------------------------------
+# hypernetwork
+# --------------------------------------------------------------------------------------
+class _NormedLinear(nn.Module):
+    """Linear -> LayerNorm -> ReLU, stored as ``net.{0,1,2}`` (pytorch_prototyping FCLayer)."""
+
+    def __init__(self, n_in, n_out):
+        super().__init__()
+        self.net = nn.Sequential(nn.Linear(n_in, n_out), nn.LayerNorm([n_out]), nn.ReLU(inplace=True))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class _HyperHead(nn.Module):
+    """cond(144) -> 256 -> 256 -> n_out, stored as ``net.{0,1,2}``
+    (pytorch_prototyping FCBlock with one hidden layer and a linear output)."""
+
+    def __init__(self, n_in, n_hidden, n_out):
+        super().__init__()
+        self.net = nn.Sequential(_NormedLinear(n_in, n_hidden), _NormedLinear(n_hidden, n_hidden),
+                                 nn.Linear(n_hidden, n_out))
+        for m in self.net.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, a=0.0, nonlinearity="relu", mode="fan_in")
+        # residual head starts at zero: emitted params == hypo_params_init (hyperlayers.py:418-423)
+        nn.init.zeros_(self.net[2].weight)
+        nn.init.zeros_(self.net[2].bias)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class HyperLinear(nn.Module):
+    """Emits one linear layer (W, b) of the SDF MLP from the pose condition."""
+
+    def __init__(self, in_ch, out_ch, hyper_in_ch=144, hyper_hidden_ch=256):
+        super().__init__()
+        self.in_ch, self.out_ch = in_ch, out_ch
+        self.register_buffer("hypo_params_init", torch.zeros(1, in_ch * out_ch + out_ch))
+        self.hypo_params = _HyperHead(hyper_in_ch, hyper_hidden_ch, in_ch * out_ch + out_ch)
+
+    def emit(self, cond):
+        p = self.hypo_params(cond) + self.hypo_params_init
+        nw = self.in_ch * self.out_ch
+        w = p[..., :nw].reshape(*p.shape[:-1], self.out_ch, self.in_ch)
+        b = p[..., nw:nw + self.out_ch].reshape(*p.shape[:-1], 1, self.out_ch)
+        return w, b
+
+    def forward(self, cond):
+        return EmittedLinear(*self.emit(cond))
+
+
+class HyperLinearFiLM(HyperLinear):
+    def forward(self, cond, freq, phase_shift):
+        w, b = self.emit(cond)
+        return EmittedFiLMLinear(w, b, freq, phase_shift)
+
+
+class HyperLayerFiLM(nn.Module):
+    def __init__(self, in_ch, out_ch, **kw):
+        super().__init__()
+        self.hyper_linear = HyperLinearFiLM(in_ch, out_ch, **kw)
+
+    def forward(self, cond, freq, phase_shift):
+        return nn.Sequential(self.hyper_linear(cond, freq, phase_shift), Sine())
+
+
+class MappingNetwork(nn.Module):
+    """latent(128) -> FiLM frequencies / phase shifts (reference hyperlayers.py:107-139)."""
+
+    def __init__(self, z_dim, hidden, n_out):
+        super().__init__()
+        self.network = nn.Sequential(nn.Linear(z_dim, hidden), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(hidden, hidden), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(hidden, hidden), nn.LeakyReLU(0.2, inplace=True),
+                                     nn.Linear(hidden, n_out))
+        for m in self.network:
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight, a=0.2, mode="fan_in", nonlinearity="leaky_relu")
+        with torch.no_grad():  # identity FiLM at init: freq = 1, phase = 0
+            self.network[-1].weight.zero_()
+            self.network[-1].bias[:n_out // 2] = 1.0
+            self.network[-1].bias[n_out // 2:] = 0.0
+
+    def forward(self, z):
+        out = self.network(z)
+        half = out.shape[-1] // 2
+        return out[..., :half], out[..., half:]
+
+
+class HyperFCFiLM(nn.Module):
+    """Hypernetwork emitting in_ch -> hidden x (num_hidden_layers+1) -> out_ch FiLM-SIREN."""
+
+    def __init__(self, hyper_in_ch, hidden_ch, num_hidden_layers, in_ch, out_ch):
+        super().__init__()
+        kw = dict(hyper_in_ch=hyper_in_ch, hyper_hidden_ch=256)
+        self.hidden_ch = hidden_ch
+        layers = [HyperLayerFiLM(in_ch, hidden_ch, **kw)]
+        layers += [HyperLayerFiLM(hidden_ch, hidden_ch, **kw) for _ in range(num_hidden_layers)]
+        layers += [HyperLinear(hidden_ch, out_ch, **kw)]
+        self.layers = nn.ModuleList(layers)
+        self.mapping_network = MappingNetwork(128, 256, (len(layers) - 1) * hidden_ch * 2)
+
+    def forward(self, cond, latent_code):
+        freqs, phases = self.mapping_network(latent_code)
+        mods = []
+        h = self.hidden_ch
+        for i, layer in enumerate(self.layers[:-1]):
+            mods.append(layer(cond, freqs[..., i * h:(i + 1) * h], phases[..., i * h:(i + 1) * h]))
+        mods.append(self.layers[-1](cond))
+        return nn.Sequential(*mods)
+
+
+class HierarchicalPoseEncoder(nn.Module):
+    """LEAP-style encoder: (rots (B,24,9), Jtrs (B,24,3)) -> (B,144)
+    (reference siren_modules.py:196-244)."""
+
+    def __init__(self, num_joints=24, rel_joints=False, **kwargs):
+        super().__init__()
+        self.num_joints = num_joints
+        self.rel_joints = rel_joints
+        self.parents = SMPL_PARENTS
+        self.layer_0 = nn.Linear(12 * num_joints, 6)
+        self.layers = nn.ModuleList([nn.Sequential(nn.Linear(19, 19), nn.ReLU(), nn.Linear(19, 6))
+                                     for _ in range(num_joints)])
+
+    def forward(self, rots, Jtrs):
+        B = rots.shape[0]
+        if self.rel_joints:
+            par = torch.as_tensor(self.parents[1:], device=Jtrs.device, dtype=torch.long)
+            Jtrs = torch.cat([Jtrs[:, :1], Jtrs[:, 1:] - Jtrs[:, par]], dim=1).detach()
+        glob = self.layer_0(torch.cat([rots.reshape(B, -1), Jtrs.reshape(B, -1)], dim=-1))
+        feats = []
+        for j in range(self.num_joints):
+            p = self.parents[j]
+            if p < 0:
+                ref, up = Jtrs[:, j], glob
+            else:
+                ref = Jtrs[:, j] if self.rel_joints else Jtrs[:, j] - Jtrs[:, p]
+                up = feats[p]
+            bone_len = ref.norm(dim=-1, keepdim=True)
+            feats.append(self.layers[j](torch.cat([rots[:, j], Jtrs[:, j], bone_len, up], dim=-1)))
+        return torch.cat(feats, dim=-1)
+
+
+class HyperBVPNet(nn.Module):
+    """Pose-conditioned hypernetwork for the canonical SDF (reference siren_modules.py:247-316).
+
+    forward(model_input) -> {'model_in','model_out','params','decoder'}; ``decoder`` is an
+    ``nn.Sequential`` of 6 x [EmittedFiLMLinear, Sine] + EmittedLinear, sliceable like the
+    reference's (IDR:336-337 uses ``sdf_network[:-1]`` / ``[-1]``).
+    """
+
+    def __init__(self, out_features=1, type="sine", in_features=2, hyper_in_ch=92, mode="mlp",
+                 hidden_features=256, num_hidden_layers=3, hierarchical_pose=False,
+                 rel_joints=False, use_FiLM=False, **kwargs):
+        super().__init__()
+        if type != "sine":
+            raise NotImplementedError("HyperBVPNet only supports sine activations")
+        if not (use_FiLM and hierarchical_pose):
+            raise NotImplementedError("only the FiLM + hierarchical-pose variant used by the ARAH "
+                                      "configs is implemented")
+        self.mode = mode
+        self.use_FiLM = use_FiLM
+        self.hierarchical_pose = hierarchical_pose
+        self.net = HyperFCFiLM(hyper_in_ch, hidden_features, num_hidden_layers, in_features, out_features)
+        self.pose_encoder = HierarchicalPoseEncoder(rel_joints=rel_joints)
+
+    def forward(self, model_input):
+        coords = model_input["coords"].clone().detach().requires_grad_(True)
+        if "rots_noise" in model_input:
+            model_input["rots"] = model_input["rots"] + model_input["rots_noise"]
+        cond = self.pose_encoder(model_input["rots"], model_input["Jtrs"])
+        latent = model_input.get("latent")
+        if latent is None:
+            raise NotImplementedError("FiLM SDF decoder needs a geometry latent code")
+        decoder = self.net(cond, latent)
+        out = decoder(coords)
+        B = coords.shape[0]
+        params = [decoder[i][0].weights.reshape(B, -1) for i in range(len(decoder) - 1)]
+        params.append(decoder[-1].weights.reshape(B, -1))
+        return {"model_in": coords, "model_out": out, "params": params, "decoder": decoder}
+
+
+# --------------------------------------------------------------------------------------
+# per-sample networks with learnable (not emitted) weights
+# --------------------------------------------------------------------------------------
+def _wn_linear(n_in, n_out, weight_norm):
+    lin = nn.Linear(n_in, n_out)
+    if weight_norm:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lin = nn.utils.weight_norm(lin)  # keeps reference names weight_g / weight_v
+    return lin
+
+
+def folded_weight(lin):
+    """Effective (out,in) weight of a (possibly weight-normed) linear layer: g * v / |v|_row."""
+    if hasattr(lin, "weight_g"):
+        v = lin.weight_v
+        return lin.weight_g * v / v.norm(dim=1, keepdim=True)
+    return lin.weight
+
+
+class Deformer(nn.Module):
+    """Forward-skinning MLP 3 -> 128 x4 -> 25, Softplus(beta=100)
+    (reference metaavatar/models/decoder.py:133-233; ARAH configs use no skip / no cond)."""
+
+    def __init__(self, d_in, d_out, d_hidden, n_layers, skip_in=(), cond_in=(), cond_dim=96,
+                 multires=0, bias=1.0, geometric_init=True, weight_norm=True, **kwargs):
+        super().__init__()
+        if multires > 0 or len(skip_in) or len(cond_in) or geometric_init:
+            raise NotImplementedError("only the plain weight-normed MLP used by the ARAH configs")
+        dims = [d_in] + [d_hidden] * n_layers + [d_out]
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            setattr(self, "lin%d" % l, _wn_linear(dims[l], dims[l + 1], weight_norm))
+        self.activation = nn.Softplus(beta=100)
+
+    def forward(self, p, c=None, **kwargs):
+        B, n, _ = p.shape
+        x = p.reshape(-1, p.shape[-1])
+        for l in range(self.num_layers - 1):
+            x = getattr(self, "lin%d" % l)(x)
+            if l < self.num_layers - 2:
+                x = self.activation(x)
+        return x.reshape(B, n, -1)
+
+    def export_weights(self):
+        """[(W (out,in), b (out,)), ...] fp32 contiguous, weight-norm folded."""
+        out = []
+        for l in range(self.num_layers - 1):
+            lin = getattr(self, "lin%d" % l)
+            out.append((folded_weight(lin).detach().float().contiguous(), lin.bias.detach().float().contiguous()))
+        return out
+
+
+class SkinningModel(nn.Module):
+    """Thin holder, ``decode_w(p, c, forward=True)`` (reference skinning_model.py:23-35)."""
+
+    def __init__(self, skinning_decoder_fwd=None, **kwargs):
+        super().__init__()
+        self.skinning_decoder_fwd = skinning_decoder_fwd
+
+    def forward(self):
+        raise NotImplementedError("You should not call the forward function of the skinning model.")
+
+    def decode_w(self, p, c=None, forward=True, **kwargs):
+        if not forward:
+            raise ValueError("This skinning model does not have backward networks.")
+        return self.skinning_decoder_fwd(p, c=c, **kwargs)
+
+
+def positional_encoding(x, n_freqs):
+    """NeRF embedding [x, sin(2^k x), cos(2^k x)]_k (reference embedder.py:6-51)."""
+    out = [x]
+    for k in range(n_freqs):
+        f = float(2 ** k)
+        out += [torch.sin(x * f), torch.cos(x * f)]
+    return torch.cat(out, dim=-1)
+
+
+class RenderingNetwork(nn.Module):
+    """Colour MLP (reference metaavatar_render/models/decoder.py:10-124)."""
+
+    def __init__(self, d_feature, mode, d_in, d_out, d_hidden, n_layers, weight_norm=True, multires=0,
+                 multires_view=0, skips=(), squeeze_out=True, rel_joints=True, pose_encoder="leap"):
+        super().__init__()
+        self.mode = mode
+        self.squeeze_out = squeeze_out
+        self.multires = multires
+        self.multires_view = multires_view
+        self.pose_encoder_type = pose_encoder
+        dims = [d_in + d_feature] + [d_hidden] * n_layers + [d_out]
+        if multires > 0:
+            dims[0] += 6 * multires
+        if multires_view > 0:
+            dims[0] += 6 * multires_view
+        if pose_encoder == "leap":
+            self.pose_encoder = HierarchicalPoseEncoder(rel_joints=rel_joints)
+        self.skips = list(skips)
+        for s in self.skips:
+            dims[s] = dims[s] // 2 + dims[0]
+        self.dims = dims
+        self.num_layers = len(dims)
+        for l in range(self.num_layers - 1):
+            n_out = dims[l + 1] - dims[0] if (l + 1) in self.skips else dims[l + 1]
+            setattr(self, "lin%d" % l, _wn_linear(dims[l], n_out, weight_norm))
+        self.relu = nn.ReLU()
+
+    def pose_vector(self, pose_feature):
+        """The per-frame constant tail of the input (1, n_pose) or None."""
+        t = self.pose_encoder_type
+        if t == "leap":
+            return self.pose_encoder(pose_feature["rots_full"][:1], pose_feature["Jtrs_posed"][:1])
+        if t in ("root", "hybrid"):
+            rot = pose_feature["rots_full"][:1, :1].reshape(1, 9)
+            tr = pose_feature["Jtrs_posed"][:1, :1].reshape(1, 3)
+            if "rot_noise" in pose_feature and "trans_noise" in pose_feature:
+                rot = rot + pose_feature["rot_noise"]
+                tr = tr + pose_feature["trans_noise"]
+            vec = torch.cat([rot, tr], dim=-1)
+            if t == "hybrid":
+                vec = torch.cat([vec, pose_feature["latent_code"]], dim=-1)
+            return vec
+        if t == "latent":
+            return pose_feature["latent_code"]
+        return None
+
+    def forward(self, points, normals, view_dirs, sdf_feature, pose_feature):
+        if self.multires > 0:
+            points = positional_encoding(points, self.multires)
+        if self.multires_view > 0:
+            view_dirs = positional_encoding(view_dirs, self.multires_view)
+        feat = sdf_feature
+        pv = self.pose_vector(pose_feature)
+        if pv is not None:
+            feat = torch.cat([feat, pv.expand(feat.shape[0], -1)], dim=-1)
+        if self.mode == "idr":
+            inp = torch.cat([points, view_dirs, normals, feat], dim=-1)
+        elif self.mode == "no_view_dir":
+            inp = torch.cat([points, normals, feat], dim=-1)
+        elif self.mode == "no_normal":
+            inp = torch.cat([points, view_dirs, feat], dim=-1)
+        else:
+            raise ValueError("unknown rendering mode %r" % self.mode)
+        x = inp
+        for l in range(self.num_layers - 1):
+            lin = getattr(self, "lin%d" % l)
+            x = lin(torch.cat([inp, x], dim=-1)) if l in self.skips else lin(x)
+            if l < self.num_layers - 2:
+                x = self.relu(x)
+        return torch.sigmoid(x) if self.squeeze_out else x
+
+    def export_weights(self):
+        out = []
+        for l in range(self.num_layers - 1):
+            lin = getattr(self, "lin%d" % l)
+            out.append((folded_weight(lin).detach().float().contiguous(), lin.bias.detach().float().contiguous()))
+        return out
+
+
+class SingleVarianceNetwork(nn.Module):
+    """Learnable VolSDF beta = |variance| (reference decoder.py:127-133)."""
+
+    def __init__(self, init_val):
+        super().__init__()
+        self.register_parameter("variance", nn.Parameter(torch.tensor(init_val)))
+
+    def forward(self, x):
+        return torch.ones_like(x) * torch.linalg.norm(self.variance)
+
+
+decoder_dict = {
+    "hyper_bvp": HyperBVPNet,
+    "deformer_mlp": Deformer,
+}

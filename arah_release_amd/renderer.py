@@ -1,0 +1,231 @@
+"""Drop-in counterparts of the reference's model / renderer classes, backed by the HIP kernels.
+
+Same constructors, same ``forward`` signatures, same dict-in / dict-out contract as
+
+    MetaAvatarRender   im2mesh/metaavatar_render/models/__init__.py:17-315
+    IDHRNetwork        im2mesh/metaavatar_render/renderer/implicit_differentiable_renderer.py:15-259
+    BodyRayTracing     im2mesh/metaavatar_render/renderer/ray_tracing.py:13-172
+
+(paths relative to the reference root).  The per-frame hypernetwork stays PyTorch; everything
+evaluated per ray / per sample goes through the C ABI (hip.py -> libarah_hip.so).  There is no
+torch implementation of the hot loops in this package: without the HIP library or without a GPU
+the forward raises.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import hip
+from .nets import folded_weight
+
+
+def _emitted_sdf_layers(sdf_network):
+    """nn.Sequential of 6 x [EmittedFiLMLinear, Sine] + EmittedLinear -> raw row-major tensors."""
+    n = len(sdf_network)
+    layers, freqs, phases = [], [], []
+    for i in range(n - 1):
+        lin = sdf_network[i][0]
+        layers.append((lin.weights[0], lin.biases.reshape(-1)))
+        freqs.append(lin.freq.reshape(-1))
+        phases.append(lin.phase_shift.reshape(-1))
+    last = sdf_network[n - 1]
+    layers.append((last.weights[0], last.biases.reshape(-1)))
+    return layers, torch.cat(freqs), torch.cat(phases)
+
+
+def _mlp_layers(module):
+    out = []
+    for l in range(module.num_layers - 1):
+        lin = getattr(module, "lin%d" % l)
+        out.append((folded_weight(lin), lin.bias))
+    return out
+
+
+def build_frame(sdf_network, skinning_model, rendering_network, deviation_network, pose_cond, smpl_verts,
+                skinning_weights, bone_transforms, trans, coord_min, coord_max, center):
+    """Pack one temporal frame for the kernels (weights emitted by the hypernetwork + body)."""
+    with torch.no_grad():
+        sdf_layers, freq, phase = _emitted_sdf_layers(sdf_network)
+        skin_layers = _mlp_layers(skinning_model.skinning_decoder_fwd)
+        color_layers, mode, pose_vec, beta = None, hip.COLOR_NO_VIEW_DIR, None, 1e-3
+        if rendering_network is not None:
+            rn = rendering_network
+            if rn.mode == "idr":
+                if rn.multires_view != 4 or rn.multires != 0:
+                    raise ValueError("kernels are built for multires_view=4, multires=0 (ARAH configs)")
+                mode = hip.COLOR_IDR
+            elif rn.mode == "no_view_dir":
+                if rn.multires != 0:
+                    raise ValueError("kernels are built for multires=0 (ARAH configs)")
+                mode = hip.COLOR_NO_VIEW_DIR
+            else:
+                raise ValueError("rendering mode %r is not used by any ARAH config" % rn.mode)
+            if list(rn.skips) != [3] or rn.num_layers != 7:
+                raise ValueError("kernels are built for the 5-hidden-layer colour MLP with a skip at 3")
+            color_layers = _mlp_layers(rn)
+            pose_vec = rn.pose_vector(pose_cond)
+            beta = float(torch.linalg.norm(deviation_network.variance))
+        return hip.Frame(sdf_layers, freq, phase, skin_layers, color_layers, mode, pose_vec, beta,
+                         smpl_verts[0], skinning_weights[0], bone_transforms[0], trans.reshape(-1)[:3].tolist(),
+                         center.reshape(-1)[:3].tolist(), float(coord_min.reshape(-1)[0]),
+                         float(coord_max.reshape(-1)[0]))
+
+
+class BodyRayTracing(nn.Module):
+    """Ray tracer for the articulated SDF: sphere tracing + joint root finding, then depth sampling
+    and per-sample canonicalisation (reference ray_tracing.py:13-172)."""
+
+    def __init__(self, root_finding_threshold=1.0e-5, sphere_tracing_iters=50, n_steps=64,
+                 near_surface_vol_samples=16, far_surface_vol_samples=16, surface_vol_range=0.05,
+                 sample_bg_pts=0, low_vram=False):
+        super().__init__()
+        if (root_finding_threshold, sphere_tracing_iters, surface_vol_range) != (1.0e-5, 50, 0.05):
+            raise ValueError("the kernels hard-wire threshold 1e-5, 50 sphere-tracing steps and a 5 cm "
+                             "surface range, like every ARAH config")
+        self.root_finding_threshold = root_finding_threshold
+        self.sphere_tracing_iters = sphere_tracing_iters
+        self.n_steps = n_steps
+        self.near_surface_vol_samples = near_surface_vol_samples
+        self.far_surface_vol_samples = far_surface_vol_samples
+        self.surface_vol_range = surface_vol_range
+        self.sample_bg_pts = sample_bg_pts
+        self.low_vram = low_vram
+        self._ws = None
+        self._sampling = {}
+
+    def workspace(self, device):
+        if self._ws is None or self._ws.device != device:
+            self._ws = hip.Workspace(device)
+        return self._ws
+
+    def sampling(self, device, cano_view_dirs=True, render_last_pt=False):
+        key = (str(device), bool(cano_view_dirs), bool(render_last_pt))
+        if key not in self._sampling:
+            self._sampling[key] = hip.Sampling(device, self.n_steps, self.near_surface_vol_samples,
+                                               self.far_surface_vol_samples, cano_view_dirs, render_last_pt)
+        return self._sampling[key]
+
+    def forward(self, sdf_network, skinning_model, cam_loc, ray_directions, body_bounds_intersections, loc,
+                sc_factor, smpl_verts, smpl_verts_cano, skinning_weights, vol_feat, bone_transforms, trans,
+                coord_min, coord_max, center, eval_mode=False, frame=None):
+        if not eval_mode:
+            raise NotImplementedError("training-time stratified jitter is not wired into the HIP sampler yet")
+        assert self.near_surface_vol_samples > 0 or self.far_surface_vol_samples > 0
+        B, N, _ = ray_directions.shape
+        if N == 0:
+            raise ValueError("No valid depth.")
+        if not bool((body_bounds_intersections[..., 0] <= body_bounds_intersections[..., 1]).all()):
+            raise AssertionError("near bound exceeds far bound")
+        dev = ray_directions.device
+        if frame is None:
+            frame = build_frame(sdf_network, skinning_model, None, None, None, smpl_verts, skinning_weights,
+                                bone_transforms, trans, coord_min, coord_max, center)
+        ws = self.workspace(dev)
+        cam = cam_loc.reshape(B, 3)
+        d = ray_directions.reshape(B * N, 3)
+        nf = body_bounds_intersections.reshape(B * N, 2)
+        xn, T, conv, start, end = hip.trace(frame, ws, cam, d, nf)
+        z, pts, Ts, mask = hip.sample_canonicalize(frame, ws, self.sampling(dev), cam, d, nf, conv, start, end)
+        S = self.n_steps
+        return (xn.reshape(B, N, 3), conv.bool().reshape(B, N), start.reshape(B, N), pts.reshape(B, N, S, 3),
+                z.reshape(B, N, S), Ts.reshape(B, N, S, 4, 4), mask.bool().reshape(B, N, S))
+
+
+class IDHRNetwork(nn.Module):
+    """Implicit differentiable human renderer (reference implicit_differentiable_renderer.py:15-259)."""
+
+    def __init__(self, deviation_network, rendering_network, skinning_model, ray_tracer, cano_view_dirs=True,
+                 train_skinning_net=False, render_last_pt=False, low_vram=False):
+        super().__init__()
+        self.deviation_network = deviation_network
+        self.rendering_network = rendering_network
+        self.skinning_model = skinning_model
+        self.ray_tracer = ray_tracer
+        self.cano_view_dirs = cano_view_dirs
+        self.train_skinning_net = train_skinning_net
+        self.render_last_pt = render_last_pt
+        self.low_vram = low_vram
+        self.last_counters = None
+
+    def forward(self, input):
+        if self.training:
+            raise NotImplementedError("the training path (autograd through loop D + regulariser queries) "
+                                      "is scheduled after the inference path; call .eval() first")
+        ray_dirs = input["ray_dirs"]
+        cam_loc = input["cam_loc"]
+        pose = input["pose"]
+        nf = input["body_bounds_intersections"]
+        B, N, _ = ray_dirs.shape
+        if N == 0:
+            raise ValueError("No valid depth.")
+        dev = ray_dirs.device
+        frame = build_frame(input["sdf_network"], self.skinning_model, self.rendering_network,
+                            self.deviation_network, input["pose_cond"], input["smpl_verts"],
+                            input["skinning_weights"], input["bone_transforms"], input["trans"],
+                            input["coord_min"], input["coord_max"], input["center"])
+        ws = self.ray_tracer.workspace(dev)
+        samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
+        rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
+                                                      ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2),
+                                                      pose[0, :3, :4].detach().float().cpu())
+        pcam = pcam.reshape(B, N, 3)
+        if B > 1:   # per-view camera pose for the remaining batch elements (IDR:114-115)
+            pw = cam_loc.reshape(B, 1, 3) + dists.reshape(B, N, 1) * ray_dirs
+            pc = torch.matmul(pw, pose[:, :3, :3].transpose(1, 2)) + pose[:, :3, 3].unsqueeze(1)
+            pcam = torch.where((pcam.abs().sum(-1, keepdim=True) > 0), pc, torch.zeros_like(pc))
+        return {"points_cam": pcam, "network_body_mask": vol.bool().reshape(B, N), "rgb_values": rgb.reshape(B, N, 3)}
+
+
+class MetaAvatarRender(nn.Module):
+    """Model entry (reference models/__init__.py:17-354): hypernetwork -> SDF MLP, then the renderer."""
+
+    def __init__(self, sdf_decoder=None, skinning_model=None, color_decoder=None, deviation_decoder=None,
+                 train_cameras=False, train_smpl=False, train_latent_code=False, train_geo_latent_code=False,
+                 cano_view_dirs=True, near_surface_samples=16, far_surface_samples=16, train_skinning_net=False,
+                 render_last_pt=False, pose_input_noise=True, view_input_noise=True, nv_noise_type="rotation",
+                 low_vram=False, n_steps=64, **kwargs):
+        super().__init__()
+        if train_cameras or train_smpl:
+            raise NotImplementedError("train_cameras / train_smpl need SMPL data files that are not "
+                                      "redistributable; use mode='val'/'test' style construction")
+        self.sdf_decoder = sdf_decoder
+        self.skinning_model = skinning_model
+        self.color_decoder = color_decoder
+        self.deviation_decoder = deviation_decoder
+        self.pose_input_noise = pose_input_noise
+        self.view_input_noise = view_input_noise
+        self.nv_noise_type = nv_noise_type
+        ray_tracer = BodyRayTracing(root_finding_threshold=1e-5, n_steps=n_steps,
+                                    near_surface_vol_samples=near_surface_samples,
+                                    far_surface_vol_samples=far_surface_samples, sample_bg_pts=0, low_vram=low_vram)
+        self.idhr_network = IDHRNetwork(deviation_decoder, color_decoder, skinning_model, ray_tracer,
+                                        cano_view_dirs=cano_view_dirs, train_skinning_net=train_skinning_net,
+                                        render_last_pt=render_last_pt, low_vram=low_vram)
+        self.train_cameras = train_cameras
+        self.train_smpl = train_smpl
+        self.train_latent_code = train_latent_code
+        self.train_geo_latent_code = train_geo_latent_code
+        if train_latent_code or train_geo_latent_code:
+            self.latent = nn.Embedding(kwargs.get("n_data_points"), 128)
+            self.frames = kwargs.get("frames")
+
+    def forward(self, inputs, gen_cano_mesh=False, eval=False):
+        if gen_cano_mesh:
+            raise NotImplementedError("canonical mesh extraction (marching cubes + rasteriser) is outside "
+                                      "the hot path (SURVEY 8f-1)")
+        rots, Jtrs = inputs["rots"], inputs["Jtrs"]
+        B, dev = rots.size(0), rots.device
+        decoder_input = {"coords": torch.zeros(1, 1, 3, dtype=torch.float32, device=dev),
+                         "rots": rots[0].unsqueeze(0), "Jtrs": Jtrs[0].unsqueeze(0)}
+        if "geo_latent_code_idx" in inputs:
+            decoder_input["latent"] = self.latent(inputs["geo_latent_code_idx"])
+        if (self.pose_input_noise or self.view_input_noise) and not eval:
+            raise NotImplementedError("input-noise augmentation belongs to the training path")
+        out = self.sdf_decoder(decoder_input)
+        inputs.update({"loc": torch.zeros(B, 1, 3, device=dev), "sc_factor": torch.ones(B, 1, 1, device=dev),
+                       "vol_feat": torch.empty(B, 0, device=dev), "sdf_network": out["decoder"]})
+        if "latent_code_idx" in inputs["pose_cond"]:
+            inputs["pose_cond"]["latent_code"] = self.latent(inputs["pose_cond"]["latent_code_idx"])
+        model_outputs = self.idhr_network(inputs)
+        model_outputs.update({"sdf_params": out["params"]})
+        return model_outputs

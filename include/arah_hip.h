@@ -1,0 +1,207 @@
+/*
+ * arah_hip.h -- C ABI of the MI355X (gfx950) implementation of ARAH's articulated-SDF
+ * volume-rendering hot path.
+ *
+ * The reference (taconite/arah-release) is pure Python: there is no FFI in it.  The interfaces
+ * these entry points replace are the Python seams of the hot path (paths relative to the
+ * reference root):
+ *
+ *   arah_trace              BodyRayTracing.sphere_tracing + search_iso_surface_depth
+ *                           im2mesh/metaavatar_render/renderer/ray_tracing.py:174-296,
+ *                           im2mesh/utils/root_finding_utils.py:365-484
+ *   arah_sample_canonicalize BodyRayTracing.ray_sampler / inv_transform_points_opt /
+ *                           search_canonical_corr  ray_tracing.py:313-461, root_finding_utils.py:267-362
+ *   arah_shade_composite    IDHRNetwork.get_rbg_value_vol_sdf + the eval tail of forward
+ *                           renderer/implicit_differentiable_renderer.py:261-396, :142-148,:225-257
+ *   arah_render             IDHRNetwork.forward (eval)  implicit_differentiable_renderer.py:42-259
+ *   arah_sdf_eval           sdf_network(x) / gradient(sdf, x)   hyperlayers.py:385-415,
+ *                           siren_modules.py:35-37, diff_operators.py:39-50
+ *   arah_skin_lbs           forward_skinning / query_weights  root_finding_utils.py:54-167,
+ *                           utils/utils.py:138-181, metaavatar/models/decoder.py:201-233
+ *   arah_skin_jacobian      forward_skinning_jac  root_finding_utils.py:170-226
+ *   arah_color_eval         RenderingNetwork.forward  metaavatar_render/models/decoder.py:69-124
+ *   arah_nearest_inverse_lbs inv_transform_points_smpl_verts  ray_tracing.py:382-400
+ *                           (pytorch3d.ops.knn_points K=1 + nearest-vertex inverse LBS)
+ *   arah_broyden3_lbs       search_canonical_corr on caller-supplied initial guesses
+ *                           (broyden.py:4-78 with g = LBS(x) - target)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name starts with "h_"; the caller owns all
+ *     buffers, including the workspace; nothing is allocated, freed or synchronised inside;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls are re-entrant
+ *     across streams as long as workspaces differ;
+ *   - return value: 0 on success, negative ARAH_E_* on error; nothing throws;
+ *   - floats are IEEE fp32, masks are uint8 (0/1), indices int32; arrays are dense row-major.
+ */
+#ifndef ARAH_HIP_H
+#define ARAH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARAH_OK 0
+#define ARAH_E_BADARG (-1)      /* null pointer / negative size */
+#define ARAH_E_SHAPE (-2)       /* network shape not supported by the compiled kernels */
+#define ARAH_E_WORKSPACE (-3)   /* workspace or frame buffer too small */
+#define ARAH_E_LAUNCH (-4)      /* HIP launch error (hipGetLastError) */
+#define ARAH_E_SAMPLING (-5)    /* n_steps < n_near + n_far + 1, or n_steps > ARAH_MAX_STEPS */
+
+#define ARAH_MAX_STEPS 128
+#define ARAH_N_JOINTS 24
+#define ARAH_COLOR_NO_VIEW_DIR 0 /* input [x, n, feat, pose]         (ZJUMOCAP-377-mono) */
+#define ARAH_COLOR_IDR 1         /* input [x, PE4(view), n, feat, pose] (ZJUMOCAP-313, H36M) */
+
+/* Row-major, un-packed network weights as PyTorch holds them (weight-norm already folded:
+ * W = g * v / |v|).  Shapes are the ones every ARAH config uses; arah_prepare_frame rejects
+ * anything else with ARAH_E_SHAPE. */
+typedef struct ArahNets {
+    /* emitted FiLM-SIREN SDF MLP 3 -> 256 x6 -> 1  (hyperlayers.py:497-510) */
+    const float* sdf_w[7];      /* [256,3], 5 x [256,256], [1,256] */
+    const float* sdf_b[7];      /* [256] x6, [1] */
+    const float* film_freq;     /* [6*256] */
+    const float* film_phase;    /* [6*256] */
+    /* skinning MLP 3 -> 128 x4 -> 25, Softplus(beta=100) */
+    const float* skin_w[5];     /* [128,3], 3 x [128,128], [25,128] */
+    const float* skin_b[5];
+    /* colour MLP in -> 256 -> 256 -> 128 -> (in+128) -> 256 -> 256 -> 3, ReLU, sigmoid, skip at 3 */
+    const float* col_w[6];      /* [256,in], [256,256], [128,256], [256,in+128], [256,256], [3,256] */
+    const float* col_b[6];
+    const float* pose_vec;      /* [n_pose] per-frame constant tail of the colour input (may be NULL if n_pose==0) */
+    int32_t col_mode;           /* ARAH_COLOR_* */
+    int32_t n_pose;             /* 128 for color_pose_encoder 'latent' */
+    float beta;                 /* |variance|, un-clipped */
+} ArahNets;
+
+/* Per-frame body (lightning_model.py:581-632 keys smpl_verts, skinning_weights, bone_transforms,
+ * trans, coord_min, coord_max, center), batch element 0. */
+typedef struct ArahBody {
+    const float* verts;         /* [n_verts,3] posed + trans */
+    const float* vert_weights;  /* [n_verts,24] */
+    const float* bones;         /* [24,4,4] */
+    float trans[3];
+    float center[3];
+    float coord_min, coord_max;
+    int32_t n_verts;            /* <= 6912 */
+} ArahBody;
+
+typedef struct ArahSampling {
+    int32_t n_steps, n_near, n_far;   /* configs/default.yaml:49-51 */
+    int32_t cano_view_dirs;           /* model.cano_view_dirs */
+    int32_t render_last_pt;           /* model.render_last_pt */
+    /* device copies of torch.linspace(0, 1, k) for k = n_steps, n_near + 1, n_far (RT:317,330,340);
+     * the caller builds them once per config so that depth samples are bit-identical to torch's */
+    const float* lin_steps;
+    const float* lin_near;
+    const float* lin_far;             /* may be NULL when n_far == 0 */
+} ArahSampling;
+
+/* Opaque-ish handle filled by arah_prepare_frame: device pointers into the caller's frame
+ * buffer (MFMA-packed weights, padded vertices) plus scalars.  POD, copy freely. */
+typedef struct ArahFrame {
+    const float* sdf_w0;        /* [256][4] */
+    const float* sdf_wp[5];     /* packed fwd */
+    const float* sdf_wpT[5];    /* packed transposed (reverse sweep) */
+    const float* sdf_w6;        /* [256] */
+    const float* sdf_b6;        /* [1] */
+    const float* sdf_bias;      /* [6][256] */
+    const float* sdf_freq;      /* [6][256] */
+    const float* sdf_phase;     /* [6][256] */
+    const float* skin_w0;       /* [128][4] */
+    const float* skin_wp[3];    /* packed 128x128 */
+    const float* skin_w4p;      /* packed [32][128] */
+    const float* skin_bias;     /* [4][128] + [32] */
+    const float* col_w0p;       /* packed [256][KIN_PAD] (columns permuted to [feat,x,n,view]) */
+    const float* col_w1p;       /* packed [256][256] */
+    const float* col_w2p;       /* packed [128][256] */
+    const float* col_w3ap;      /* packed [256][KIN_PAD] */
+    const float* col_w3bp;      /* packed [256][128] */
+    const float* col_w4p;       /* packed [256][256] */
+    const float* col_w5;        /* [3][256] */
+    const float* col_bias;      /* b0'[256] b1[256] b2[128] b3'[256] b4[256] b5[4] */
+    const float* verts4;        /* [n_verts_pad][4] */
+    const float* vert_weights;  /* caller's */
+    const float* bones;         /* caller's [24][16] */
+    float beta;
+    float trans[3];
+    float center[3];
+    float coord_min, coord_max;
+    int32_t n_verts;
+    int32_t col_mode;
+} ArahFrame;
+
+/* Work counters (points evaluated), SURVEY 8(d). */
+typedef struct ArahCounters {
+    uint64_t n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn;
+    uint64_t reserved[2];
+} ArahCounters;
+
+/* ---- frame preparation ------------------------------------------------------------------ */
+size_t arah_frame_bytes(const ArahNets* h_nets, const ArahBody* h_body);
+int arah_prepare_frame(const ArahNets* h_nets, const ArahBody* h_body, void* frame_buf, size_t frame_bytes,
+                       ArahFrame* h_frame_out, void* stream);
+
+/* ---- workspace -------------------------------------------------------------------------- */
+size_t arah_workspace_bytes(int32_t n_rays, int32_t n_steps);
+/* zero / read the device-side work counters that live at the head of a workspace */
+int arah_counters_reset(void* workspace, void* stream);
+int arah_counters_read(const void* workspace, ArahCounters* h_out, void* stream); /* syncs the stream */
+
+/* ---- unit seams (parity tests; also usable on their own) --------------------------------- */
+/* x_norm [P,3] -> sdf [P] (normalised units), optional feat [P,256], optional grad [P,3] */
+int arah_sdf_eval(const ArahFrame* h_frame, const float* x_norm, int32_t n_pts, float* sdf, float* feat,
+                  float* grad, void* workspace, size_t workspace_bytes, void* stream);
+/* raw canonical x_hat [P,3] -> optional w [P,24], x_bar [P,3], T [P,16] */
+int arah_skin_lbs(const ArahFrame* h_frame, const float* x_hat, int32_t n_pts, float* w, float* x_bar,
+                  float* T, void* workspace, size_t workspace_bytes, void* stream);
+/* raw canonical x_hat [P,3] -> d x_bar / d x_hat [P,3,3] */
+int arah_skin_jacobian(const ArahFrame* h_frame, const float* x_hat, int32_t n_pts, float* jac,
+                       void* workspace, size_t workspace_bytes, void* stream);
+/* x_norm [P,3], normal [P,3], view [P,3] (ignored for NO_VIEW_DIR), feat [P,256] -> rgb [P,3] */
+int arah_color_eval(const ArahFrame* h_frame, const float* x_norm, const float* normal, const float* view,
+                    const float* feat, int32_t n_pts, float* rgb, void* workspace, size_t workspace_bytes,
+                    void* stream);
+/* posed points [P,3] -> nearest vertex idx [P] (optional), raw canonical x_hat0 [P,3], T0 [P,16] */
+int arah_nearest_inverse_lbs(const ArahFrame* h_frame, const float* pts, int32_t n_pts, int32_t* idx,
+                             float* x_hat0, float* T0, void* workspace, size_t workspace_bytes, void* stream);
+/* Broyden on g(x) = LBS(x) - tgt from caller-supplied x0 [P,3], T0 [P,16];
+ * J^-1_0 = (sum_j w_j(x0) A_j)[:3,:3]^-1.  -> x [P,3] raw canonical, T [P,16], err [P], conv [P] */
+int arah_broyden3_lbs(const ArahFrame* h_frame, const float* tgt, const float* x0, const float* T0,
+                      int32_t n_pts, float* x, float* T, float* err, uint8_t* conv, void* workspace,
+                      size_t workspace_bytes, void* stream);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* rays: cam_loc [n_cams,3], ray r belongs to camera r / rays_per_cam; dirs [N,3]; near_far [N,2].
+ * -> points_hat_norm [N,3], T [N,16], conv [N], start [N], end [N]   (RT:283-296) */
+int arah_trace(const ArahFrame* h_frame, const float* cam_loc, int32_t rays_per_cam, const float* dirs,
+               const float* near_far, int32_t n_rays, float* points_hat_norm, float* T, uint8_t* conv,
+               float* start, float* end, void* workspace, size_t workspace_bytes, void* stream);
+/* -> z [N,S], pts [N,S,3] normalised canonical, T [N,S,16], mask [N,S]   (RT:380, 549-555) */
+int arah_sample_canonicalize(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float* cam_loc,
+                             int32_t rays_per_cam, const float* dirs, const float* near_far,
+                             const uint8_t* conv, const float* start, const float* end, int32_t n_rays,
+                             float* z, float* pts, float* T, uint8_t* mask, void* workspace,
+                             size_t workspace_bytes, void* stream);
+/* -> rgb [N,3], acc [N], vol_mask [N]   (IDR:148, 225-230, 261-396) */
+int arah_shade_composite(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float* dirs,
+                         const float* z, const float* pts, const float* T, const uint8_t* mask,
+                         int32_t n_rays, float* rgb, float* acc, uint8_t* vol_mask, void* workspace,
+                         size_t workspace_bytes, void* stream);
+/* whole eval forward.  pose34 = host [3][4] world->camera (R|t).  Any of the optional outputs may
+ * be NULL, then they live in the workspace.  -> rgb [N,3], points_cam [N,3], vol_mask [N] */
+int arah_render(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float* cam_loc,
+                int32_t rays_per_cam, const float* dirs, const float* near_far, const float* h_pose34,
+                int32_t n_rays, float* rgb, float* points_cam, uint8_t* vol_mask, float* acc,
+                float* dists, uint8_t* surface_conv, void* workspace, size_t workspace_bytes,
+                void* stream);
+
+/* name of the dominant kernel, for profilers */
+const char* arah_dominant_kernel(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARAH_HIP_H */

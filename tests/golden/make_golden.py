@@ -1,0 +1,226 @@
+"""Generate the golden fixtures in tests/golden/*.npz by running the REFERENCE itself on CPU.
+
+Runs only in the build container (needs /root/reference, see ref_shim.py).  The synthetic subject
+(arah_release_amd.synthetic + assets/synthetic_weights.npz) is loaded into the reference's own model
+(built through its own ``config.get_model``) under the reference's own parameter names, then the
+reference's functions are called directly and their inputs/outputs are stored.
+
+    python tests/golden/make_golden.py            # writes F1..F7 (about 9 MB)
+
+Fixtures:
+  f1_broyden.npz       broyden() KATs, D=3 (g = LBS(x) - target) and D=4 (joint residual)
+  f2_pointwise.npz     hierarchical_softmax, (un)normalize, skinning, Deformer fwd, query_weights,
+                       forward_skinning, forward_skinning_jac
+  f3_sdf.npz           emitted SDF MLP: value, feature, autograd gradient
+  f4_color_<mode>.npz  RenderingNetwork forward, both colour modes
+  f5_tracer_<cfg>.npz  BodyRayTracing.forward 7-tuple (and its inputs), (64,16,16) and (32,8,8)
+  f6_shade_<cfg>.npz   get_rbg_value_vol_sdf on the f5 outputs
+  f7_forward_<cfg>.npz whole MetaAvatarRender.forward(eval=True) dict for small frames
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import ref_shim  # noqa: E402
+
+ref_shim.install()
+os.chdir(ref_shim.REF_ROOT)
+
+import im2mesh.config as ref_config  # noqa: E402
+from im2mesh.metaavatar_render import config as ref_render_config  # noqa: E402
+from im2mesh.utils import root_finding_utils as RFU  # noqa: E402
+from im2mesh.utils.broyden import broyden as ref_broyden  # noqa: E402
+from im2mesh.utils.utils import hierarchical_softmax as ref_hsoftmax  # noqa: E402
+from im2mesh.utils import diff_operators  # noqa: E402
+
+from arah_release_amd import config as my_config  # noqa: E402
+from arah_release_amd import synthetic  # noqa: E402
+
+REF_CFG = {"zju377_mono": "configs/arah-zju/ZJUMOCAP-377-mono_4gpus.yaml",
+           "zju313": "configs/arah-zju/ZJUMOCAP-313_4gpus.yaml",
+           "h36m": "configs/arah-h36m/H36M_S9_4gpus.yaml"}
+
+
+def build_reference_model(name, n_steps=64, near=16, far=16):
+    cfg = ref_config.load_config(REF_CFG[name], "configs/default.yaml")
+    cfg["model"].update(n_steps=n_steps, near_surface_samples=near, far_surface_samples=far)
+    my_cfg = my_config.builtin_config(name, n_steps, near, far)
+    sd = my_config.synthetic_state_dict(my_cfg)
+    fake = "/tmp/arah_fake_ckpt_%s.ckpt" % name
+    torch.save({"state_dict": {"model.latent.weight": sd["latent.weight"]}}, fake)
+    torch.manual_seed(0)
+    model = ref_render_config.get_model(cfg, mode="test", checkpoint_path=fake)
+    res = model.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys   # our names ARE the reference's names
+    # shapes restated in builtin_config must equal the reference yaml's
+    for k in ("renderer_kwargs", "decoder_kwargs", "skinning_decoder_kwargs", "cano_view_dirs",
+              "color_pose_encoder", "geo_pose_encoder"):
+        assert cfg["model"][k] == my_cfg["model"][k], (k, cfg["model"][k], my_cfg["model"][k])
+    return model.eval(), cfg
+
+
+def npify(d):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, torch.Tensor):
+            out[k] = v.detach().cpu().numpy()
+        elif isinstance(v, (np.ndarray, float, int, bool, np.floating, np.integer)):
+            out[k] = np.asarray(v)
+    return out
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **npify(arrays))
+    print("wrote %-28s %.2f MB" % (name, os.path.getsize(path) / 1e6))
+
+
+def frame_tensors(model, inputs):
+    """What the reference's tracer / renderer need besides the rays."""
+    dec_in = {"coords": torch.zeros(1, 1, 3), "rots": inputs["rots"][:1], "Jtrs": inputs["Jtrs"][:1],
+              "latent": model.latent(inputs["geo_latent_code_idx"])}
+    with torch.no_grad():
+        sdf_network = model.sdf_decoder(dec_in)["decoder"]
+    B = inputs["rots"].shape[0]
+    return dict(sdf_network=sdf_network, loc=torch.zeros(B, 1, 3), sc_factor=torch.ones(B, 1, 1),
+                vol_feat=torch.empty(B, 0))
+
+
+def main():
+    torch.set_num_threads(os.cpu_count())
+    scene = synthetic.SyntheticScene(seed=0)
+    model, cfg = build_reference_model("zju377_mono")
+    inputs = scene.make_inputs(64, 64, frame_idx=0)
+    ft = frame_tensors(model, inputs)
+    sdf_network, loc, sc, vol = ft["sdf_network"], ft["loc"], ft["sc_factor"], ft["vol_feat"]
+    cmin, cmax, center = inputs["coord_min"], inputs["coord_max"], inputs["center"]
+    bones, trans = inputs["bone_transforms"], inputs["trans"]
+    skin = model.skinning_model
+    g = torch.Generator().manual_seed(123)
+
+    # ------------------------------------------------------------------ F2 pointwise pieces
+    P = 1024
+    logits = torch.randn(1, P, 25, generator=g) * 3
+    x_norm = torch.rand(1, P, 3, generator=g) * 1.6 - 0.8
+    x_hat = RFU.unnormalize_canonical_points(x_norm, cmin, cmax, center)
+    with torch.no_grad():
+        hs = ref_hsoftmax(logits)
+        xn_back = RFU.normalize_canonical_points(x_hat, cmin, cmax, center)
+        dlog = skin.decode_w(x_norm, c=torch.empty(1, 0), forward=True)
+        w = RFU.query_weights(x_hat, loc, sc, cmin, cmax, center, skin, vol)
+        xbar, T = RFU.forward_skinning(x_hat, loc, sc, cmin, cmax, center, skin, vol, bones)
+    jac = RFU.forward_skinning_jac(x_hat.clone(), loc, sc, cmin, cmax, center, skin, vol, bones)
+    save("f2_pointwise.npz", logits=logits[0], hsoftmax=hs[0], x_norm=x_norm[0], x_hat=x_hat[0],
+         x_norm_back=xn_back[0], deformer_logits=dlog[0], weights=w[0], x_bar=xbar[0], T=T[0], jac=jac[0],
+         coord_min=cmin.reshape(-1), coord_max=cmax.reshape(-1), center=center.reshape(-1), bones=bones[0])
+
+    # ------------------------------------------------------------------ F3 SDF MLP
+    with torch.enable_grad():
+        xg = x_norm.clone().requires_grad_(True)
+        feat = sdf_network[:-1](xg)
+        sdf = sdf_network[-1](feat)
+        grad = diff_operators.gradient(sdf, xg, create_graph=False)
+    save("f3_sdf.npz", x_norm=x_norm[0], sdf=sdf[0, :, 0], feat=feat[0], grad=grad[0])
+
+    # ------------------------------------------------------------------ F1 Broyden KATs
+    # D=3: g = LBS(x) - target, as in search_canonical_corr (root_finding_utils.py:267-303)
+    Pb = 256
+    xh_true = x_hat[:, :Pb]
+    with torch.no_grad():
+        tgt, _ = RFU.forward_skinning(xh_true, loc, sc, cmin, cmax, center, skin, vol, bones)
+        x0 = xh_true + torch.randn(1, Pb, 3, generator=g) * 0.02
+        x0[:, :8] += 0.5   # a few hopeless starts exercise the divergence / best-iterate paths
+        w0 = RFU.query_weights(x0, loc, sc, cmin, cmax, center, skin, vol)
+        T0 = torch.einsum("bpn,bnij->bpij", w0, bones)
+        Jinv0 = T0[:, :, :3, :3].inverse()
+
+        def g3(x, mask=None):
+            xx = x.reshape(1, Pb, 3)
+            xb, Tt = RFU.forward_skinning(xx, loc, sc, cmin, cmax, center, skin, vol, bones, mask=mask)
+            err = (xb - tgt).flatten(0, 1)[mask].unsqueeze(-1)
+            return err, Tt.flatten(0, 1)[mask]
+
+        T_init = torch.eye(4).expand(Pb, 4, 4).clone() * 7.0   # sentinel: returned when the start is already best
+        r3 = ref_broyden(g3, x0.reshape(Pb, 3, 1), T_init, Jinv0.flatten(0, 1))
+    save("f1_broyden3.npz", tgt=tgt[0], x0=x0[0], T0=T_init, Jinv0=Jinv0[0], result=r3["result"][:, :, 0],
+         transforms=r3["transforms"], diff=r3["diff"], valid=r3["valid_ids"])
+
+    for tag, (S, near, far) in (("s64", (64, 16, 16)), ("s32", (32, 8, 8))):
+        for name in ("zju377_mono", "h36m"):
+            if tag == "s32" and name == "h36m":
+                continue
+            model, cfg = build_reference_model(name, S, near, far)
+            inputs = scene.make_inputs(96, 96, frame_idx=3, max_rays=1024)
+            ft = frame_tensors(model, inputs)
+            tracer = model.idhr_network.ray_tracer
+            with torch.no_grad():
+                tr = tracer(ft["sdf_network"], model.skinning_model, cam_loc=inputs["cam_loc"],
+                            ray_directions=inputs["ray_dirs"],
+                            body_bounds_intersections=inputs["body_bounds_intersections"], loc=ft["loc"],
+                            sc_factor=ft["sc_factor"], smpl_verts=inputs["smpl_verts"],
+                            smpl_verts_cano=inputs["minimal_shape"], skinning_weights=inputs["skinning_weights"],
+                            vol_feat=ft["vol_feat"], bone_transforms=inputs["bone_transforms"],
+                            trans=inputs["trans"], coord_min=inputs["coord_min"], coord_max=inputs["coord_max"],
+                            center=inputs["center"], eval_mode=True)
+            xn, nbm, dists, spts, sz, sT, sm = tr
+            # bottom row of every valid blended transform is (0,0,0,sum w ~ 1): store the 3x4 part only
+            bot = sT[0][sm[0]][:, 3]
+            assert float((bot - torch.tensor([0., 0., 0., 1.])).abs().max()) < 1e-5
+            if name == "zju377_mono":
+                save("f5_tracer_%s.npz" % tag, frame_idx=3, H=96, W=96, max_rays=1024, n_steps=S, n_near=near,
+                     n_far=far, points_hat_norm=xn[0], network_body_mask=nbm[0], dists=dists[0], sampler_pts=spts[0],
+                     sampler_dists=sz[0], sampler_transforms34=sT[0][:, :, :3, :].reshape(sT.shape[1], S, 12),
+                     sampler_converge_mask=sm[0])
+            # ---------------------------------------------------------- F6 shading on the tracer output
+            vol_mask = sm[0].any(-1)
+            pose_cond = dict(inputs["pose_cond"])
+            pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+            idhr = model.idhr_network
+            rgb, acc = idhr.get_rbg_value_vol_sdf(ft["sdf_network"], spts[0][vol_mask], sz[0][vol_mask],
+                                                  sT[0][vol_mask], sm[0][vol_mask], inputs["ray_dirs"][0][vol_mask],
+                                                  inputs["ray_dirs"][0][vol_mask].clone(), pose_cond, ft["loc"][:1],
+                                                  ft["sc_factor"][:1], ft["vol_feat"], inputs["bone_transforms"][:1],
+                                                  inputs["coord_min"][:1], inputs["coord_max"][:1],
+                                                  inputs["center"][:1], point_batch_size=1000000)
+            # inputs of this call are the f5_tracer_<tag> arrays (the tracer does not depend on the colour net)
+            save("f6_shade_%s_%s.npz" % (name, tag), vol_mask=vol_mask, rgb=rgb.detach(), acc=acc.detach(),
+                 frame_idx=3, H=96, W=96, max_rays=1024, n_steps=S, n_near=near, n_far=far)
+
+    # ------------------------------------------------------------------ F4 colour MLP (both modes)
+    for name in ("zju377_mono", "zju313"):
+        model, cfg = build_reference_model(name)
+        inputs = scene.make_inputs(64, 64, frame_idx=0)
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        pts = torch.rand(P, 3, generator=g) * 2 - 1
+        nrm = torch.randn(P, 3, generator=g)
+        view = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+        feat = torch.rand(P, 256, generator=g) * 2 - 1
+        with torch.no_grad():
+            rgb = model.color_decoder(pts, nrm, view, feat, pose_cond)
+        save("f4_color_%s.npz" % name, points=pts, normals=nrm, view=view, feat=feat, rgb=rgb)
+
+    # ------------------------------------------------------------------ F7 whole forward
+    for name, (H, W), (S, near, far), fidx in (("zju377_mono", (64, 64), (64, 16, 16), 0),
+                                               ("zju313", (64, 64), (64, 16, 16), 1),
+                                               ("h36m", (48, 48), (32, 8, 8), 2),
+                                               ("zju377_mono", (128, 128), (32, 8, 8), 5)):
+        model, cfg = build_reference_model(name, S, near, far)
+        inputs = scene.make_inputs(H, W, frame_idx=fidx)
+        with torch.no_grad():
+            out = model(inputs, gen_cano_mesh=False, eval=True)
+        save("f7_forward_%s_%dx%d_s%d.npz" % (name, H, W, S), frame_idx=fidx, H=H, W=W, n_steps=S, n_near=near,
+             n_far=far, rgb_values=out["rgb_values"][0], points_cam=out["points_cam"][0],
+             network_body_mask=out["network_body_mask"][0], sdf_param0=out["sdf_params"][0][0, :16],
+             ray_dirs=inputs["ray_dirs"][0], body_bounds_intersections=inputs["body_bounds_intersections"][0])
+
+
+if __name__ == "__main__":
+    main()
