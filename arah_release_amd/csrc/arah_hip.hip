@@ -1358,6 +1358,9 @@ void setup_attributes() {
     allow_lds(k_color_eval<true>, lds_color<true>());
 }
 
+// optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
+hipEvent_t g_shade_ev0 = nullptr, g_shade_ev1 = nullptr;
+
 RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
     RaySet rs;
     rs.cam_loc = cam_loc;
@@ -1434,6 +1437,12 @@ ColSegs one_seg(int len) {
 extern "C" {
 
 const char* arah_dominant_kernel(void) { return "k_shade"; }
+
+int arah_set_shade_events(void* start_event, void* stop_event) {
+    g_shade_ev0 = reinterpret_cast<hipEvent_t>(start_event);
+    g_shade_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
+    return ARAH_OK;
+}
 
 size_t arah_frame_bytes(const ArahNets* h_nets, const ArahBody* h_body) {
     if (!h_nets || !h_body) return 0;
@@ -1744,9 +1753,9 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
 int arah_trace(const ArahFrame* f, const float* cam_loc, int32_t rays_per_cam, const float* dirs,
                const float* near_far, int32_t n, float* points_hat_norm, float* T, uint8_t* conv, float* start,
                float* end, void* workspace, size_t wbytes, void* stream) {
-    if (!f || !cam_loc || !dirs || !near_far || !points_hat_norm || !T || !conv || !start || !end || n < 0 || !workspace)
-        return ARAH_E_BADARG;
+    if (!f || n < 0 || !workspace) return ARAH_E_BADARG;
     if (n == 0) return ARAH_OK;
+    if (!cam_loc || !dirs || !near_far || !points_hat_norm || !T || !conv || !start || !end) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
@@ -1797,12 +1806,11 @@ int arah_sample_canonicalize(const ArahFrame* f, const ArahSampling* cfg, const 
                              const float* dirs, const float* near_far, const uint8_t* conv, const float* start,
                              const float* end, int32_t n, float* z, float* pts, float* T, uint8_t* mask,
                              void* workspace, size_t wbytes, void* stream) {
-    if (!f || !cfg || !cam_loc || !dirs || !near_far || !conv || !start || !end || !z || !pts || !T || !mask || n < 0 ||
-        !workspace)
-        return ARAH_E_BADARG;
+    if (!f || !cfg || n < 0 || !workspace) return ARAH_E_BADARG;
     int rc = check_sampling(cfg);
     if (rc) return rc;
     if (n == 0) return ARAH_OK;
+    if (!cam_loc || !dirs || !near_far || !conv || !start || !end || !z || !pts || !T || !mask) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
@@ -1820,6 +1828,7 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 255) / 256)), dim3(256), 0, s, mask, (int)Q, w.listA, &w.counts[0]);
     const int g = grid_for(Q, kTile);
+    if (g_shade_ev0) hipEventRecord(g_shade_ev0, s);
     if (f->col_mode == ARAH_COLOR_IDR)
         hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(kThreads), lds_shade<true>(), s, fd, S, cfg->cano_view_dirs, dirs,
                            pts, T, (const int*)w.listA, (const int*)&w.counts[0], 0, w.shaded, w.spill,
@@ -1828,6 +1837,7 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
         hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(kThreads), lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs,
                            pts, T, (const int*)w.listA, (const int*)&w.counts[0], 0, w.shaded, w.spill,
                            &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col);
+    if (g_shade_ev1) hipEventRecord(g_shade_ev1, s);
     hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);
     return check_launch();
@@ -1836,9 +1846,10 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
 int arah_shade_composite(const ArahFrame* f, const ArahSampling* cfg, const float* dirs, const float* z,
                          const float* pts, const float* T, const uint8_t* mask, int32_t n, float* rgb, float* acc,
                          uint8_t* vol_mask, void* workspace, size_t wbytes, void* stream) {
-    if (!f || !cfg || !dirs || !z || !pts || !T || !mask || !rgb || !vol_mask || n < 0 || !workspace) return ARAH_E_BADARG;
+    if (!f || !cfg || n < 0 || !workspace) return ARAH_E_BADARG;
     if (cfg->n_steps <= 0 || cfg->n_steps > ARAH_MAX_STEPS) return ARAH_E_SAMPLING;
     if (n == 0) return ARAH_OK;
+    if (!dirs || !z || !pts || !T || !mask || !rgb || !vol_mask) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
@@ -1850,11 +1861,12 @@ int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_lo
                 const float* dirs, const float* near_far, const float* h_pose34, int32_t n, float* rgb,
                 float* points_cam, uint8_t* vol_mask, float* acc, float* dists, uint8_t* surface_conv,
                 void* workspace, size_t wbytes, void* stream) {
-    if (!f || !cfg || !cam_loc || !dirs || !near_far || !rgb || !vol_mask || n < 0 || !workspace) return ARAH_E_BADARG;
-    if (points_cam && !h_pose34) return ARAH_E_BADARG;
+    if (!f || !cfg || n < 0 || !workspace) return ARAH_E_BADARG;
     int rc = check_sampling(cfg);
     if (rc) return rc;
-    if (n == 0) return ARAH_OK;
+    if (n == 0) return ARAH_OK;   // empty ray set: nothing to do, data pointers may be NULL
+    if (!cam_loc || !dirs || !near_far || !rgb || !vol_mask) return ARAH_E_BADARG;
+    if (points_cam && !h_pose34) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();

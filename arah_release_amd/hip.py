@@ -61,7 +61,7 @@ class ArahCounters(C.Structure):
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_trace", "arah_sample_canonicalize",
-           "arah_shade_composite", "arah_render", "arah_dominant_kernel"]
+           "arah_shade_composite", "arah_render", "arah_dominant_kernel", "arah_set_shade_events"]
 
 _lib = None
 
@@ -349,6 +349,17 @@ def shade_composite(frame, ws, sampling, dirs, z, pts, T, mask):
                                     _ptr(acc), _ptr(vol), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
            "arah_shade_composite")
     return rgb, acc, vol
+
+
+def set_shade_events(start=None, stop=None):
+    """Record torch.cuda.Event `start`/`stop` around the dominant kernel of every following render."""
+    lib = load_library()
+    for ev in (start, stop):   # torch creates the hipEvent lazily, on the first record
+        if ev is not None:
+            ev.record()
+    a = C.c_void_p(start.cuda_event) if start is not None else None
+    b = C.c_void_p(stop.cuda_event) if stop is not None else None
+    _check(lib.arah_set_shade_events(a, b), "arah_set_shade_events")
 
 
 def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):

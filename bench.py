@@ -1,0 +1,179 @@
+"""Headline benchmark: rendered rays/s of the articulated-SDF volume renderer (BASELINE.json).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one ``MetaAvatarRender.forward(inputs, eval=True)`` (per-frame hypernetwork included,
+gen_cano_mesh off, data generation excluded: the input dict is resident in HBM before the timed
+region) on one synthetic 512x512 frame of the ZJUMOCAP-377-mono configuration with 64 samples/ray
+(BASELINE.json configs[1]).  Frames are independent, so N GPUs render disjoint frames (frame
+i -> rank i mod N): no data-path collective, weak scaling, value = all rays of all ranks
+/ max-over-ranks time.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (loop D's k_shade): algorithmic MFMA flops per launch / HIP-event
+                duration vs the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline  the oracle (a torch-CPU restatement of the reference, pinned against it) on a bounded
+                sample of the same frame's rays, on the host cores of this box; rank 0, N == 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F_SDF = 657408          # 2*(3*256 + 5*256^2 + 256)
+F_SDF_GRAD = 657408
+F_COL = {"no_view_dir": 794112, "idr": 821760}
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def shard_frames(rank, world, steps, warmup):
+    """Frame indices of this rank: (warmup frames, timed frames). Frame i belongs to rank i mod world."""
+    per_rank = warmup + steps
+    mine = [rank + world * k for k in range(per_rank)]
+    return mine[:warmup], mine[warmup:]
+
+
+def aggregate(local_rays, local_seconds, dist=None):
+    """Whole-job rays and the max-over-ranks time."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return float(local_rays), float(local_seconds)
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    r = torch.tensor([float(local_rays)], dtype=torch.float64, device=dev)
+    t = torch.tensor([float(local_seconds)], dtype=torch.float64, device=dev)
+    dist.all_reduce(r, op=dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(r.item()), float(t.item())
+
+
+def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays):
+    """Oracle on `sample_rays` rays spread evenly over frame 0 of the benchmark workload."""
+    from arah_release_amd import config
+    from oracle import arah_oracle as O
+    model, cfg = config.build_synthetic_model(cfg_name, n_steps, near, far, device="cpu")
+    inputs = scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays)
+    n = inputs["ray_dirs"].shape[1]
+    t0 = time.perf_counter()
+    O.render_inputs(model, inputs, cfg["model"]["cano_view_dirs"], n_steps, near, far)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d rays evenly subsampled from frame 0 of the %dx%dx%d workload, oracle/arah_oracle.py "
+                      "(torch CPU fp32, cKDTree 1-NN), %.1f s" % (n, size, size, n_steps, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--n-steps", type=int, default=64)
+    ap.add_argument("--config", default="zju377_mono")
+    ap.add_argument("--cpu-sample-rays", type=int, default=4096)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    assert world == max(args.gpus, 1), "launch with --nproc-per-node == --gpus"
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from arah_release_amd import config, hip, synthetic
+
+    near = far = args.n_steps // 4
+    model, cfg = config.build_synthetic_model(args.config, args.n_steps, near, far, device=dev)
+    scene = synthetic.SyntheticScene(0)
+    warm_frames, timed_frames = shard_frames(rank, world, args.steps, args.warmup)
+    warm_inputs = [scene.make_inputs(args.size, args.size, frame_idx=f, device=dev) for f in warm_frames]
+    timed_inputs = [scene.make_inputs(args.size, args.size, frame_idx=f, device=dev) for f in timed_frames]
+    n_rays_local = sum(int(i["ray_dirs"].shape[1]) for i in timed_inputs)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    with torch.no_grad():
+        for inp in warm_inputs:
+            model(inp, eval=True)
+        sync()
+        ws = model.idhr_network.ray_tracer.workspace(dev)
+        ws.ensure(1, 1)
+        ws.reset_counters()
+        shade_ms = []
+        t0 = time.perf_counter()
+        for inp in timed_inputs:
+            model(inp, eval=True)
+        sync()
+        elapsed = time.perf_counter() - t0
+        counters = ws.counters()
+        # dominant-kernel timing on the same workload, outside the timed region (the events would not
+        # perturb it, but reading them needs a sync per step)
+        hip.set_shade_events(ev0, ev1)
+        for inp in timed_inputs:
+            model(inp, eval=True)
+            torch.cuda.synchronize()
+            shade_ms.append(ev0.elapsed_time(ev1))
+        hip.set_shade_events(None, None)
+
+    total_rays, t_max = aggregate(n_rays_local, elapsed, dist if world > 1 else None)
+    if rank == 0:
+        mode = cfg["model"]["renderer_kwargs"]["mode"]
+        n_launch = max(len(shade_ms), 1)
+        flops_per_sample = F_SDF + F_SDF_GRAD + F_COL[mode]
+        samples_per_launch = counters["n_col"] / n_launch
+        avg_ms = sum(shade_ms) / n_launch
+        achieved = samples_per_launch * flops_per_sample / (avg_ms * 1e-3) / 1e12
+        total_flops = (F_SDF * counters["n_sdf_fwd"] + F_SDF_GRAD * counters["n_sdf_grad"] +
+                       105472 * (counters["n_skin_fwd"] + 3 * counters["n_skin_jac"]) + F_COL[mode] * counters["n_col"] +
+                       55120 * counters["n_knn"])
+        line = {
+            "metric": "rendered rays/sec", "value": total_rays / t_max, "unit": "rays/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ZJUMOCAP-377-mono test.py inference, %dx%d, %d samples/ray (near %d / far %d), "
+                                   "synthetic capsule body + fitted SIREN, one frame per step" %
+                                   (args.size, args.size, args.n_steps, near, far),
+                       "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
+                       "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world},
+            "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "samples_per_launch": samples_per_launch,
+                         "flops_per_sample": flops_per_sample},
+            "work": {"per_ray": {k: v / max(n_rays_local, 1) for k, v in counters.items()},
+                     "algorithmic_mflop_per_ray": total_flops / max(n_rays_local, 1) / 1e6,
+                     "whole_path_tflops_rank0": total_flops / elapsed / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(scene, args.config, args.size, args.n_steps, near, far,
+                                                args.cpu_sample_rays)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -200,6 +200,10 @@ int arah_render(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float
 
 /* name of the dominant kernel, for profilers */
 const char* arah_dominant_kernel(void);
+/* Profiling hook: when both are non-NULL hipEvent_t handles, every following arah_shade_composite /
+ * arah_render records them on its stream immediately before / after the launch of the dominant
+ * kernel (loop D's shading kernel).  Pass NULLs to switch it off.  Process-global, not thread safe. */
+int arah_set_shade_events(void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,329 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and with the golden vectors generated
+from the reference.  GPU tests are marked ``gpu``; the CPU part checks that the library loads and
+exports every symbol of include/arah_hip.h.
+
+Tolerances: fp32 MFMA kernels vs fp32 CPU arithmetic -> rtol 1e-4 / atol 2e-5 on element-wise seams
+(looser where noted, e.g. after 6 sine layers or through derivatives); path-dependent seams: mask
+agreement >= 99.5 %, depth/points within 1e-4..2e-4 on agreeing rays, PSNR >= 45 dB on images.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO, golden, psnr, get_model
+
+gpu = pytest.mark.gpu
+
+
+def T(x, dev="cuda"):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+
+
+def assert_rows_close(a, b, atol, rtol=0.0, frac=0.995):
+    """Root finding is path dependent: a handful of points may legitimately settle on another root of
+    the (non-injective) LBS map after fp32 re-ordering.  Require >= `frac` of the rows within tolerance
+    (path-dependent fixtures are judged on agreement fractions, not allclose)."""
+    a = np.asarray(a, np.float64).reshape(len(a), -1)
+    b = np.asarray(b, np.float64).reshape(len(b), -1)
+    ok = (np.abs(a - b) <= atol + rtol * np.abs(b)).all(axis=1)
+    assert ok.mean() >= frac, "only %.4f of %d rows within tolerance" % (ok.mean(), len(ok))
+
+
+# ------------------------------------------------------------------------------------------ CPU
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as g
+    g.build()
+    from arah_release_amd import hip
+    lib = hip.load_library()
+    header = open(os.path.join(REPO, "include", "arah_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(arah_[a-z0-9_]+)\s*\(", header))
+    assert declared and declared == set(hip.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes_match_header():
+    """ctypes mirrors of the POD structs must have the C layout (pointer + int32/float fields)."""
+    import ctypes as C
+    from arah_release_amd import hip
+    assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 4 * 3 + 4   # padded to 8
+    assert C.sizeof(hip.ArahSampling) == 4 * 5 + 4 + 8 * 3
+    assert C.sizeof(hip.ArahCounters) == 64
+
+
+def test_product_has_no_cpu_fallback():
+    from arah_release_amd import hip
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        hip.require_gpu()
+
+
+# ------------------------------------------------------------------------------------------ GPU
+@pytest.fixture(scope="module")
+def ctx(scene):
+    from arah_release_amd import hip, renderer
+    dev = torch.device("cuda:0")
+    model, cfg = get_model("zju377_mono", dev)
+    inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    return dict(hip=hip, frame=frame, ws=hip.Workspace(dev), dev=dev, model=model, cfg=cfg)
+
+
+@gpu
+def test_sdf_eval(ctx):
+    g = golden("f3_sdf.npz")
+    hip = ctx["hip"]
+    sdf, feat, grad = hip.sdf_eval(ctx["frame"], ctx["ws"], T(g["x_norm"]), want_feat=True, want_grad=True)
+    np.testing.assert_allclose(sdf.cpu().numpy(), g["sdf"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=1e-4, atol=5e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=1e-3, atol=2e-4)
+    sdf2, _, _ = hip.sdf_eval(ctx["frame"], ctx["ws"], T(g["x_norm"]))
+    np.testing.assert_array_equal(sdf2.cpu().numpy(), sdf.cpu().numpy())   # fwd-only kernel == fwd+grad kernel
+    # ragged tile (n not a multiple of 64) and a single point
+    for n in (1, 63, 65):
+        s, _, gr = hip.sdf_eval(ctx["frame"], ctx["ws"], T(g["x_norm"][:n]), want_grad=True)
+        np.testing.assert_array_equal(s.cpu().numpy(), sdf.cpu().numpy()[:n])
+        np.testing.assert_array_equal(gr.cpu().numpy(), grad.cpu().numpy()[:n])
+
+
+@gpu
+def test_skin_lbs_and_jacobian(ctx):
+    g = golden("f2_pointwise.npz")
+    hip = ctx["hip"]
+    w, xb, Tm = hip.skin_lbs(ctx["frame"], ctx["ws"], T(g["x_hat"]))
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=2e-3, atol=2e-5)
+    np.testing.assert_allclose(xb.cpu().numpy(), g["x_bar"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(Tm.cpu().numpy(), g["T"], rtol=1e-4, atol=2e-5)
+    jac = hip.skin_jacobian(ctx["frame"], ctx["ws"], T(g["x_hat"]))
+    np.testing.assert_allclose(jac.cpu().numpy(), g["jac"], rtol=2e-3, atol=3e-4)
+
+
+@gpu
+@pytest.mark.parametrize("name", ["zju377_mono", "zju313"])
+def test_color_eval(scene, name):
+    from arah_release_amd import hip, renderer
+    g = golden("f4_color_%s.npz" % name)
+    dev = torch.device("cuda:0")
+    model, cfg = get_model(name, dev)
+    inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    rgb = hip.color_eval(frame, hip.Workspace(dev), T(g["points"]), T(g["normals"]), T(g["view"]), T(g["feat"]))
+    np.testing.assert_allclose(rgb.cpu().numpy(), g["rgb"], rtol=1e-4, atol=2e-5)
+
+
+@gpu
+def test_nearest_inverse_lbs(ctx, scene):
+    from oracle import arah_oracle as O
+    hip = ctx["hip"]
+    cpu_model, _ = get_model("zju377_mono")
+    fr = O.frame_from_model(cpu_model, scene.make_inputs(64, 64, frame_idx=0))
+    gen = torch.Generator().manual_seed(5)
+    sel = torch.randint(0, fr.verts.shape[0], (4096,), generator=gen)
+    pts = fr.verts[sel] + torch.randn(4096, 3, generator=gen) * 0.03
+    idx, x0, T0 = hip.nearest_inverse_lbs(ctx["frame"], ctx["ws"], pts.to(ctx["dev"]))
+    ref_idx = O.nearest_vertex(fr, pts)
+    same = (idx.cpu().long() == ref_idx).numpy()
+    assert same.mean() >= 0.999     # fp32 vs fp64 distance ties only
+    x_ref, T_ref = O.nn_inverse_lbs(fr, pts)
+    np.testing.assert_allclose(x0.cpu().numpy()[same], x_ref.numpy()[same], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(T0.cpu().numpy()[same], T_ref.numpy()[same], rtol=1e-4, atol=2e-5)
+
+
+@gpu
+def test_broyden3(ctx):
+    g = golden("f1_broyden3.npz")
+    hip = ctx["hip"]
+    x, Tm, err, ok = hip.broyden3_lbs(ctx["frame"], ctx["ws"], T(g["tgt"]), T(g["x0"]), T(g["T0"]))
+    ok = ok.cpu().numpy()
+    valid = g["valid"]
+    assert (ok == valid).mean() >= 0.995
+    both = ok & valid
+    assert_rows_close(x.cpu().numpy()[both], g["result"][both], atol=2e-5, frac=0.99)
+    assert_rows_close(Tm.cpu().numpy()[both], g["transforms"][both], atol=1e-4, rtol=1e-3, frac=0.99)
+    never = np.isclose(g["transforms"][:, 0, 0], 7.0)
+    assert (np.isclose(Tm.cpu().numpy()[:, 0, 0], 7.0) == never).mean() >= 0.99
+
+
+def _tracer_inputs(scene, g, dev):
+    return scene.make_inputs(int(g["H"]), int(g["W"]), frame_idx=int(g["frame_idx"]), max_rays=int(g["max_rays"]),
+                             device=dev)
+
+
+@gpu
+@pytest.mark.parametrize("tag", ["s64", "s32"])
+def test_tracer_against_reference(scene, tag):
+    """BodyRayTracing.forward 7-tuple vs the reference's (fixture f5)."""
+    from arah_release_amd import config
+    g = golden("f5_tracer_%s.npz" % tag)
+    dev = torch.device("cuda:0")
+    S, nn, nfar = int(g["n_steps"]), int(g["n_near"]), int(g["n_far"])
+    model, cfg = config.build_synthetic_model("zju377_mono", S, nn, nfar, device=dev)
+    inputs = _tracer_inputs(scene, g, dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        B = 1
+        out = model.idhr_network.ray_tracer(
+            dec["decoder"], model.skinning_model, cam_loc=inputs["cam_loc"], ray_directions=inputs["ray_dirs"],
+            body_bounds_intersections=inputs["body_bounds_intersections"], loc=torch.zeros(B, 1, 3, device=dev),
+            sc_factor=torch.ones(B, 1, 1, device=dev), smpl_verts=inputs["smpl_verts"],
+            smpl_verts_cano=inputs["minimal_shape"], skinning_weights=inputs["skinning_weights"],
+            vol_feat=torch.empty(B, 0, device=dev), bone_transforms=inputs["bone_transforms"], trans=inputs["trans"],
+            coord_min=inputs["coord_min"], coord_max=inputs["coord_max"], center=inputs["center"], eval_mode=True)
+    xn, conv, dists, spts, sz, sT, smask = [o[0].cpu().numpy() for o in out]
+    ref_conv = g["network_body_mask"]
+    agree = conv == ref_conv
+    assert agree.mean() >= 0.995
+    both = conv & ref_conv
+    assert_rows_close(dists[both], g["dists"][both], atol=1e-4, frac=0.999)
+    assert_rows_close(xn[both], g["points_hat_norm"][both], atol=2e-4, frac=0.999)
+    np.testing.assert_array_equal(dists[~conv & ~ref_conv], g["dists"][~conv & ~ref_conv])   # near bound, copied
+    # samples: rays classified alike have (nearly) the same depths; masks agree on >= 99.5 % of all slots
+    assert_rows_close(sz[agree], g["sampler_dists"][agree], atol=1e-4, frac=0.999)
+    ref_mask = g["sampler_converge_mask"]
+    assert (smask[agree] == ref_mask[agree]).mean() >= 0.995
+    bm = smask & ref_mask & agree[:, None]
+    assert_rows_close(spts[bm], g["sampler_pts"][bm], atol=3e-4, frac=0.999)
+    assert_rows_close(sT[bm][:, :3, :].reshape(-1, 12), g["sampler_transforms34"][bm], atol=3e-4, rtol=1e-3, frac=0.999)
+    np.testing.assert_allclose(sT[bm][:, 3, :], np.tile([0, 0, 0, 1.0], (bm.sum(), 1)), rtol=0, atol=1e-5)
+
+
+@gpu
+@pytest.mark.parametrize("name,tag", [("zju377_mono", "s64"), ("h36m", "s64"), ("zju377_mono", "s32")])
+def test_shade_composite_against_reference(scene, name, tag):
+    """Loop D on the reference's own tracer output (fixtures f5 + f6)."""
+    from arah_release_amd import config, hip, renderer
+    g5 = golden("f5_tracer_%s.npz" % tag)
+    g = golden("f6_shade_%s_%s.npz" % (name, tag))
+    dev = torch.device("cuda:0")
+    S, nn, nfar = int(g["n_steps"]), int(g["n_near"]), int(g["n_far"])
+    model, cfg = config.build_synthetic_model(name, S, nn, nfar, device=dev)
+    inputs = _tracer_inputs(scene, g5, dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    T34 = g5["sampler_transforms34"].reshape(-1, S, 3, 4)
+    T44 = np.concatenate([T34, np.tile(np.array([0, 0, 0, 1], np.float32), T34.shape[:2] + (1, 1))], axis=2)
+    samp = hip.Sampling(dev, S, nn, nfar, cfg["model"]["cano_view_dirs"], False)
+    rgb, acc, vol = hip.shade_composite(frame, hip.Workspace(dev), samp, inputs["ray_dirs"][0], T(g5["sampler_dists"]),
+                                        T(g5["sampler_pts"]), T(T44), T(g5["sampler_converge_mask"].astype(np.uint8)))
+    vm = g["vol_mask"]
+    np.testing.assert_array_equal(vol.cpu().numpy().astype(bool), vm)
+    np.testing.assert_allclose(rgb.cpu().numpy()[vm], g["rgb"], rtol=1e-3, atol=5e-5)
+    np.testing.assert_allclose(acc.cpu().numpy()[vm], g["acc"][:, 0], rtol=1e-3, atol=5e-5)
+    assert np.abs(rgb.cpu().numpy()[~vm]).max(initial=0) == 0
+
+
+@gpu
+@pytest.mark.parametrize("fname,name", [("f7_forward_zju377_mono_64x64_s64.npz", "zju377_mono"),
+                                        ("f7_forward_zju313_64x64_s64.npz", "zju313"),
+                                        ("f7_forward_h36m_48x48_s32.npz", "h36m"),
+                                        ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono")])
+def test_forward_against_reference(scene, fname, name):
+    """MetaAvatarRender.forward(inputs, eval=True): dict in / dict out vs the reference's dict (f7)."""
+    from arah_release_amd import config
+    g = golden(fname)
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model(name, int(g["n_steps"]), int(g["n_near"]), int(g["n_far"]), device=dev)
+    inputs = scene.make_inputs(int(g["H"]), int(g["W"]), frame_idx=int(g["frame_idx"]), device=dev)
+    with torch.no_grad():
+        out = model(inputs, gen_cano_mesh=False, eval=True)
+    assert set(out.keys()) == {"points_cam", "network_body_mask", "rgb_values", "sdf_params"}
+    np.testing.assert_allclose(out["sdf_params"][0][0, :16].cpu().numpy(), g["sdf_param0"], rtol=1e-5, atol=1e-7)
+    mask = out["network_body_mask"][0].cpu().numpy()
+    assert mask.dtype == bool and (mask == g["network_body_mask"]).mean() >= 0.995
+    rgb = out["rgb_values"][0].cpu().numpy()
+    assert psnr(rgb, g["rgb_values"]) >= 45.0
+    pc = out["points_cam"][0].cpu().numpy()
+    hit, hit_ref = np.abs(pc).sum(-1) > 0, np.abs(g["points_cam"]).sum(-1) > 0
+    assert (hit == hit_ref).mean() >= 0.995
+    assert_rows_close(pc[hit & hit_ref], g["points_cam"][hit & hit_ref], atol=2e-4, frac=0.999)
+
+
+@gpu
+def test_full_size_properties(scene):
+    """BASELINE config 2 size (512x512, 64 samples/ray): properties that need no oracle.
+    Rays are independent, so (i) rendering a permutation of the rays gives the permuted image
+    bit-for-bit, (ii) rendering two halves separately equals rendering them together, (iii) colours
+    are convex combinations of sigmoid outputs: 0 <= rgb <= acc <= 1."""
+    from arah_release_amd import config, hip, renderer
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model("zju377_mono", device=dev)
+    inputs = scene.make_inputs(512, 512, frame_idx=7, device=dev)
+    N = inputs["ray_dirs"].shape[1]
+    assert N > 100000
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    ws = hip.Workspace(dev)
+    samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
+    pose = torch.eye(4)[:3]
+    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+    rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam, d, nf, pose)
+    torch.cuda.synchronize()
+    assert float(rgb.min()) >= 0 and float(acc.max()) <= 1.0
+    assert bool((rgb.max(dim=-1)[0] <= acc + 1e-5).all())
+    assert 0.05 < float(conv.float().mean()) < 0.6 and float(vol.float().mean()) > 0.9
+    perm = torch.randperm(N, generator=torch.Generator().manual_seed(1)).to(dev)
+    rgb_p, _, vol_p, acc_p, dists_p, conv_p = hip.render(frame, ws, samp, cam, d[perm].contiguous(),
+                                                         nf[perm].contiguous(), pose)
+    assert torch.equal(rgb_p, rgb[perm]) and torch.equal(conv_p, conv[perm]) and torch.equal(dists_p, dists[perm])
+    half = N // 2
+    rgb_a = hip.render(frame, ws, samp, cam, d[:half].contiguous(), nf[:half].contiguous(), pose)[0]
+    rgb_b = hip.render(frame, ws, samp, cam, d[half:].contiguous(), nf[half:].contiguous(), pose)[0]
+    assert torch.equal(torch.cat([rgb_a, rgb_b]), rgb)
+
+
+@gpu
+def test_edge_cases(ctx, scene):
+    """Empty ray set, rays whose interval is empty (near == far), a single ray."""
+    hip = ctx["hip"]
+    dev = ctx["dev"]
+    samp = hip.Sampling(dev, 64, 16, 16, False, False)
+    inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
+    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+    pose = torch.eye(4)[:3]
+    out = hip.render(ctx["frame"], ctx["ws"], samp, cam, d[:0].contiguous(), nf[:0].contiguous(), pose)
+    assert out[0].shape == (0, 3)
+    nf0 = nf[:128].clone()
+    nf0[:, 1] = nf0[:, 0]                       # near == far: diverged from the start (RT:190-193)
+    rgb, pcam, vol, acc, dists, conv = hip.render(ctx["frame"], ctx["ws"], samp, cam, d[:128].contiguous(), nf0, pose)
+    assert not bool(conv.any()) and torch.equal(dists, nf0[:, 0]) and float(pcam.abs().max()) == 0
+    one = hip.render(ctx["frame"], ctx["ws"], samp, cam, d[1000:1001].contiguous(), nf[1000:1001].contiguous(), pose)
+    many = hip.render(ctx["frame"], ctx["ws"], samp, cam, d[:2000].contiguous(), nf[:2000].contiguous(), pose)
+    assert torch.equal(one[0][0], many[0][1000])
+    with pytest.raises(ValueError):
+        hip.Sampling(dev, 16, 16, 16)           # n_steps < near + far + 1 (RT:346)
