@@ -14,8 +14,8 @@
 #include <string.h>
 
 #include "../../include/arah_hip.h"
-#include "mlp.hpp"
 #include "pointwise.hpp"
+#include "mlp.hpp"
 
 using namespace arah;
 
@@ -263,14 +263,7 @@ __device__ __forceinline__ void append_ids(bool keep, int id, int* list, int* co
 // per-point tail of the skinning network: logits -> w -> T, x_bar  (RFU:99, 13-34).
 // logit_row is this thread's private LDS row (>= 25 floats); it is overwritten with the 24 weights.
 __device__ __forceinline__ void skin_tail(float* logit_row, const float* sbones, V3 xhat, float (&T)[16], V3& xbar) {
-    {
-        float x[25], w[24];
-#pragma unroll
-        for (int i = 0; i < 25; ++i) x[i] = logit_row[i] * 20.0f;
-        hsoftmax<float>(x, w);
-#pragma unroll
-        for (int i = 0; i < 24; ++i) logit_row[i] = w[i];
-    }
+    hsoftmax_row(logit_row);
     blend(logit_row, sbones, T);
     xbar = apply34(T, xhat);
 }
@@ -401,15 +394,14 @@ __global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState 
 // ------------------------------------------------------------------------------------------
 // unit seam: skinning weights / forward LBS
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void k_skin_eval(FrameDev fr, const float* x_hat, int n, float* w_out,
+__global__ __launch_bounds__(kThreads, 4) void k_skin_eval(FrameDev fr, const float* x_hat, int n, float* w_out,
                                                          float* xbar_out, float* T_out, unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [64][4] normalised
     float* xraw = xin + 64 * 4;               // [64][4] raw
     float* sbones = xraw + 64 * 4;            // [24][16]
     float* logits = sbones + 24 * 16;         // [64][33]
-    float* act = logits + 64 * kLogitLd + 16; // [64][132]
-    act = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(act) + 15) & ~uintptr_t(15));
+    float* act = logits + 64 * kLogitLd;      // [64][132]; 64*33 floats keeps the 16-byte alignment
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
@@ -458,8 +450,7 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
     float* xraw = xin + 16 * 4;               // [16][4]
     float* sbones = xraw + 16 * 4;            // [24][16]
     float* logits = sbones + 24 * 16;         // [64][33]  (col = n*16 + j)
-    float* act = logits + 64 * kLogitLd + 16;
-    act = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(act) + 15) & ~uintptr_t(15));   // [64][132]
+    float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer   // [64][132]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
     const int n = list ? *count : n_direct;
@@ -568,18 +559,16 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
 
 // ------------------------------------------------------------------------------------------
 // loop C: 3-D Broyden on g(x) = LBS(x) - target, one iteration per launch (RFU:267-362,
-// broyden.py:4-78).  State per point id (dense index): xeval = point to evaluate now,
-// step = the update that led there, gx, Jinv, err_best; best x -> xbest[id] (raw canonical),
-// best T -> Tbest[id].  FIRST: evaluates g(x0), derives J^-1_0 from the same weights (RFU:327).
+// broyden.py:4-78).  The state of a live point is one 160-byte record that travels with it through
+// the ping-pong buffers in LIST ORDER: an iteration streams records in (coalesced), evaluates the
+// skinning MLP on 64 of them per tile, and streams the survivors out (ballot-compacted, coalesced).
+// Dense per-id outputs (best x, best T, |g|_best) are written exactly once, when a point retires.
+//   r0 = {x_eval(3), id}   r1 = {step(3), |g|_best}   r2 = {g(3), J0}   r3 = {J1..J4}   r4 = {J5..J8}
+//   r5 = {x_best(3), -}    r6..r9 = T_best (4x4 row-major)
+// FIRST: evaluates g(x0), derives J^-1_0 from the same weights (RFU:327); nobody retires.
 // ------------------------------------------------------------------------------------------
-struct Broyden3State {
-    float* xeval;     // [Q][3]
-    float* step;      // [Q][3]
-    float* gx;        // [Q][3]
-    float* Jinv;      // [Q][9]
-    float* err_best;  // [Q]
-    float* xbest;     // [Q][3]
-    float* Tbest;     // [Q][16]
+struct CanonRec {
+    f32x4 r[10];
 };
 
 struct TargetSrc {
@@ -595,98 +584,165 @@ __device__ __forceinline__ V3 target_of(const TargetSrc& ts, const BodyConst& bc
     return V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
 }
 
+struct CanonOut {
+    float* pts;    // [Q][3] raw canonical best x
+    float* T;      // [Q][16]
+    float* err;    // [Q]
+};
+
+__device__ __forceinline__ void canon_flush(const CanonOut& o, int id, const f32x4 xb, const f32x4 (&Tb)[4], float eb) {
+    o.pts[(size_t)id * 3] = xb[0];
+    o.pts[(size_t)id * 3 + 1] = xb[1];
+    o.pts[(size_t)id * 3 + 2] = xb[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) reinterpret_cast<f32x4*>(o.T + (size_t)id * 16)[c] = Tb[c];
+    o.err[id] = eb;
+}
+
 template <bool FIRST>
-__global__ __launch_bounds__(kThreads) void k_canon_iter(FrameDev fr, Broyden3State st, TargetSrc ts, const int* list,
-                                                          const int* count, int* next_list, int* next_count,
-                                                          unsigned long long* ctr) {
+__global__ __launch_bounds__(kThreads, 4) void k_canon_iter(FrameDev fr, const CanonRec* __restrict__ rin,
+                                                             CanonRec* __restrict__ rout, const int* count,
+                                                             int* next_count, TargetSrc ts, CanonOut outp,
+                                                             unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [64][4] normalised
-    float* xraw = xin + 64 * 4;               // [64][4]
+    float* xraw = xin + 64 * 4;               // [64][4] raw x + id
     float* sbones = xraw + 64 * 4;            // [24][16]
-    int* ids = reinterpret_cast<int*>(sbones + 24 * 16);   // [64]
-    float* logits = reinterpret_cast<float*>(ids + 64);    // [64][33]
-    float* act = logits + 64 * kLogitLd + 16;
-    act = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(act) + 15) & ~uintptr_t(15));
+    float* logits = sbones + 24 * 16 + 64;    // [64][33]
+    float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = *count;
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
         if (tid < kTile) {
             const int i = tile * kTile + tid;
-            const int id = i < n ? list[i] : -1;
-            ids[tid] = id;
-            V3 p = V3{0.f, 0.f, 0.f};
-            if (id >= 0) p = V3{st.xeval[(size_t)id * 3], st.xeval[(size_t)id * 3 + 1], st.xeval[(size_t)id * 3 + 2]};
-            const V3 q = normalize_pt(fr.bc, p);
+            f32x4 r0 = {0.f, 0.f, 0.f, __int_as_float(-1)};
+            if (i < n) r0 = rin[i].r[0];
+            const V3 q = normalize_pt(fr.bc, V3{r0[0], r0[1], r0[2]});
             reinterpret_cast<f32x4*>(xin)[tid] = f32x4{q.x, q.y, q.z, 0.f};
-            reinterpret_cast<f32x4*>(xraw)[tid] = f32x4{p.x, p.y, p.z, 0.f};
+            reinterpret_cast<f32x4*>(xraw)[tid] = r0;
         }
         __syncthreads();
         skin_mlp(fr.skin, xin, act, logits, wave, lane);
         if (tid == 0) count_add(ctr, min(kTile, n - tile * kTile));
         if (tid < kTile) {
-            const int id = ids[tid];
-            bool keep = false;
+            const int i = tile * kTile + tid;
+            const f32x4 r0 = reinterpret_cast<const f32x4*>(xraw)[tid];
+            const int id = __float_as_int(r0[3]);
+            const V3 x = V3{r0[0], r0[1], r0[2]};
+            bool keep = false, improved = false;
+            float T[16], gx[3], dg[3], dx[3], eb = 0.f;
             if (id >= 0) {
-                float T[16];
-                V3 xb;
-                const V3 x = V3{xraw[tid * 4], xraw[tid * 4 + 1], xraw[tid * 4 + 2]};
-                skin_tail(logits + tid * kLogitLd, sbones, x, T, xb);
+                f32x4 r1, r2;
+                if (!FIRST) {   // issued before the softmax/blend below, consumed after it
+                    r1 = rin[i].r[1];
+                    r2 = rin[i].r[2];
+                }
+                V3 xbar;
+                skin_tail(logits + tid * kLogitLd, sbones, x, T, xbar);
                 const V3 tg = target_of(ts, fr.bc, id);
-                float gnew[3] = {xb.x - tg.x, xb.y - tg.y, xb.z - tg.z};
+                const float gnew[3] = {xbar.x - tg.x, xbar.y - tg.y, xbar.z - tg.z};
+                if (FIRST) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
+                    eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                    keep = true;                                        // every point takes at least one step
+                } else {
+                    eb = r1[3];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        dx[r] = r1[r];
+                        dg[r] = gnew[r] - r2[r];
+                        gx[r] = r2[r] + dg[r];                          // broyden.py:50-51
+                    }
+                    const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                    improved = err < eb;                                // broyden.py:54-61
+                    if (improved) eb = err;
+                    keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
+                }
+            }
+            // survivors get their slot in the output stream now, so that the record can be written
+            // piece by piece (short register live ranges)
+            const unsigned long long m = __ballot(keep);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(next_count, __popcll(m));
+            base = __shfl(base, 0);
+            CanonRec* dst = rout + base + __popcll(m & ((1ull << lane) - 1ull));
+            if (id >= 0) {
+                // best iterate: the new one if it improved, else carried over (FIRST: x0 and the
+                // nearest-vertex T0, broyden.py:41); retiring points hand it in
+                f32x4 xb, Tb[4];
+                if (improved) {
+                    xb = f32x4{x.x, x.y, x.z, 0.f};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Tb[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
+                } else {
+                    xb = rin[i].r[5];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Tb[c] = rin[i].r[6 + c];
+                }
+                if (keep) {
+                    dst->r[5] = xb;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dst->r[6 + c] = Tb[c];
+                } else {
+                    canon_flush(outp, id, xb, Tb, eb);
+                }
+            }
+            if (keep) {
                 float J[9], stp[3];
                 if (FIRST) {
                     inv3_of44(T, J);                                    // RFU:327-328
-                    const float err = sqrtf(gnew[0] * gnew[0] + gnew[1] * gnew[1] + gnew[2] * gnew[2]);
-                    st.err_best[id] = err;                              // x_best = x0, T_best = T0 already stored
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        stp[r] = -(J[r * 3] * gnew[0] + J[r * 3 + 1] * gnew[1] + J[r * 3 + 2] * gnew[2]);
-                        st.gx[(size_t)id * 3 + r] = gnew[r];
-                    }
-                    keep = true;                                        // every point takes at least one step
+                    for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
                 } else {
-                    float gx[3], dg[3], dx[3];
+                    const f32x4 r2 = rin[i].r[2], r3 = rin[i].r[3], r4 = rin[i].r[4];
+                    J[0] = r2[3];
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        dx[r] = st.step[(size_t)id * 3 + r];
-                        const float gold = st.gx[(size_t)id * 3 + r];
-                        dg[r] = gnew[r] - gold;
-                        gx[r] = gold + dg[r];                           // broyden.py:50-51
+                    for (int e = 0; e < 4; ++e) {
+                        J[1 + e] = r3[e];
+                        J[5 + e] = r4[e];
                     }
-                    const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                    float eb = st.err_best[id];
-                    if (err < eb) {                                     // broyden.py:54-61
-                        eb = err;
-                        st.err_best[id] = err;
-                        st.xbest[(size_t)id * 3] = x.x;
-                        st.xbest[(size_t)id * 3 + 1] = x.y;
-                        st.xbest[(size_t)id * 3 + 2] = x.z;
-                        store_T(st.Tbest + (size_t)id * 16, T);
-                    }
-                    keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
-                    if (keep) {
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) J[e] = st.Jinv[(size_t)id * 9 + e];
-                        broyden_update<3>(J, dx, dg, gx, stp);
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) st.gx[(size_t)id * 3 + r] = gx[r];
-                    }
+                    broyden_update<3>(J, dx, dg, gx, stp);
                 }
-                if (keep) {
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) st.Jinv[(size_t)id * 9 + e] = J[e];
-                    st.step[(size_t)id * 3] = stp[0];
-                    st.step[(size_t)id * 3 + 1] = stp[1];
-                    st.step[(size_t)id * 3 + 2] = stp[2];
-                    st.xeval[(size_t)id * 3] = x.x + stp[0];
-                    st.xeval[(size_t)id * 3 + 1] = x.y + stp[1];
-                    st.xeval[(size_t)id * 3 + 2] = x.z + stp[2];
-                }
+                dst->r[0] = f32x4{x.x + stp[0], x.y + stp[1], x.z + stp[2], r0[3]};
+                dst->r[1] = f32x4{stp[0], stp[1], stp[2], eb};
+                dst->r[2] = f32x4{gx[0], gx[1], gx[2], J[0]};
+                dst->r[3] = f32x4{J[1], J[2], J[3], J[4]};
+                dst->r[4] = f32x4{J[5], J[6], J[7], J[8]};
             }
-            append_ids(keep, id, next_list, next_count);
         }
         __syncthreads();
+    }
+}
+
+// records still alive after the last iteration hand in their best iterate
+__global__ void k_canon_drain(const CanonRec* __restrict__ rin, const int* count, CanonOut outp) {
+    const int n = *count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const f32x4 r0 = rin[i].r[0];
+        f32x4 Tb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Tb[c] = rin[i].r[6 + c];
+        canon_flush(outp, __float_as_int(r0[3]), rin[i].r[5], Tb, rin[i].r[1][3]);
+    }
+}
+
+// initial records from (x0, T0) stored densely by id: rec[i] = {x0, id, ..., best = (x0, T0)}
+__global__ void k_canon_seed(const int* list, const int* count, const float* x0, const float* T0, CanonRec* rout) {
+    const int n = *count;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int id = list[i];
+        const f32x4 x = {x0[(size_t)id * 3], x0[(size_t)id * 3 + 1], x0[(size_t)id * 3 + 2], __int_as_float(id)};
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rout[i].r[0] = x;
+        rout[i].r[1] = z;
+        rout[i].r[2] = z;
+        rout[i].r[3] = z;
+        rout[i].r[4] = z;
+        rout[i].r[5] = x;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) rout[i].r[6 + c] = reinterpret_cast<const f32x4*>(T0 + (size_t)id * 16)[c];
     }
 }
 
@@ -744,8 +800,7 @@ __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4St
     float* sbones = outv + 64 * 4;            // [24][16]
     int* ids = reinterpret_cast<int*>(sbones + 24 * 16);
     float* logits = reinterpret_cast<float*>(ids + 64);    // [64][33]
-    float* act = logits + 64 * kLogitLd + 16;
-    act = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(act) + 15) & ~uintptr_t(15));   // [64][260]
+    float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer   // [64][260]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = *count;
     const float scale = sdf_scale(fr.bc);
@@ -946,17 +1001,6 @@ __global__ void k_iota(int n, int* list, int* count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) list[i] = i;
     if (i == 0) *count = n;
-}
-
-// seed state of loop C: xeval = xbest = x0 (already in xbest by the nearest-vertex kernel)
-__global__ void k_canon_seed(const int* list, const int* count, const float* xbest, float* xeval) {
-    const int n = *count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int id = list[i];
-        xeval[(size_t)id * 3] = xbest[(size_t)id * 3];
-        xeval[(size_t)id * 3 + 1] = xbest[(size_t)id * 3 + 1];
-        xeval[(size_t)id * 3 + 2] = xbest[(size_t)id * 3 + 2];
-    }
 }
 
 // RT:447-461, 549-555: normalise the solution, converged = |g|_best < thr; masked-off samples are zeros
@@ -1252,7 +1296,8 @@ struct Workspace {
     float *o_xnorm, *o_Tray, *o_start, *o_end, *o_acc;
     uint8_t* o_conv;
     // per sample
-    float *q_xeval, *q_step, *q_gx, *q_Jinv, *q_err;
+    float* q_err;
+    CanonRec *recA, *recB;
     float *o_z, *o_pts, *o_T;
     uint8_t* o_mask;
     uint8_t* q_smask;
@@ -1292,11 +1337,9 @@ Workspace carve(void* base, int n_rays, int n_steps) {
     w.o_conv = c.take<uint8_t>(N);
     w.listA = c.take<int>(Q);
     w.listB = c.take<int>(Q);
-    w.q_xeval = c.take<float>(Q * 3);
-    w.q_step = c.take<float>(Q * 3);
-    w.q_gx = c.take<float>(Q * 3);
-    w.q_Jinv = c.take<float>(Q * 9);
     w.q_err = c.take<float>(Q);
+    w.recA = c.take<CanonRec>(Q);
+    w.recB = c.take<CanonRec>(Q);
     w.o_z = c.take<float>(Q);
     w.o_pts = c.take<float>(Q * 3);
     w.o_T = c.take<float>(Q * 16);
@@ -1653,23 +1696,26 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
     return check_launch();
 }
 
-// shared driver of loop C: assumes xbest/Tbest already hold (x0, T0) for every id in listA, counts[0] = size
-static int run_broyden3(const FrameDev& fd, Workspace& w, Broyden3State st, TargetSrc ts, long long max_pts,
+// shared driver of loop C: (x0, T0) are stored densely by id in out.pts / out.T for every id in listA
+static int run_broyden3(const FrameDev& fd, Workspace& w, TargetSrc ts, CanonOut outp, long long max_pts,
                         hipStream_t s) {
-    int* cnt = w.counts;   // cnt[it] = size of the list consumed by iteration it
+    int* cnt = w.counts;   // cnt[it] = number of records consumed by iteration it
     const int g = grid_for(max_pts, kTile);
     hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
-                       (const int*)&cnt[0], (const float*)st.xbest, st.xeval);
+                       (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, w.recA);
     for (int it = 0; it <= kBroydenSteps; ++it) {
-        int* lin = (it & 1) ? w.listB : w.listA;
-        int* lout = (it & 1) ? w.listA : w.listB;
+        const CanonRec* rin = (it & 1) ? w.recB : w.recA;
+        CanonRec* rout = (it & 1) ? w.recA : w.recB;
         if (it == 0)
-            hipLaunchKernelGGL(k_canon_iter<true>, dim3(g), dim3(kThreads), kLdsSkin, s, fd, st, ts, (const int*)lin,
-                               (const int*)&cnt[it], lout, &cnt[it + 1], &w.ctr->n_skin_fwd);
+            hipLaunchKernelGGL(k_canon_iter<true>, dim3(g), dim3(kThreads), kLdsSkin, s, fd, rin, rout,
+                               (const int*)&cnt[it], &cnt[it + 1], ts, outp, &w.ctr->n_skin_fwd);
         else
-            hipLaunchKernelGGL(k_canon_iter<false>, dim3(g), dim3(kThreads), kLdsSkin, s, fd, st, ts, (const int*)lin,
-                               (const int*)&cnt[it], lout, &cnt[it + 1], &w.ctr->n_skin_fwd);
+            hipLaunchKernelGGL(k_canon_iter<false>, dim3(g), dim3(kThreads), kLdsSkin, s, fd, rin, rout,
+                               (const int*)&cnt[it], &cnt[it + 1], ts, outp, &w.ctr->n_skin_fwd);
     }
+    const int last = kBroydenSteps + 1;
+    hipLaunchKernelGGL(k_canon_drain, dim3(grid_for(max_pts, 256)), dim3(256), 0, s,
+                       (const CanonRec*)((last & 1) ? w.recB : w.recA), (const int*)&cnt[last], outp);
     return check_launch();
 }
 
@@ -1686,13 +1732,12 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
     hipMemcpyAsync(T, T0, (size_t)n * 16 * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, n, w.listA, &w.counts[0]);
-    Broyden3State st{w.q_xeval, w.q_step, w.q_gx, w.q_Jinv, w.q_err, x, T};
     TargetSrc ts;
     ts.tgt = tgt;
     ts.rs = make_rays(nullptr, nullptr, 1);
     ts.depth = nullptr;
     ts.n_steps = 1;
-    int rc = run_broyden3(fd, w, st, ts, n, s);
+    int rc = run_broyden3(fd, w, ts, CanonOut{x, T, w.q_err}, n, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_broyden3_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, (const float*)w.q_err, err, conv);
     return check_launch();
@@ -1781,13 +1826,12 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     hipLaunchKernelGGL(k_nearest_invlbs<SRC_SAMPLES>, dim3(grid_for(Q, kKnnThreads)), dim3(kKnnThreads), kLdsKnn, s, fd,
                        (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA, (const int*)&w.counts[0], 0,
                        (int*)nullptr, pts, T, &w.ctr->n_knn);
-    Broyden3State st{w.q_xeval, w.q_step, w.q_gx, w.q_Jinv, w.q_err, pts, T};
     TargetSrc ts;
     ts.tgt = nullptr;
     ts.rs = rs;
     ts.depth = z;
     ts.n_steps = S;
-    int rc = run_broyden3(fd, w, st, ts, Q, s);
+    int rc = run_broyden3(fd, w, ts, CanonOut{pts, T, w.q_err}, Q, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_canon_finalize, dim3(gq), dim3(256), 0, s, fd, (int)Q, (const uint8_t*)w.q_smask,
                        (const float*)w.q_err, pts, T, mask);

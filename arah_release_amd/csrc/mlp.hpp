@@ -20,6 +20,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "pointwise.hpp"
+
 namespace arah {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -38,6 +40,29 @@ __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, 
     const int j = lane & 15, g = lane >> 4;
     const float* bptr = act + j * ld + 4 * g;
     const f32x4* aptr = reinterpret_cast<const f32x4*>(wp) + (size_t)mt0 * KC * 64 + lane;
+    if constexpr (KC * MT <= 8) {
+        // narrow layer: the whole A slice of this wave is 8 VGPR-quads -- load it once, no dependent waits
+        f32x4 a_all[MT][KC];
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int kc = 0; kc < KC; ++kc) a_all[m][kc] = aptr[(m * KC + kc) * 64];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            __builtin_amdgcn_sched_barrier(0);   // keep the B fragments of later chunks from being hoisted (VGPRs)
+            f32x4 b[kNT];
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) b[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kc * 16);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < kNT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_all[m][kc][t], b[n][t], acc[m][n], 0, 0, 0);
+        }
+        return;
+    }
     f32x4 a_cur[MT], a_nxt[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_cur[m] = aptr[(m * KC) * 64];
@@ -290,9 +315,12 @@ struct SkinNet {
 constexpr int kSkinLd = 132;
 constexpr int kLogitLd = 33;
 
+// Softplus(beta=100): log1p(exp(100 x))/100 == max(x,0) + log(1 + exp(-|100 x|))/100.  The correction is
+// <= 0.00693 and needs only ABSOLUTE accuracy (~1e-9 here), so hardware exp2/log2 are enough; for
+// 100 x > 20 it vanishes in fp32 and the result is x, like torch's threshold branch.
 __device__ __forceinline__ float softplus100(float x) {
-    const float bx = 100.0f * x;
-    return bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
+    const float e = exp_fast(-fabsf(100.0f * x));
+    return fmaxf(x, 0.f) + __builtin_amdgcn_logf(1.0f + e) * 6.93147180559945e-3f;
 }
 
 // xin LDS [64][4] normalised coords -> logits LDS [64][kLogitLd] (25 valid, un-scaled)

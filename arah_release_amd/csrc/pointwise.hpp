@@ -59,16 +59,32 @@ __device__ __forceinline__ Dual3 operator/(Dual3 a, Dual3 b) {
     const float q = a.v / b.v, ib = 1.0f / b.v;
     return Dual3{q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib}};
 }
+// exp(y) for y <= ~88: explicit ln2 split so that the hardware exp2 only sees |r*log2e| <= 0.5
+// (v_exp_f32 is ~1 ulp there; feeding it y*log2e directly loses |y| ulps of the argument).
+__device__ __forceinline__ float exp_fast(float y) {
+    y = fmaxf(y, -87.0f);
+    const float n = rintf(y * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, y);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+}
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ float one_minus(float a) { return 1.0f - a; }
 __device__ __forceinline__ Dual3 one_minus(Dual3 a) { return Dual3{1.0f - a.v, {-a.d[0], -a.d[1], -a.d[2]}}; }
-__device__ __forceinline__ float sigm(float x) { return 1.0f / (1.0f + expf(-x)); }
+// sigmoid via exp(-|x|): no overflow, ~2 ulp
+__device__ __forceinline__ float sigm(float x) {
+    const float e = exp_fast(-fabsf(x));
+    const float s = rcp_fast(1.0f + e);
+    return x >= 0.f ? s : e * s;
+}
 __device__ __forceinline__ Dual3 sigm(Dual3 x) {
-    const float s = 1.0f / (1.0f + expf(-x.v)), ds = s * (1.0f - s);
+    const float s = sigm(x.v), ds = s * (1.0f - s);
     return Dual3{s, {ds * x.d[0], ds * x.d[1], ds * x.d[2]}};
 }
-__device__ __forceinline__ float expo(float x) { return expf(x); }
+__device__ __forceinline__ float expo(float x) { return exp_fast(x); }
 __device__ __forceinline__ Dual3 expo(Dual3 x) {
-    const float e = expf(x.v);
+    const float e = exp_fast(x.v);
     return Dual3{e, {e * x.d[0], e * x.d[1], e * x.d[2]}};
 }
 __device__ __forceinline__ float val(float x) { return x; }
@@ -143,6 +159,63 @@ __device__ __forceinline__ void hsoftmax(const S (&x)[25], S (&w)[24]) {
         w[22 + k] = w[20 + k] * sg[22 + k];
         w[20 + k] = w[20 + k] * one_minus(sg[22 + k]);
     }
+}
+
+// In-place float version on a thread-private LDS row: in 25 raw logits, out 24 weights.  Same arithmetic
+// as hsoftmax<float>(20 * logits); the 25 sigmoids run in a rolled loop so that they do not all sit in
+// VGPRs at once (the fully unrolled form needs > 128 registers next to the MFMA accumulators).
+__device__ __forceinline__ void hsoftmax_row(float* row) {
+    float ra, rb, rc, sa, sb, sc;
+    softmax3<float>(row[1] * 20.0f, row[2] * 20.0f, row[3] * 20.0f, ra, rb, rc);
+    softmax3<float>(row[12] * 20.0f, row[13] * 20.0f, row[14] * 20.0f, sa, sb, sc);
+#pragma unroll 1
+    for (int i = 0; i < 25; ++i) row[i] = sigm(row[i] * 20.0f);
+    float w[24];
+    const float g0 = row[0];
+    w[1] = g0 * ra;
+    w[2] = g0 * rb;
+    w[3] = g0 * rc;
+    w[0] = 1.0f - g0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float g = row[4 + k];
+        w[4 + k] = w[1 + k] * g;
+        w[1 + k] = w[1 + k] * (1.0f - g);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float g = row[7 + k];
+        w[7 + k] = w[4 + k] * g;
+        w[4 + k] = w[4 + k] * (1.0f - g);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float g = row[10 + k];
+        w[10 + k] = w[7 + k] * g;
+        w[7 + k] = w[7 + k] * (1.0f - g);
+    }
+    const float g24 = row[24];
+    w[12] = w[9] * g24 * sa;
+    w[13] = w[9] * g24 * sb;
+    w[14] = w[9] * g24 * sc;
+    w[9] = w[9] * (1.0f - g24);
+    {
+        const float g = row[15];
+        w[15] = w[12] * g;
+        w[12] = w[12] * (1.0f - g);
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl) {   // 13,14 -> 16,17 -> 18,19 -> 20,21 -> 22,23
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = (lvl == 0 ? 13 : 14 + 2 * lvl) + k, c = 16 + 2 * lvl + k;
+            const float g = row[c];
+            w[c] = w[p] * g;
+            w[p] = w[p] * (1.0f - g);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 24; ++i) row[i] = w[i];
 }
 
 // T = sum_j w_j A_j  (RFU:26).  w: 24 floats (LDS or global, stride 1), bones: [24][16] in LDS.
