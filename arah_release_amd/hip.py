@@ -46,7 +46,8 @@ class ArahFrame(C.Structure):
                 ("skin_w0", _fp), ("skin_wp", _fp * 3), ("skin_w4p", _fp), ("skin_bias", _fp),
                 ("col_w0p", _fp), ("col_w1p", _fp), ("col_w2p", _fp), ("col_w3ap", _fp), ("col_w3bp", _fp),
                 ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
-                ("verts4", _fp), ("vert_weights", _fp), ("bones", _fp),
+                ("verts4", _fp), ("knn_spheres", _fp), ("knn_grid", _fp), ("knn_cells", _fp),
+                ("verts", _fp), ("vert_weights", _fp), ("bones", _fp),
                 ("beta", C.c_float), ("trans", C.c_float * 3), ("center", C.c_float * 3),
                 ("coord_min", C.c_float), ("coord_max", C.c_float), ("n_verts", C.c_int32),
                 ("col_mode", C.c_int32)]

@@ -122,7 +122,11 @@ typedef struct ArahFrame {
     const float* col_w4p;       /* packed [256][256] */
     const float* col_w5;        /* [3][256] */
     const float* col_bias;      /* b0'[256] b1[256] b2[128] b3'[256] b4[256] b5[4] */
-    const float* verts4;        /* [n_verts_pad][4] */
+    const float* verts4;        /* [256][28][4] k-d clustered vertices (x, y, z, original index) */
+    const float* knn_spheres;   /* [256][4] bounding spheres of the clusters */
+    const void* knn_grid;       /* grid geometry (device) */
+    const void* knn_cells;      /* [n_cells][64] candidate clusters per cell */
+    const float* verts;         /* caller's [n_verts][3] */
     const float* vert_weights;  /* caller's */
     const float* bones;         /* caller's [24][16] */
     float beta;
