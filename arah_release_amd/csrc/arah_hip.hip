@@ -1357,6 +1357,61 @@ __global__ void k_broyden3_finalize(int n, const float* err_best, float* err_out
     conv[i] = err_best[i] < kRootThresh ? 1 : 0;
 }
 
+// VolSDF density of a metric SDF value (IDR:366-368)
+__device__ __forceinline__ float volsdf_density(float sdf, float inv_beta) {
+    const float sgn = (-sdf > 0.f) ? 1.f : ((-sdf < 0.f) ? -1.f : 0.f);
+    return fmaxf(inv_beta * (0.5f + 0.5f * sgn * (1.0f - expf(-fabsf(sdf) * inv_beta))), 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// loop D, pass 1 (exact lazy shading): SDF value -> density for every valid sample.  A sample whose
+// density is exactly +0 (outside the surface by more than ~104 beta: exp underflows in fp32) has
+// alpha = 1 - exp(-0 * delta) = 0 and weight 0 whatever its colour, and it scales the transmittance by
+// (1 - 0 + 1e-7) independently of its colour (IDR:387-394).  Its normal and colour are therefore dead
+// values: only samples with density > 0 go on to pass 2 (k_shade).  The composited image is
+// bit-identical to shading everything (tests/test_hip_parity.py::test_lazy_shading_is_exact).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
+                                                       f32x4* shaded, int* next_list, int* next_count,
+                                                       unsigned long long* ctr_fwd) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;
+    float* outv = xin + 64 * 4;
+    int* ids = reinterpret_cast<int*>(outv + 64 * 4);
+    float* actA = reinterpret_cast<float*>(ids + 64);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = *count;
+    const float scale = sdf_scale(fr.bc);
+    const float inv_beta = 1.0f / fminf(fmaxf(fabsf(fr.beta), 1e-6f), 1e6f);
+    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+        if (tid < kTile) {
+            const int i = tile * kTile + tid;
+            const int id = i < n ? list[i] : -1;
+            ids[tid] = id;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (id >= 0) x = f32x4{pts[(size_t)id * 3], pts[(size_t)id * 3 + 1], pts[(size_t)id * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = x;
+        }
+        __syncthreads();
+        f32x4 dlast[kSdfMT][kNT];
+        sdf_trunk<false>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head(fr.sdf, actA, kSdfLd, outv, 4, tid);
+        __syncthreads();
+        if (tid == 0) count_add(ctr_fwd, min(kTile, n - tile * kTile));
+        if (tid < kTile) {
+            const int id = ids[tid];
+            bool keep = false;
+            if (id >= 0) {
+                const float dens = volsdf_density(outv[tid * 4] * scale, inv_beta);
+                shaded[id] = f32x4{0.f, 0.f, 0.f, dens};
+                keep = dens > 0.f;
+            }
+            append_ids(keep, id, next_list, next_count);
+        }
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // loop D: SDF value + normal (reverse sweep) + colour MLP + VolSDF density per valid sample
 // (IDR:291-368), then per-ray compositing (IDR:370-394)
@@ -1461,9 +1516,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
             count_add(ctr_col, cnt);
         }
         if (tid < kTile && ids[tid] >= 0) {
-            const float sdf = outv[tid * 4] * scale;                    // IDR:359
-            const float sgn = (-sdf > 0.f) ? 1.f : ((-sdf < 0.f) ? -1.f : 0.f);
-            const float dens = fmaxf(inv_beta * (0.5f + 0.5f * sgn * (1.0f - expf(-fabsf(sdf) * inv_beta))), 0.f);   // IDR:368
+            const float dens = volsdf_density(outv[tid * 4] * scale, inv_beta);   // IDR:359, 368
             shaded[ids[tid]] = f32x4{rgbv[tid * 4], rgbv[tid * 4 + 1], rgbv[tid * 4 + 2], dens};
         }
         __syncthreads();
@@ -1720,6 +1773,7 @@ void setup_attributes() {
     allow_lds(k_sdf_eval<false>, kLdsSdfFwd);
     allow_lds(k_sdf_eval<true>, kLdsSdfGrad);
     allow_lds(k_sdf_march, kLdsSdfFwd);
+    allow_lds(k_density, kLdsSdfFwd);
     allow_lds(k_skin_eval, kLdsSkin);
     allow_lds(k_skin_jac, kLdsSkin);
     allow_lds(k_canon_iter<true>, kLdsSkin);
@@ -1733,7 +1787,7 @@ void setup_attributes() {
 }
 
 // optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
-hipEvent_t g_shade_ev0 = nullptr, g_shade_ev1 = nullptr;
+hipEvent_t g_shade_ev0 = nullptr, g_shade_ev1 = nullptr, g_density_ev0 = nullptr, g_density_ev1 = nullptr;
 
 KnnData knn_of(const FrameDev& fd) {
     return KnnData{fd.knn.sorted4, fd.knn.spheres, reinterpret_cast<const GridInfo*>(fd.knn.grid), fd.knn.cells};
@@ -1822,6 +1876,12 @@ const char* arah_dominant_kernel(void) { return "k_shade"; }
 int arah_set_shade_events(void* start_event, void* stop_event) {
     g_shade_ev0 = reinterpret_cast<hipEvent_t>(start_event);
     g_shade_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
+    return ARAH_OK;
+}
+
+int arah_set_density_events(void* start_event, void* stop_event) {
+    g_density_ev0 = reinterpret_cast<hipEvent_t>(start_event);
+    g_density_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
     return ARAH_OK;
 }
 
@@ -2220,15 +2280,25 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 255) / 256)), dim3(256), 0, s, mask, (int)Q, w.listA, &w.counts[0]);
     const int g = grid_for(Q, kTile);
+    const int* slist = w.listA;
+    const int* scount = &w.counts[0];
+    if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
+        if (g_density_ev0) hipEventRecord(g_density_ev0, s);
+        hipLaunchKernelGGL(k_density, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts, (const int*)w.listA,
+                           (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd);
+        if (g_density_ev1) hipEventRecord(g_density_ev1, s);
+        slist = w.listB;
+        scount = &w.counts[1];
+    }
     if (g_shade_ev0) hipEventRecord(g_shade_ev0, s);
     if (f->col_mode == ARAH_COLOR_IDR)
         hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(kThreads), lds_shade<true>(), s, fd, S, cfg->cano_view_dirs, dirs,
-                           pts, T, (const int*)w.listA, (const int*)&w.counts[0], 0, w.shaded, w.spill,
-                           &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col);
+                           pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad,
+                           &w.ctr->n_col);
     else
         hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(kThreads), lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs,
-                           pts, T, (const int*)w.listA, (const int*)&w.counts[0], 0, w.shaded, w.spill,
-                           &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col);
+                           pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad,
+                           &w.ctr->n_col);
     if (g_shade_ev1) hipEventRecord(g_shade_ev1, s);
     hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);

@@ -36,7 +36,7 @@ class ArahBody(C.Structure):
 
 class ArahSampling(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("n_near", C.c_int32), ("n_far", C.c_int32),
-                ("cano_view_dirs", C.c_int32), ("render_last_pt", C.c_int32),
+                ("cano_view_dirs", C.c_int32), ("render_last_pt", C.c_int32), ("full_shading", C.c_int32),
                 ("lin_steps", _fp), ("lin_near", _fp), ("lin_far", _fp)]
 
 
@@ -62,7 +62,8 @@ class ArahCounters(C.Structure):
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_trace", "arah_sample_canonicalize",
-           "arah_shade_composite", "arah_render", "arah_dominant_kernel", "arah_set_shade_events"]
+           "arah_shade_composite", "arah_render", "arah_dominant_kernel", "arah_set_shade_events",
+           "arah_set_density_events"]
 
 _lib = None
 
@@ -206,7 +207,8 @@ class Frame:
 class Sampling:
     """ArahSampling + the device linspace tables (bit-identical to torch.linspace on the CPU)."""
 
-    def __init__(self, device, n_steps=64, n_near=16, n_far=16, cano_view_dirs=True, render_last_pt=False):
+    def __init__(self, device, n_steps=64, n_near=16, n_far=16, cano_view_dirs=True, render_last_pt=False,
+                 full_shading=False):
         if n_steps < n_near + n_far + 1 or n_steps > ARAH_MAX_STEPS:
             raise ValueError("need n_near + n_far + 1 <= n_steps <= %d (ARAH_E_SAMPLING)" % ARAH_MAX_STEPS)
         self.lin_steps = torch.linspace(0.0, 1.0, n_steps, dtype=torch.float32).to(device)
@@ -215,6 +217,7 @@ class Sampling:
         s = ArahSampling()
         s.n_steps, s.n_near, s.n_far = int(n_steps), int(n_near), int(n_far)
         s.cano_view_dirs, s.render_last_pt = int(bool(cano_view_dirs)), int(bool(render_last_pt))
+        s.full_shading = int(bool(full_shading))
         s.lin_steps, s.lin_near, s.lin_far = _ptr(self.lin_steps), _ptr(self.lin_near), _ptr(self.lin_far)
         self.handle = s
         self.n_steps, self.n_near, self.n_far = n_steps, n_near, n_far
@@ -361,6 +364,16 @@ def set_shade_events(start=None, stop=None):
     a = C.c_void_p(start.cuda_event) if start is not None else None
     b = C.c_void_p(stop.cuda_event) if stop is not None else None
     _check(lib.arah_set_shade_events(a, b), "arah_set_shade_events")
+
+
+def set_density_events(start=None, stop=None):
+    lib = load_library()
+    for ev in (start, stop):
+        if ev is not None:
+            ev.record()
+    a = C.c_void_p(start.cuda_event) if start is not None else None
+    b = C.c_void_p(stop.cuda_event) if stop is not None else None
+    _check(lib.arah_set_density_events(a, b), "arah_set_density_events")
 
 
 def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):

@@ -11,6 +11,8 @@ evaluated per ray / per sample goes through the C ABI (hip.py -> libarah_hip.so)
 torch implementation of the hot loops in this package: without the HIP library or without a GPU
 the forward raises.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -92,6 +94,9 @@ class BodyRayTracing(nn.Module):
         self.low_vram = low_vram
         self._ws = None
         self._sampling = {}
+        # False: exact lazy shading (normals/colours only where the VolSDF density is > 0); True: shade every
+        # valid sample like the reference.  Same image either way (bit for bit); see DESIGN.md section 4.
+        self.full_shading = os.environ.get("ARAH_FULL_SHADING", "0") == "1"
 
     def workspace(self, device):
         if self._ws is None or self._ws.device != device:
@@ -99,10 +104,11 @@ class BodyRayTracing(nn.Module):
         return self._ws
 
     def sampling(self, device, cano_view_dirs=True, render_last_pt=False):
-        key = (str(device), bool(cano_view_dirs), bool(render_last_pt))
+        key = (str(device), bool(cano_view_dirs), bool(render_last_pt), bool(self.full_shading))
         if key not in self._sampling:
             self._sampling[key] = hip.Sampling(device, self.n_steps, self.near_surface_vol_samples,
-                                               self.far_surface_vol_samples, cano_view_dirs, render_last_pt)
+                                               self.far_surface_vol_samples, cano_view_dirs, render_last_pt,
+                                               self.full_shading)
         return self._sampling[key]
 
     def forward(self, sdf_network, skinning_model, cam_loc, ray_directions, body_bounds_intersections, loc,

@@ -92,6 +92,9 @@ typedef struct ArahSampling {
     int32_t n_steps, n_near, n_far;   /* configs/default.yaml:49-51 */
     int32_t cano_view_dirs;           /* model.cano_view_dirs */
     int32_t render_last_pt;           /* model.render_last_pt */
+    int32_t full_shading;             /* 0 (default): exact lazy shading -- normal + colour only for samples whose
+                                         density is > 0, the rest provably get weight 0; 1: shade every valid sample
+                                         like the reference does (same image, bit for bit) */
     /* device copies of torch.linspace(0, 1, k) for k = n_steps, n_near + 1, n_far (RT:317,330,340);
      * the caller builds them once per config so that depth samples are bit-identical to torch's */
     const float* lin_steps;
@@ -208,6 +211,8 @@ const char* arah_dominant_kernel(void);
  * arah_render records them on its stream immediately before / after the launch of the dominant
  * kernel (loop D's shading kernel).  Pass NULLs to switch it off.  Process-global, not thread safe. */
 int arah_set_shade_events(void* start_event, void* stop_event);
+/* same for the density pre-pass (k_density) of lazy shading */
+int arah_set_density_events(void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ def test_struct_sizes_match_header():
     import ctypes as C
     from arah_release_amd import hip
     assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 4 * 3 + 4   # padded to 8
-    assert C.sizeof(hip.ArahSampling) == 4 * 5 + 4 + 8 * 3
+    assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
     assert C.sizeof(hip.ArahCounters) == 64
 
 
@@ -305,6 +305,42 @@ def test_full_size_properties(scene):
     rgb_a = hip.render(frame, ws, samp, cam, d[:half].contiguous(), nf[:half].contiguous(), pose)[0]
     rgb_b = hip.render(frame, ws, samp, cam, d[half:].contiguous(), nf[half:].contiguous(), pose)[0]
     assert torch.equal(torch.cat([rgb_a, rgb_b]), rgb)
+
+
+@gpu
+@pytest.mark.parametrize("name", ["zju377_mono", "h36m"])
+def test_lazy_shading_is_exact(scene, name):
+    """Default pipeline shades (normal + colour) only samples whose VolSDF density is > 0; the others have
+    alpha == 0 exactly.  The image must equal the shade-everything image bit for bit, while the number of
+    colour evaluations drops."""
+    from arah_release_amd import config, hip, renderer
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model(name, device=dev)
+    inputs = scene.make_inputs(128, 128, frame_idx=4, device=dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    ws = hip.Workspace(dev)
+    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+    pose = torch.eye(4)[:3]
+    res, ncol = {}, {}
+    for full in (False, True):
+        for last in (False, True):
+            samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], last, full_shading=full)
+            ws.ensure(d.shape[0], 64)
+            ws.reset_counters()
+            res[(full, last)] = hip.render(frame, ws, samp, cam, d, nf, pose)
+            ncol[(full, last)] = ws.counters()["n_col"]
+    for last in (False, True):
+        lazy, full = res[(False, last)], res[(True, last)]
+        assert torch.equal(lazy[0], full[0]) and torch.equal(lazy[3], full[3]) and torch.equal(lazy[2], full[2])
+        assert 0 < ncol[(False, last)] < ncol[(True, last)]
 
 
 @gpu
