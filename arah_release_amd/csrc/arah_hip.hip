@@ -460,6 +460,10 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_clusters(const GridInfo* 
     }
 }
 
+struct CanonRec {   // loop C's travelling per-point state (layout documented at k_canon_iter)
+    f32x4 r[10];
+};
+
 struct KnnData {
     const float* sorted4;          // [kMaxVerts][4]  (x, y, z, original index)
     const float* spheres;          // [kMaxClusters][4]
@@ -496,7 +500,7 @@ template <int SRC>
 __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, KnnData kd, const float* pts, RaySet rs,
                                                                  const float* depth, int n_steps, const int* list,
                                                                  const int* count, int n_direct, int* idx_out,
-                                                                 float* x_out, float* T_out,
+                                                                 float* x_out, float* T_out, CanonRec* rec_out,
                                                                  unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* sv = smem;                              // [kMaxClusters][33][4] sorted vertices, one pad slot per cluster
@@ -565,6 +569,20 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         V3 xh = inverse_affine_apply(T, y);
         if (SRC == SRC_RAYS) xh = normalize_pt(fr.bc, xh);
         if (idx_out) idx_out[id] = bi;
+        if (SRC == SRC_SAMPLES && rec_out) {   // loop C starts from here: the record IS the initial state
+            const f32x4 x = {xh.x, xh.y, xh.z, __int_as_float(id)};
+            const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
+            CanonRec* r = rec_out + i;
+            r->r[0] = x;
+            r->r[1] = zz;
+            r->r[2] = zz;
+            r->r[3] = zz;
+            r->r[4] = zz;
+            r->r[5] = x;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r->r[6 + c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
+            continue;
+        }
         x_out[(size_t)id * 3 + 0] = xh.x;
         x_out[(size_t)id * 3 + 1] = xh.y;
         x_out[(size_t)id * 3 + 2] = xh.z;
@@ -896,10 +914,6 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
 //   r5 = {x_best(3), -}    r6..r9 = T_best (4x4 row-major)
 // FIRST: evaluates g(x0), derives J^-1_0 from the same weights (RFU:327); nobody retires.
 // ------------------------------------------------------------------------------------------
-struct CanonRec {
-    f32x4 r[10];
-};
-
 struct TargetSrc {
     const float* tgt;     // explicit [Q][3] or null
     RaySet rs;
@@ -1319,11 +1333,42 @@ __global__ void k_sample_depths(int n, int S, int n_near, int n_far, const float
     }
 }
 
-// list of all q with flag[q] != 0 (wave-aggregated, order irrelevant)
-__global__ void k_build_list(const uint8_t* flag, int n, int* list, int* count) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool keep = i < n && flag[i] != 0;
-    append_ids(keep, i, list, count);
+// list of all q with flag[q] != 0.  One atomic per 4096 elements (a single device-scope counter saturates
+// near 90 atomics/us): each thread takes 4 consecutive flags, waves are combined through LDS.
+__global__ __launch_bounds__(1024) void k_build_list(const uint8_t* flag, int n, int* list, int* count) {
+    __shared__ int wave_cnt[16];
+    __shared__ int block_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i0 = (blockIdx.x * 1024 + tid) * 4;
+    unsigned bits = 0;
+    if (i0 + 3 < n) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(flag + i0);   // n_steps-aligned rows keep this 4-byte aligned
+        bits = (w & 0xffu ? 1u : 0u) | (w & 0xff00u ? 2u : 0u) | (w & 0xff0000u ? 4u : 0u) | (w & 0xff000000u ? 8u : 0u);
+    } else {
+        for (int k = 0; k < 4; ++k)
+            if (i0 + k < n && flag[i0 + k]) bits |= 1u << k;
+    }
+    const int mine = __popc(bits);
+    int incl = mine;   // inclusive prefix over the wave
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+    }
+    if (lane == 63) wave_cnt[wave] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int c = wave_cnt[k];
+            wave_cnt[k] = tot;
+            tot += c;
+        }
+        block_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    int pos = block_base + wave_cnt[wave] + incl - mine;
+    for (int k = 0; k < 4; ++k)
+        if (bits & (1u << k)) list[pos++] = i0 + k;
 }
 
 __global__ void k_iota(int n, int* list, int* count) {
@@ -2099,17 +2144,18 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
     RaySet rs = make_rays(nullptr, nullptr, 1);
     hipLaunchKernelGGL(k_nearest_invlbs<SRC_POINTS>, dim3(grid_for(n, kKnnThreads)), dim3(kKnnThreads), kLdsKnn,
                        reinterpret_cast<hipStream_t>(stream), to_dev(*f), knn_of(to_dev(*f)), pts, rs, (const float*)nullptr, 1,
-                       (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, &w.ctr->n_knn);
+                       (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, (CanonRec*)nullptr, &w.ctr->n_knn);
     return check_launch();
 }
 
 // shared driver of loop C: (x0, T0) are stored densely by id in out.pts / out.T for every id in listA
 static int run_broyden3(const FrameDev& fd, Workspace& w, TargetSrc ts, CanonOut outp, long long max_pts,
-                        hipStream_t s) {
+                        bool seeded, hipStream_t s) {
     int* cnt = w.counts;   // cnt[it] = number of records consumed by iteration it
     const int g = grid_for(max_pts, kTile);
-    hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
-                       (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, w.recA);
+    if (!seeded)
+        hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
+                           (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, w.recA);
     for (int it = 0; it <= kBroydenSteps; ++it) {
         const CanonRec* rin = (it & 1) ? w.recB : w.recA;
         CanonRec* rout = (it & 1) ? w.recA : w.recB;
@@ -2144,7 +2190,7 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
     ts.rs = make_rays(nullptr, nullptr, 1);
     ts.depth = nullptr;
     ts.n_steps = 1;
-    int rc = run_broyden3(fd, w, ts, CanonOut{x, T, w.q_err}, n, s);
+    int rc = run_broyden3(fd, w, ts, CanonOut{x, T, w.q_err}, n, false, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_broyden3_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, (const float*)w.q_err, err, conv);
     return check_launch();
@@ -2170,7 +2216,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
         int* lout = (it & 1) ? w.listA : w.listB;
         hipLaunchKernelGGL(k_nearest_invlbs<SRC_RAYS>, dim3(gk), dim3(kKnnThreads), kLdsKnn, s, fd, knn_of(fd),
                            (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin, (const int*)&cntA[it], 0,
-                           w.nn_idx, w.xcur, w.Tcur, &w.ctr->n_knn);
+                           w.nn_idx, w.xcur, w.Tcur, (CanonRec*)nullptr, &w.ctr->n_knn);
         hipLaunchKernelGGL(k_sdf_march, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts, (const int*)lin,
                            (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
     }
@@ -2229,17 +2275,17 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     hipLaunchKernelGGL(k_sample_depths, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->n_near, cfg->n_far, near_far,
                        conv, start, end, cfg->lin_steps, cfg->lin_near, cfg->lin_far, z, w.q_smask);
     const int gq = (int)((Q + 255) / 256);
-    hipLaunchKernelGGL(k_build_list, dim3(gq), dim3(256), 0, s, (const uint8_t*)w.q_smask, (int)Q, w.listA, &w.counts[0]);
+    hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 4095) / 4096)), dim3(1024), 0, s, (const uint8_t*)w.q_smask, (int)Q, w.listA, &w.counts[0]);
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
     hipLaunchKernelGGL(k_nearest_invlbs<SRC_SAMPLES>, dim3(grid_for(Q, kKnnThreads)), dim3(kKnnThreads), kLdsKnn, s, fd,
                        knn_of(fd), (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA, (const int*)&w.counts[0], 0,
-                       (int*)nullptr, pts, T, &w.ctr->n_knn);
+                       (int*)nullptr, pts, T, w.recA, &w.ctr->n_knn);
     TargetSrc ts;
     ts.tgt = nullptr;
     ts.rs = rs;
     ts.depth = z;
     ts.n_steps = S;
-    int rc = run_broyden3(fd, w, ts, CanonOut{pts, T, w.q_err}, Q, s);
+    int rc = run_broyden3(fd, w, ts, CanonOut{pts, T, w.q_err}, Q, true, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_canon_finalize, dim3(gq), dim3(256), 0, s, fd, (int)Q, (const uint8_t*)w.q_smask,
                        (const float*)w.q_err, pts, T, mask);
@@ -2278,7 +2324,7 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     const FrameDev fd = to_dev(*f);
     const long long Q = (long long)n * S;
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
-    hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 255) / 256)), dim3(256), 0, s, mask, (int)Q, w.listA, &w.counts[0]);
+    hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 4095) / 4096)), dim3(1024), 0, s, mask, (int)Q, w.listA, &w.counts[0]);
     const int g = grid_for(Q, kTile);
     const int* slist = w.listA;
     const int* scount = &w.counts[0];
