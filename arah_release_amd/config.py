@@ -27,8 +27,12 @@ _DEFAULT = {
               "train_smpl": False, "geo_pose_encoder": "latent", "color_pose_encoder": "latent",
               "cano_view_dirs": True, "n_steps": 64, "near_surface_samples": 16, "far_surface_samples": 16,
               "render_last_pt": False},
+    # configs/default.yaml:53-75 overridden by configs/arah-zju/ZJUMOCAP-*_4gpus.yaml:46-60
     "training": {"train_skinning_net": True, "pose_input_noise": True, "view_input_noise": True,
-                 "nv_noise_type": "rotation"},
+                 "nv_noise_type": "rotation", "lr": 1.0e-6, "skinning_lr": 1.0e-4, "pose_net_factor": 100,
+                 "rgb_weight": 3.0e+1, "perceptual_weight": 0.0, "eikonal_weight": 5.0e+1, "mask_weight": 0.0,
+                 "off_surface_weight": 1.0e+2, "inside_weight": 10.0, "params_weight": 1.0e+2,
+                 "skinning_weight": 10.0, "rgb_loss_type": "l1", "batch_size": 1},
 }
 _IDR = {"mode": "idr", "d_in": 9, "d_out": 3, "d_hidden": 256, "n_layers": 5, "weight_norm": True, "multires": 0,
         "multires_view": 4, "skips": [3], "squeeze_out": True}
@@ -195,10 +199,12 @@ def synthetic_state_dict(cfg, asset_path=None):
     return sd
 
 
-def build_synthetic_model(name="zju377_mono", n_steps=64, near=16, far=16, device="cpu", seed=0):
+def build_synthetic_model(name="zju377_mono", n_steps=64, near=16, far=16, device="cpu", seed=0, training=None):
     """Builtin config + synthetic weights; deterministic (the hyper heads are seeded but irrelevant:
     their last layer is zero, so the emitted SDF MLP equals the fitted one for every pose)."""
     cfg = builtin_config(name, n_steps, near, far)
+    if training:
+        cfg["training"].update(training)
     gen = torch.random.get_rng_state()
     torch.manual_seed(seed)
     model = get_render_model(cfg, mode="test", n_data_points=4)

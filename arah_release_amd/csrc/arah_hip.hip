@@ -1258,8 +1258,8 @@ __global__ void k_trace_begin(const float* near_far, int n, float* t, float* far
 // after the 50 marching steps: un-normalise the start points, select the rays of the joint root
 // find (eval: non-diverged, RT:249) and seed the best-iterate arrays with the sphere-tracing result.
 __global__ void k_joint_select(FrameDev fr, int n, const float* xcur_norm, const float* Tcur, const float* t,
-                               const uint8_t* diverged, float* x0_raw, float* xbest, float* zbest, float* Tbest,
-                               float* err_best, int* list, int* count) {
+                               const uint8_t* diverged, int root_find_all, float* x0_raw, float* xbest, float* zbest,
+                               float* Tbest, float* err_best, int* list, int* count) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     if (i < n) {
@@ -1270,7 +1270,7 @@ __global__ void k_joint_select(FrameDev fr, int n, const float* xcur_norm, const
         zbest[i] = t[i];
         for (int e = 0; e < 16; ++e) Tbest[(size_t)i * 16 + e] = Tcur[(size_t)i * 16 + e];
         err_best[i] = 3.4e38f;   // rays outside the root find never count as converged (RFU:473-476)
-        keep = diverged[i] == 0;
+        keep = root_find_all || diverged[i] == 0;   // RT:249: all rays while training, the non-diverged ones in eval
     }
     append_ids(keep, i, list, count);
 }
@@ -1293,18 +1293,32 @@ __global__ void k_trace_finalize(FrameDev fr, int n, const float* near_far, cons
     end[i] = fa;
 }
 
-// depth samples of one ray (RT:313-350, eval mode): thread per ray.  lin_* are torch.linspace tables.
+// stratified jitter of an ascending run v[0..m) (perturb_z_vals, RT:298-311): sample i moves inside
+// [mid(i-1,i), mid(i,i+1)] by t in [0,1); `val(i)` evaluates the un-jittered run
+template <typename F>
+__device__ __forceinline__ float jittered(F val, int i, int m, float t) {
+    const float v = val(i);
+    const float lower = i == 0 ? v : 0.5f * (v + val(i - 1));
+    const float upper = i == m - 1 ? v : 0.5f * (val(i + 1) + v);
+    return lower + (upper - lower) * t;
+}
+
+// depth samples of one ray (RT:313-350): thread per ray.  lin_* are torch.linspace tables; rand_* are the
+// caller's torch.rand draws of training mode (NULL in eval mode).
 __global__ void k_sample_depths(int n, int S, int n_near, int n_far, const float* near_far, const uint8_t* conv,
                                 const float* start, const float* end, const float* lin_s, const float* lin_near,
-                                const float* lin_far, float* z, uint8_t* mask) {
+                                const float* lin_far, const float* rand_s, const float* rand_near,
+                                const float* rand_far, float* z, uint8_t* mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float st = start[i], en = end[i];
     float* zr = z + (size_t)i * S;
     uint8_t* mr = mask + (size_t)i * S;
+    auto uni = [&](int s) { return st + (en - st) * lin_s[s]; };
+    auto uni_j = [&](int s) { return rand_s ? jittered(uni, s, S, rand_s[(size_t)i * S + s]) : uni(s); };
     if (!conv[i] || (n_near <= 0 && n_far <= 0)) {
         for (int s = 0; s < S; ++s) {
-            zr[s] = st + (en - st) * lin_s[s];
+            zr[s] = uni_j(s);
             mr[s] = 1;
         }
         return;
@@ -1313,22 +1327,30 @@ __global__ void k_sample_depths(int n, int S, int n_near, int n_far, const float
     const float base = st - kSurfaceRange;
     const float nb = near_far[i * 2];
     const float span = fmaxf(st - kSurfaceRange - nb, 1e-5f);
+    auto surf = [&](int a) { return base + (kSurfaceRange * 2.0f) * lin_near[a]; };
+    auto farv = [&](int b) { return nb + span * lin_far[b]; };
+    auto surf_j = [&](int a) {   // the surface sample itself (index near/2) is not moved (RT:334, 305-307)
+        if (!rand_near) return surf(a);
+        return jittered(surf, a, n_near + 1, a == n_near / 2 ? 0.5f : rand_near[(size_t)i * (n_near + 1) + a]);
+    };
+    auto far_j = [&](int b) { return rand_far ? jittered(farv, b, n_far, rand_far[(size_t)i * n_far + b]) : farv(b); };
     // merge the two ascending runs (== torch.sort of their concatenation, RT:348-350)
     int a = 0, b = 0;
+    float va = surf_j(0), vb = n_far > 0 ? far_j(0) : 3.4e38f;
     for (int s = 0; s < nc; ++s) {
-        const float va = a <= n_near ? base + (kSurfaceRange * 2.0f) * lin_near[a] : 3.4e38f;
-        const float vb = b < n_far ? nb + span * lin_far[b] : 3.4e38f;
         if (vb <= va) {
             zr[s] = vb;
             ++b;
+            vb = b < n_far ? far_j(b) : 3.4e38f;
         } else {
             zr[s] = va;
             ++a;
+            va = a <= n_near ? surf_j(a) : 3.4e38f;
         }
         mr[s] = 1;
     }
     for (int s = nc; s < S; ++s) {
-        zr[s] = st + (en - st) * lin_s[s];
+        zr[s] = uni_j(s);
         mr[s] = 0;
     }
 }
@@ -2198,8 +2220,8 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
 
 // ---- loops A + B -----------------------------------------------------------------------------
 static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, int32_t rays_per_cam,
-                      const float* dirs, const float* near_far, int32_t n, float* points_hat_norm, float* T,
-                      uint8_t* conv, float* start, float* end, hipStream_t s) {
+                      const float* dirs, const float* near_far, int32_t n, int root_find_all, float* points_hat_norm,
+                      float* T, uint8_t* conv, float* start, float* end, hipStream_t s) {
     const FrameDev fd = to_dev(*f);
     const RaySet rs = make_rays(cam_loc, dirs, rays_per_cam);
     const int gb = (n + 255) / 256;
@@ -2222,7 +2244,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     }
     // joint root find on the non-diverged rays; best-iterate arrays: x -> xbest_ray, depth -> zbest_ray, T -> T (output)
     hipLaunchKernelGGL(k_joint_select, dim3(gb), dim3(256), 0, s, fd, n, (const float*)w.xcur, (const float*)w.Tcur,
-                       (const float*)w.t, (const uint8_t*)w.diverged, w.x0raw, w.xbest_ray, w.zbest_ray, T,
+                       (const float*)w.t, (const uint8_t*)w.diverged, root_find_all, w.x0raw, w.xbest_ray, w.zbest_ray, T,
                        w.err_best_ray, w.listA, &cntB[0]);
     hipLaunchKernelGGL(k_skin_jac, dim3(grid_for(n, 16)), dim3(kThreads), kLdsSkin, s, fd, (const float*)w.x0raw,
                        (const int*)w.listA, (const int*)&cntB[0], 0, w.jac_lbs, &w.ctr->n_skin_jac);
@@ -2250,30 +2272,30 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
 }
 
 int arah_trace(const ArahFrame* f, const float* cam_loc, int32_t rays_per_cam, const float* dirs,
-               const float* near_far, int32_t n, float* points_hat_norm, float* T, uint8_t* conv, float* start,
-               float* end, void* workspace, size_t wbytes, void* stream) {
+               const float* near_far, int32_t n, int32_t root_find_all, float* points_hat_norm, float* T,
+               uint8_t* conv, float* start, float* end, void* workspace, size_t wbytes, void* stream) {
     if (!f || n < 0 || !workspace) return ARAH_E_BADARG;
     if (n == 0) return ARAH_OK;
     if (!cam_loc || !dirs || !near_far || !points_hat_norm || !T || !conv || !start || !end) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
-    return trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, points_hat_norm, T, conv, start, end,
-                      reinterpret_cast<hipStream_t>(stream));
+    return trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, root_find_all, points_hat_norm, T, conv, start,
+                      end, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- sampler + loop C -------------------------------------------------------------------------
 static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w, const float* cam_loc,
                        int32_t rays_per_cam, const float* dirs, const float* near_far, const uint8_t* conv,
-                       const float* start, const float* end, int32_t n, float* z, float* pts, float* T,
-                       uint8_t* mask, hipStream_t s) {
+                       const float* start, const float* end, int32_t n, const float* rand_s, const float* rand_near,
+                       const float* rand_far, float* z, float* pts, float* T, uint8_t* mask, hipStream_t s) {
     const int S = cfg->n_steps;
     const FrameDev fd = to_dev(*f);
     const RaySet rs = make_rays(cam_loc, dirs, rays_per_cam);
     const long long Q = (long long)n * S;
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipLaunchKernelGGL(k_sample_depths, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->n_near, cfg->n_far, near_far,
-                       conv, start, end, cfg->lin_steps, cfg->lin_near, cfg->lin_far, z, w.q_smask);
+                       conv, start, end, cfg->lin_steps, cfg->lin_near, cfg->lin_far, rand_s, rand_near, rand_far, z, w.q_smask);
     const int gq = (int)((Q + 255) / 256);
     hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 4095) / 4096)), dim3(1024), 0, s, (const uint8_t*)w.q_smask, (int)Q, w.listA, &w.counts[0]);
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
@@ -2302,8 +2324,9 @@ static int check_sampling(const ArahSampling* cfg) {
 
 int arah_sample_canonicalize(const ArahFrame* f, const ArahSampling* cfg, const float* cam_loc, int32_t rays_per_cam,
                              const float* dirs, const float* near_far, const uint8_t* conv, const float* start,
-                             const float* end, int32_t n, float* z, float* pts, float* T, uint8_t* mask,
-                             void* workspace, size_t wbytes, void* stream) {
+                             const float* end, int32_t n, const float* rand_steps, const float* rand_near,
+                             const float* rand_far, float* z, float* pts, float* T, uint8_t* mask, void* workspace,
+                             size_t wbytes, void* stream) {
     if (!f || !cfg || n < 0 || !workspace) return ARAH_E_BADARG;
     int rc = check_sampling(cfg);
     if (rc) return rc;
@@ -2312,8 +2335,10 @@ int arah_sample_canonicalize(const ArahFrame* f, const ArahSampling* cfg, const 
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
-    return sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, conv, start, end, n, z, pts, T, mask,
-                       reinterpret_cast<hipStream_t>(stream));
+    if ((rand_steps || rand_near || rand_far) && (!rand_steps || !rand_near || (cfg->n_far > 0 && !rand_far)))
+        return ARAH_E_BADARG;   // jitter is all or nothing
+    return sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, conv, start, end, n, rand_steps, rand_near,
+                       rand_far, z, pts, T, mask, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- loop D -----------------------------------------------------------------------------------
@@ -2381,10 +2406,10 @@ int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_lo
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* o_start = dists ? dists : w.o_start;
     uint8_t* o_conv = surface_conv ? surface_conv : w.o_conv;
-    rc = trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, w.o_xnorm, w.o_Tray, o_conv, o_start, w.o_end, s);
+    rc = trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, 0, w.o_xnorm, w.o_Tray, o_conv, o_start, w.o_end, s);
     if (rc) return rc;
-    rc = sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, o_conv, o_start, w.o_end, n, w.o_z, w.o_pts,
-                     w.o_T, w.o_mask, s);
+    rc = sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, o_conv, o_start, w.o_end, n, nullptr, nullptr,
+                     nullptr, w.o_z, w.o_pts, w.o_T, w.o_mask, s);
     if (rc) return rc;
     rc = shade_impl(f, cfg, w, dirs, w.o_z, w.o_pts, w.o_T, w.o_mask, n, rgb, acc ? acc : w.o_acc, vol_mask, s);
     if (rc) return rc;

@@ -303,7 +303,7 @@ def broyden3_lbs(frame, ws, tgt, x0, T0):
     return x, T, err, conv.bool()
 
 
-def trace(frame, ws, cam_loc, dirs, near_far):
+def trace(frame, ws, cam_loc, dirs, near_far, root_find_all=False):
     """cam_loc (B,3), dirs (B*N,3) flat, near_far (B*N,2) -> x_norm, T, conv, start, end."""
     lib = load_library()
     cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
@@ -316,13 +316,17 @@ def trace(frame, ws, cam_loc, dirs, near_far):
     start = torch.empty(n, device=dev)
     end = torch.empty(n, device=dev)
     _check(lib.arah_trace(C.byref(frame.handle), _ptr(cam), C.c_int32(n // cam.shape[0]), _ptr(d), _ptr(nf),
-                          C.c_int32(n), _ptr(xn), _ptr(T), _ptr(conv), _ptr(start), _ptr(end), _ptr(buf),
-                          C.c_size_t(buf.numel()), _stream()), "arah_trace")
+                          C.c_int32(n), C.c_int32(int(bool(root_find_all))), _ptr(xn), _ptr(T), _ptr(conv), _ptr(start),
+                          _ptr(end), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_trace")
     return xn, T, conv, start, end
 
 
-def sample_canonicalize(frame, ws, sampling, cam_loc, dirs, near_far, conv, start, end):
+def sample_canonicalize(frame, ws, sampling, cam_loc, dirs, near_far, conv, start, end, rand=None):
+    """rand: None (eval) or (rand_steps (N,S), rand_near (N,near+1), rand_far (N,far)) uniform draws."""
     lib = load_library()
+    r_s = r_n = r_f = None
+    if rand is not None:
+        r_s, r_n, r_f = [_f32(t) for t in rand]
     cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
     n, S = d.shape[0], sampling.n_steps
     buf = ws.ensure(n, S)
@@ -333,8 +337,9 @@ def sample_canonicalize(frame, ws, sampling, cam_loc, dirs, near_far, conv, star
     mask = torch.empty(n, S, dtype=torch.uint8, device=dev)
     _check(lib.arah_sample_canonicalize(C.byref(frame.handle), C.byref(sampling.handle), _ptr(cam),
                                         C.c_int32(n // cam.shape[0]), _ptr(d), _ptr(nf), _ptr(conv.contiguous()),
-                                        _ptr(_f32(start)), _ptr(_f32(end)), C.c_int32(n), _ptr(z), _ptr(pts), _ptr(T),
-                                        _ptr(mask), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
+                                        _ptr(_f32(start)), _ptr(_f32(end)), C.c_int32(n), _ptr(r_s), _ptr(r_n), _ptr(r_f),
+                                        _ptr(z), _ptr(pts), _ptr(T), _ptr(mask), _ptr(buf), C.c_size_t(buf.numel()),
+                                        _stream()),
            "arah_sample_canonicalize")
     return z, pts, T, mask
 

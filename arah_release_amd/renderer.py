@@ -17,8 +17,15 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from . import hip
+from . import hip, training
 from .nets import folded_weight
+
+
+def draw_uniform(shape, device, tag):
+    """torch.rand draws of the training path, in the order the reference makes them ('steps', 'near', 'far' in
+    ray_tracing.py:304, then 'eikonal' in implicit_differentiable_renderer.py:127).  Tests replace this hook
+    to replay the reference's draws."""
+    return torch.rand(shape, device=device)
 
 
 def _emitted_sdf_layers(sdf_network):
@@ -114,8 +121,6 @@ class BodyRayTracing(nn.Module):
     def forward(self, sdf_network, skinning_model, cam_loc, ray_directions, body_bounds_intersections, loc,
                 sc_factor, smpl_verts, smpl_verts_cano, skinning_weights, vol_feat, bone_transforms, trans,
                 coord_min, coord_max, center, eval_mode=False, frame=None):
-        if not eval_mode:
-            raise NotImplementedError("training-time stratified jitter is not wired into the HIP sampler yet")
         assert self.near_surface_vol_samples > 0 or self.far_surface_vol_samples > 0
         B, N, _ = ray_directions.shape
         if N == 0:
@@ -130,8 +135,14 @@ class BodyRayTracing(nn.Module):
         cam = cam_loc.reshape(B, 3)
         d = ray_directions.reshape(B * N, 3)
         nf = body_bounds_intersections.reshape(B * N, 2)
-        xn, T, conv, start, end = hip.trace(frame, ws, cam, d, nf)
-        z, pts, Ts, mask = hip.sample_canonicalize(frame, ws, self.sampling(dev), cam, d, nf, conv, start, end)
+        # training: joint root find on every ray (RT:249) and stratified jitter of the depth samples (RT:319-346)
+        xn, T, conv, start, end = hip.trace(frame, ws, cam, d, nf, root_find_all=not eval_mode)
+        rand = None
+        if not eval_mode:
+            S_, nn_, nf_ = self.n_steps, self.near_surface_vol_samples, self.far_surface_vol_samples
+            rand = (draw_uniform((B * N, S_), dev, "steps"), draw_uniform((B * N, nn_ + 1), dev, "near"),
+                    draw_uniform((B * N, max(nf_, 1)), dev, "far"))
+        z, pts, Ts, mask = hip.sample_canonicalize(frame, ws, self.sampling(dev), cam, d, nf, conv, start, end, rand)
         S = self.n_steps
         return (xn.reshape(B, N, 3), conv.bool().reshape(B, N), start.reshape(B, N), pts.reshape(B, N, S, 3),
                 z.reshape(B, N, S), Ts.reshape(B, N, S, 4, 4), mask.bool().reshape(B, N, S))
@@ -153,10 +164,62 @@ class IDHRNetwork(nn.Module):
         self.low_vram = low_vram
         self.last_counters = None
 
+    def forward_train(self, input):
+        """Training forward (IDR:42-248): HIP kernels for the ray tracer (no_grad, like the reference), autograd
+        for loop D and the regulariser queries (training.py)."""
+        ray_dirs, cam_loc = input["ray_dirs"], input["cam_loc"]
+        sdf_network, pose_cond = input["sdf_network"], input["pose_cond"]
+        cmin, cmax, center = input["coord_min"], input["coord_max"], input["center"]
+        B, N, _ = ray_dirs.shape
+        dev = ray_dirs.device
+        pred_weights = None
+        if "points_skinning" in input:
+            pred_weights = training.query_weights(input["points_skinning"], cmin, cmax, center, self.skinning_model)
+        with torch.no_grad():
+            xn, _, _, s_pts, s_z, s_T, s_mask = self.ray_tracer(
+                sdf_network, self.skinning_model, cam_loc=cam_loc, ray_directions=ray_dirs,
+                body_bounds_intersections=input["body_bounds_intersections"], loc=input["loc"],
+                sc_factor=input["sc_factor"], smpl_verts=input["smpl_verts"], smpl_verts_cano=input["minimal_shape"],
+                skinning_weights=input["skinning_weights"], vol_feat=input["vol_feat"],
+                bone_transforms=input["bone_transforms"], trans=input["trans"], coord_min=cmin, coord_max=cmax,
+                center=center, eval_mode=False)
+        inside_sdf = sdf_network(input["points_inside"]).squeeze(0) if "points_inside" in input else None
+        n_reg = 1024
+        eik = ((draw_uniform((B, n_reg, 3), dev, "eikonal") - 0.5) * 2).reshape(-1, 3)
+        probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3)], dim=0).requires_grad_(True)
+        sdf_probe = sdf_network(probe).squeeze(0)
+        uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
+        grad_eik = torch.autograd.grad(sdf_probe, probe, torch.ones_like(sdf_probe), create_graph=True,
+                                       retain_graph=True)[0][:B * n_reg]
+        vol_mask = s_mask.any(-1)
+        dirs_in, ray_augm = ray_dirs, False
+        if "view_noise" in pose_cond:
+            vn = pose_cond["view_noise"]
+            if vn is None:
+                dirs_in = torch.zeros_like(ray_dirs)
+            elif vn.shape[-2:] == (3, 3):
+                dirs_in = torch.matmul(vn, ray_dirs.transpose(1, 2)).transpose(1, 2)
+                ray_augm = True
+            else:
+                dirs_in = ray_dirs + vn
+        rgb_hit, w_hit = training.shade_composite_train(
+            self, sdf_network, s_pts[vol_mask], s_z[vol_mask], s_T[vol_mask], s_mask[vol_mask], dirs_in[vol_mask],
+            ray_dirs[vol_mask], pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
+            self.ray_tracer.n_steps, ray_augm=ray_augm)
+        rgb = torch.zeros_like(xn).masked_scatter(vol_mask.unsqueeze(-1), rgb_hit)
+        acc = torch.zeros(B, N, device=dev).masked_scatter(vol_mask, w_hit)
+        out = {"rgb_values": rgb, "sdf_output": acc, "network_body_mask": vol_mask, "body_mask": input["body_mask"],
+               "off_surface_mask": vol_mask, "off_surface_sdf": uniform_sdf, "grad_theta": grad_eik,
+               "surface_normals": None}
+        if pred_weights is not None:
+            out["pred_weights"] = pred_weights
+        if inside_sdf is not None:
+            out["inside_sdf"] = inside_sdf
+        return out
+
     def forward(self, input):
         if self.training:
-            raise NotImplementedError("the training path (autograd through loop D + regulariser queries) "
-                                      "is scheduled after the inference path; call .eval() first")
+            return self.forward_train(input)
         ray_dirs = input["ray_dirs"]
         cam_loc = input["cam_loc"]
         pose = input["pose"]
@@ -226,7 +289,21 @@ class MetaAvatarRender(nn.Module):
         if "geo_latent_code_idx" in inputs:
             decoder_input["latent"] = self.latent(inputs["geo_latent_code_idx"])
         if (self.pose_input_noise or self.view_input_noise) and not eval:
-            raise NotImplementedError("input-noise augmentation belongs to the training path")
+            if np.random.uniform() <= 0.5:   # models/__init__.py:157-174
+                if self.pose_input_noise:
+                    decoder_input["rots_noise"] = torch.normal(mean=0, std=0.1, size=rots.shape, dtype=rots.dtype, device=dev)
+                    inputs["pose_cond"]["rot_noise"] = torch.normal(mean=0, std=0.1, size=(B, 9), dtype=rots.dtype, device=dev)
+                    inputs["pose_cond"]["trans_noise"] = torch.normal(mean=0, std=0.1, size=(B, 3), dtype=rots.dtype, device=dev)
+                if self.view_input_noise:
+                    if self.nv_noise_type == "gaussian":
+                        inputs["pose_cond"]["view_noise"] = torch.normal(mean=0, std=0.1, size=inputs["ray_dirs"].shape,
+                                                                          dtype=rots.dtype, device=dev)
+                    elif self.nv_noise_type == "rotation":
+                        inputs["pose_cond"]["view_noise"] = torch.tensor(training.augm_rots(45, 45, 45), dtype=torch.float32,
+                                                                          device=dev).unsqueeze(0)
+                    else:
+                        raise ValueError("wrong nv_noise_type, expected either gaussian or rotation, got %s"
+                                         % self.nv_noise_type)
         out = self.sdf_decoder(decoder_input)
         inputs.update({"loc": torch.zeros(B, 1, 3, device=dev), "sc_factor": torch.ones(B, 1, 1, device=dev),
                        "vol_feat": torch.empty(B, 0, device=dev), "sdf_network": out["decoder"]})

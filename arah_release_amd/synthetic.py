@@ -269,4 +269,20 @@ class SyntheticScene:
         if eval_mode:
             inputs["image_mask"] = torch.from_numpy(image_mask[None]).to(device)
             inputs["ray_dirs_cam"] = f32(d[None])
+        else:
+            # training-only keys of compose_inputs (lightning_model.py:612-630); the dataset draws them with
+            # igl / trimesh / libmesh (zju_mocap.py:461-543), here: seeded numpy on the capsule body
+            rng = np.random.RandomState(77 + frame_idx)
+            n_reg = 1024
+            sel = rng.randint(0, N_VERTS, n_reg)
+            surf = self.verts_cano[sel].astype(np.float64)
+            eps = 1e-4
+            grad = np.stack([(capsule_union_sdf(surf + eps * e) - capsule_union_sdf(surf - eps * e)) / (2 * eps)
+                             for e in np.eye(3)], axis=-1)
+            inside = surf - 0.01 * grad                                    # 1 cm under the surface
+            inputs["rgb_values"] = f32((0.5 + 0.5 * np.sin(np.stack([7 * d[:, 0], 9 * d[:, 1], 5 * d[:, 0] + 3 * d[:, 1]], -1)))[None])
+            inputs["points_skinning"] = f32(surf[None])
+            inputs["sampled_weights"] = f32(self.weights[sel][None])
+            inputs["points_inside"] = f32(normalize_points_np(inside, self.coord_min, self.coord_max, self.center)[None])
+            inputs["points_uniform"] = f32((rng.rand(1, n_reg, 3) * 2 - 1))
         return inputs

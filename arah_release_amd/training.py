@@ -1,0 +1,265 @@
+"""Differentiable (PyTorch autograd, on the GPU) half of the training step.
+
+In the reference, loops A-C of the renderer run under ``torch.no_grad()`` even while training
+(implicit_differentiable_renderer.py:87, root_finding_utils.py:302,348,460): they are served by the
+HIP kernels unchanged.  What carries gradients is
+
+  * loop D on the 2048 sampled rays: SDF value / feature, its input gradient (double backward through the
+    SIREN), the colour MLP, the VolSDF density and the compositing (IDR:261-396, training branches),
+    including the implicit-gradient re-attachment of the canonical points to the skinning network
+    (IDR:315-334);
+  * the small regulariser queries (skinning weights at surface points, SDF inside the body, eikonal and
+    uniform off-surface points, IDR:73-79,117-140);
+  * the loss (renderer/loss.py:123-191).
+
+These are kept on autograd, as SURVEY 7 step 7 plans for a first cut; a hand-written backward of
+loop D is the follow-up.  Everything here is plain torch on whatever device the tensors live on.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------
+# canonical-space helpers (root_finding_utils.py:13-113)
+# ------------------------------------------------------------------------------------------------
+def normalize_canonical_points(pts, coord_min, coord_max, center):
+    span = coord_max - coord_min
+    return (((pts - center) - coord_min + span * 0.05) / span / 1.1 - 0.5) * 2.0
+
+
+def unnormalize_canonical_points(pts, coord_min, coord_max, center):
+    span = coord_max - coord_min
+    return (pts / 2.0 + 0.5) * 1.1 * span + coord_min - span * 0.05 + center
+
+
+def hierarchical_softmax(x):
+    """(..., 25) logits -> (..., 24) weights along the SMPL kinematic tree (utils/utils.py:138-181)."""
+    lead = x.shape[:-1]
+    x = x.reshape(-1, 25)
+    gate = torch.sigmoid(x)
+    keep = 1.0 - gate
+    w = [None] * 24
+    hips = torch.softmax(x[:, 1:4], dim=-1)
+    w[0] = keep[:, 0]
+    for k in range(3):
+        w[1 + k] = gate[:, 0] * hips[:, k]
+
+    def hand_down(parent, child, g):
+        w[child] = w[parent] * gate[:, g]
+        w[parent] = w[parent] * keep[:, g]
+
+    for parent, child in ((1, 4), (2, 5), (3, 6), (4, 7), (5, 8), (6, 9), (7, 10), (8, 11)):
+        hand_down(parent, child, child)
+    chest = torch.softmax(x[:, 12:15], dim=-1)
+    for k in range(3):
+        w[12 + k] = w[9] * gate[:, 24] * chest[:, k]
+    w[9] = w[9] * keep[:, 24]
+    for parent, child in ((12, 15), (13, 16), (14, 17), (16, 18), (17, 19), (18, 20), (19, 21), (20, 22), (21, 23)):
+        hand_down(parent, child, child)
+    return torch.stack(w, dim=-1).reshape(*lead, 24)
+
+
+def query_weights(x_hat, coord_min, coord_max, center, skinning_model):
+    """(B,N,3) canonical points -> (B,N,24) skinning weights (root_finding_utils.py:54-113, 25-logit branch)."""
+    logits = skinning_model.decode_w(normalize_canonical_points(x_hat, coord_min, coord_max, center),
+                                     c=torch.empty(x_hat.shape[0], 0, device=x_hat.device))
+    if logits.shape[-1] != 25:
+        raise ValueError("Wrong output size of skinning network. Expected 25, got %d." % logits.shape[-1])
+    return hierarchical_softmax(logits * 20.0)
+
+
+def forward_skinning(x_hat, coord_min, coord_max, center, skinning_model, bone_transforms):
+    """x_bar = (sum_j w_j A_j) [x_hat; 1] (root_finding_utils.py:147-167, 13-34)."""
+    w = query_weights(x_hat, coord_min, coord_max, center, skinning_model)
+    T = torch.einsum("bpn,bnij->bpij", w, bone_transforms)
+    x_bar = torch.einsum("bpij,bpj->bpi", T[..., :3, :3], x_hat) + T[..., :3, 3]
+    return x_bar, T
+
+
+def input_jacobian(y, x):
+    """d y / d x for y (1,P,3) computed from x (1,P,3), row by row, detached (diff_operators.py:53-66)."""
+    rows = [torch.autograd.grad(y[..., i].sum(), x, retain_graph=True)[0] for i in range(y.shape[-1])]
+    return torch.stack(rows, dim=-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# loop D with gradients (IDR:261-396, self.training branches)
+# ------------------------------------------------------------------------------------------------
+def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, converge_mask, view_dirs,
+                          view_dirs_orig, pose_cond, bone_transforms, coord_min, coord_max, center, n_steps,
+                          ray_augm=False, point_batch_size=100000):
+    n_rays, S, _ = points.shape
+    dev = points.device
+    lengths = converge_mask.sum(-1)
+    slot = torch.arange(S, device=dev)[None, :] < lengths[:, None]          # left-packed valid slots
+    pts = points[converge_mask]
+    Tf = transforms_fwd[converge_mask]
+    vd = view_dirs[:, None, :].expand(n_rays, S, 3)[converge_mask]
+    vd0 = view_dirs_orig[:, None, :].expand(n_rays, S, 3)[converge_mask]
+    if idhr.cano_view_dirs:
+        Rb = torch.linalg.inv(Tf).detach()[:, :3, :3]
+        vin = torch.einsum("pij,pj->pi", Rb, -vd)
+        vin0 = torch.einsum("pij,pj->pi", Rb, -vd0)
+    else:
+        vin, vin0 = -vd, -vd0
+    sdf_all, rgb_all = [], []
+    for c in range(0, pts.shape[0], point_batch_size):
+        pi = pts[c:c + point_batch_size].unsqueeze(0).requires_grad_(True)
+        vi, vi0, Ti = vin[c:c + point_batch_size], vin0[c:c + point_batch_size], Tf[c:c + point_batch_size]
+        with torch.enable_grad():
+            if idhr.train_skinning_net:
+                # x_hat is a root of LBS(x_hat) = x_bar found without a graph; re-attach it with the implicit
+                # function theorem: d x_hat = -J^-1 d LBS  (IDR:315-334)
+                x_hat = unnormalize_canonical_points(pi, coord_min, coord_max, center)
+                x_lbs, _ = forward_skinning(x_hat, coord_min, coord_max, center, idhr.skinning_model, bone_transforms)
+                Jinv = torch.linalg.inv(input_jacobian(x_lbs, pi)).detach()
+                pi = pi - torch.matmul(Jinv, (x_lbs - x_lbs.detach()).unsqueeze(-1)).squeeze(-1)
+            feat = sdf_network[:-1](pi).squeeze(0)
+            sdf = sdf_network[-1](feat)
+            normal = torch.autograd.grad(sdf, pi, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]
+            if not idhr.cano_view_dirs:
+                normal = torch.einsum("pij,bpj->bpi", Ti[:, :3, :3], normal)
+            if ray_augm:
+                with torch.no_grad():   # keep the un-rotated view where the augmented one looks at the back face
+                    nn_ = normal / torch.linalg.norm(normal, dim=-1, keepdim=True)
+                    back = torch.arccos((nn_.squeeze(0) * vi).sum(-1)) >= np.pi / 2.0
+                vi = torch.where(back[:, None], vi0, vi)
+        sdf_all.append((sdf / 2.0 * 1.1 * (coord_max.squeeze() - coord_min.squeeze())).squeeze(0))
+        rgb_all.append(idhr.rendering_network(pi.squeeze(0), normal.squeeze(0), vi, feat, pose_cond))
+    sdf_v = torch.cat(sdf_all, dim=0)
+    rgb_v = torch.cat(rgb_all, dim=0)
+    beta = idhr.deviation_network(sdf_v).clip(1e-6, 1e6)
+    inv_beta = torch.reciprocal(beta)
+    dens_v = F.relu(inv_beta * (0.5 + 0.5 * torch.sign(-sdf_v) * (1 - torch.exp(-sdf_v.abs() * inv_beta))))
+    rgb = torch.zeros(n_rays, S, 3, device=dev).masked_scatter(slot.unsqueeze(-1), rgb_v)
+    dens = torch.zeros(n_rays, S, device=dev).masked_scatter(slot, dens_v.squeeze(-1))
+    zp = torch.full((n_rays, S), 1e10, device=dev).masked_scatter(slot, z_vals[converge_mask])
+    delta = zp[:, 1:] - zp[:, :-1]
+    if idhr.render_last_pt:
+        delta = torch.cat([delta, torch.full((n_rays, 1), 1e10, device=dev)], dim=-1)
+    else:
+        delta = torch.cat([delta, torch.full((n_rays, 1), 1.0 / n_steps, device=dev)], dim=-1)
+        last = F.one_hot(lengths - 1, S).bool()
+        delta = torch.where(last, torch.full_like(delta, 1.0 / n_steps), delta)
+    alpha = 1.0 - torch.exp(-dens * delta)
+    trans = torch.cumprod(torch.cat([torch.ones(n_rays, 1, device=dev), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
+    w = alpha * trans * slot
+    return (rgb * w.unsqueeze(-1)).sum(dim=1), w.sum(dim=-1, keepdim=True).clip(0, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# input augmentation (models/__init__.py:157-174, utils/utils.py:183-230)
+# ------------------------------------------------------------------------------------------------
+def augm_rots(roll_range=90, pitch_range=90, yaw_range=90):
+    """Random rotation about x, y, z (degrees; normal, uniform, normal draws clipped to +-2*range)."""
+    def clipped(v, r):
+        return min(2 * r, max(-2 * r, v))
+
+    ax = np.deg2rad(clipped(np.random.randn() * roll_range, roll_range))
+    ay = np.deg2rad(clipped(np.random.rand() * pitch_range, pitch_range))
+    az = np.deg2rad(clipped(np.random.randn() * yaw_range, yaw_range))
+    rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+    ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+    rz = np.array([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]])
+    return rx @ (ry @ rz)
+
+
+# ------------------------------------------------------------------------------------------------
+# loss (renderer/loss.py:6-191) and optimiser groups (lightning_model.py:403-461)
+# ------------------------------------------------------------------------------------------------
+class IDHRLoss(nn.Module):
+    """rgb + perceptual + eikonal + mask + off-surface + inside + SDF-parameter + skinning terms, weighted."""
+
+    TERMS = ("rgb", "perceptual", "eikonal", "mask", "off_surface", "inside", "sdf_params", "skinning")
+
+    def __init__(self, rgb_weight, perceptual_weight, eikonal_weight, mask_weight, off_surface_weight, inside_weight,
+                 params_weight, skinning_weight, rgb_loss_type="l1", perceptual_loss_fn=None):
+        super().__init__()
+        self.weights = dict(rgb=rgb_weight, perceptual=perceptual_weight, eikonal=eikonal_weight, mask=mask_weight,
+                            off_surface=off_surface_weight, inside=inside_weight, sdf_params=params_weight,
+                            skinning=skinning_weight)
+        kinds = {"l1": nn.L1Loss(reduction="sum"), "mse": nn.MSELoss(reduction="sum"),
+                 "smoothed_l1": nn.SmoothL1Loss(reduction="sum", beta=1e-1)}
+        if rgb_loss_type not in kinds:
+            raise ValueError("Unsupported RGB loss type: %s. Only l1, smoothed_l1 and mse are supported" % rgb_loss_type)
+        self.pixel_loss = kinds[rgb_loss_type]
+        self.p_loss = perceptual_loss_fn
+
+    def forward(self, out, gt):
+        dev = out["rgb_values"].device
+        zero = lambda: torch.zeros(1, device=dev)
+        hit = out["network_body_mask"][:, :2048]
+        body = out["body_mask"][:, :2048]
+        off = out["off_surface_mask"][:, :2048]
+        n_px = float(body.numel())
+        terms = {k: zero() for k in self.TERMS}
+        if self.weights["rgb"] > 0:
+            m = hit
+            if m.sum() == 0:
+                terms["rgb"] = torch.tensor(0.0, device=dev)
+            else:
+                if body.max() > 1:          # patch sampling marks boundary pixels with 100
+                    m = m & (body != 100)
+                terms["rgb"] = self.pixel_loss(out["rgb_values"][:, :2048][m], gt["rgb"][:, :2048][m]) / float(m.numel())
+        if self.weights["perceptual"] > 0:
+            if self.p_loss is None:
+                raise ValueError("perceptual_weight > 0 needs a perceptual_loss_fn (e.g. LPIPS)")
+            pred = out["rgb_values"][:, 2048:].reshape(-1, 48, 48, 3).permute(0, 3, 1, 2)
+            ref = gt["rgb"][:, 2048:].reshape(-1, 48, 48, 3).permute(0, 3, 1, 2)
+            terms["perceptual"] = self.p_loss(pred, ref, normalize=True).mean() if hit.sum() > 0 else torch.tensor(0.0, device=dev)
+        if self.weights["mask"] > 0:
+            if off.sum() == 0:
+                terms["mask"] = torch.tensor(0.0, device=dev)
+            else:
+                terms["mask"] = torch.norm(out["sdf_output"][off] - body[off].float(), dim=-1).sum() / n_px
+        if self.weights["eikonal"] > 0:
+            g = out["grad_theta"]
+            terms["eikonal"] = (torch.abs(g.norm(2, dim=-1) - 1).sum() / n_px) if g.shape[0] else torch.tensor(0.0, device=dev)
+        if self.weights["off_surface"] > 0:
+            terms["off_surface"] = torch.exp(-1e2 * out["off_surface_sdf"]).sum() / n_px
+        if self.weights["inside"] > 0:
+            terms["inside"] = torch.sigmoid(out["inside_sdf"] * 5e3).sum() / n_px
+        if self.weights["sdf_params"] > 0:
+            p = torch.cat(out["sdf_params"], dim=1)
+            terms["sdf_params"] = p.norm(dim=-1).mean() / p.size(-1)
+        if self.weights["skinning"] > 0:
+            terms["skinning"] = torch.abs(out["pred_weights"] - gt["sampled_weights"]).sum(-1).mean()
+        total = sum(self.weights[k] * terms[k] for k in self.TERMS)
+        res = {"loss": total}
+        res.update({k + "_loss": v for k, v in terms.items()})
+        return res
+
+
+def build_loss(cfg, perceptual_loss_fn=None):
+    t = cfg["training"]
+    return IDHRLoss(rgb_weight=t["rgb_weight"], perceptual_weight=t["perceptual_weight"],
+                    eikonal_weight=t["eikonal_weight"], mask_weight=t["mask_weight"],
+                    off_surface_weight=t["off_surface_weight"], inside_weight=t["inside_weight"],
+                    params_weight=t["params_weight"], skinning_weight=t["skinning_weight"],
+                    rgb_loss_type=t.get("rgb_loss_type", "l1"), perceptual_loss_fn=perceptual_loss_fn)
+
+
+def configure_optimizers(model, cfg):
+    """Adam with the reference's parameter groups and learning rates (lightning_model.py:403-461)."""
+    t = cfg["training"]
+    lr = t["lr"]
+    groups = [{"params": model.sdf_decoder.net.layers.parameters(), "lr": lr},
+              {"params": model.sdf_decoder.pose_encoder.parameters(), "lr": lr * t["pose_net_factor"]},
+              {"params": model.color_decoder.parameters(), "lr": 1e-4},
+              {"params": model.deviation_decoder.parameters(), "lr": 1e-4}]
+    if t["train_skinning_net"]:
+        groups.append({"params": model.skinning_model.parameters(), "lr": t["skinning_lr"]})
+    if hasattr(model, "latent"):
+        groups.append({"params": model.latent.parameters(), "lr": 1e-4, "weight_decay": 0.05})
+    return torch.optim.Adam(params=groups)
+
+
+def training_step(model, criteria, inputs):
+    """compute_loss of the reference's harness (lightning_model.py:636-653): forward + loss dict."""
+    out = model(inputs)
+    gt = {"rgb": inputs["rgb_values"]}
+    if "sampled_weights" in inputs:
+        gt["sampled_weights"] = inputs["sampled_weights"]
+    return criteria(out, gt)

@@ -182,14 +182,18 @@ int arah_broyden3_lbs(const ArahFrame* h_frame, const float* tgt, const float* x
 
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* rays: cam_loc [n_cams,3], ray r belongs to camera r / rays_per_cam; dirs [N,3]; near_far [N,2].
+ * root_find_all: 0 = joint root find on the non-diverged rays (eval), 1 = on every ray (training, RT:249).
  * -> points_hat_norm [N,3], T [N,16], conv [N], start [N], end [N]   (RT:283-296) */
 int arah_trace(const ArahFrame* h_frame, const float* cam_loc, int32_t rays_per_cam, const float* dirs,
-               const float* near_far, int32_t n_rays, float* points_hat_norm, float* T, uint8_t* conv,
-               float* start, float* end, void* workspace, size_t workspace_bytes, void* stream);
-/* -> z [N,S], pts [N,S,3] normalised canonical, T [N,S,16], mask [N,S]   (RT:380, 549-555) */
+               const float* near_far, int32_t n_rays, int32_t root_find_all, float* points_hat_norm, float* T,
+               uint8_t* conv, float* start, float* end, void* workspace, size_t workspace_bytes, void* stream);
+/* rand_steps [N,S], rand_near [N,near+1], rand_far [N,far]: uniform [0,1) draws for the stratified jitter of
+ * training mode (perturb_z_vals, RT:298-311, in the order the reference draws them); all NULL = eval mode.
+ * -> z [N,S], pts [N,S,3] normalised canonical, T [N,S,16], mask [N,S]   (RT:380, 549-555) */
 int arah_sample_canonicalize(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float* cam_loc,
                              int32_t rays_per_cam, const float* dirs, const float* near_far,
                              const uint8_t* conv, const float* start, const float* end, int32_t n_rays,
+                             const float* rand_steps, const float* rand_near, const float* rand_far,
                              float* z, float* pts, float* T, uint8_t* mask, void* workspace,
                              size_t workspace_bytes, void* stream);
 /* -> rgb [N,3], acc [N], vol_mask [N]   (IDR:148, 225-230, 261-396) */

@@ -6,6 +6,7 @@ Runs only in the build container (needs /root/reference, see ref_shim.py).  The 
 reference's functions are called directly and their inputs/outputs are stored.
 
     python tests/golden/make_golden.py            # writes F1..F7 (about 9 MB)
+    python tests/golden/make_golden.py f8         # writes F8 (training step, about 1 MB)
 
 Fixtures:
   f1_broyden.npz       broyden() KATs, D=3 (g = LBS(x) - target) and D=4 (joint residual)
@@ -16,6 +17,8 @@ Fixtures:
   f5_tracer_<cfg>.npz  BodyRayTracing.forward 7-tuple (and its inputs), (64,16,16) and (32,8,8)
   f6_shade_<cfg>.npz   get_rbg_value_vol_sdf on the f5 outputs
   f7_forward_<cfg>.npz whole MetaAvatarRender.forward(eval=True) dict for small frames
+  f8_train_step_*.npz  training forward + IDHRLoss + backward: outputs, loss terms, per-parameter gradient norms,
+                       and the reference's recorded torch.rand draws
 """
 import os
 import sys
@@ -93,7 +96,63 @@ def frame_tensors(model, inputs):
                 vol_feat=torch.empty(B, 0))
 
 
+def make_f8():
+    """F8: one training step (forward, loss, backward) of the reference on 2048 synthetic rays, ZJUMOCAP-313 shapes
+    (idr colour net, cano_view_dirs False, train_skinning_net True) with a fixed view-rotation augmentation.
+    The reference's torch.rand draws are recorded so that the build can replay them."""
+    from im2mesh.metaavatar_render.renderer.loss import IDHRLoss
+    torch.set_num_threads(os.cpu_count())
+    scene = synthetic.SyntheticScene(seed=0)
+    cfg = ref_config.load_config(REF_CFG["zju313"], "configs/default.yaml")
+    cfg["training"].update(pose_input_noise=False, view_input_noise=False)   # the np.random gate is not replayable
+    my_cfg = my_config.builtin_config("zju313")
+    sd = my_config.synthetic_state_dict(my_cfg)
+    fake = "/tmp/arah_fake_ckpt_f8.ckpt"
+    torch.save({"state_dict": {"model.latent.weight": sd["latent.weight"]}}, fake)
+    torch.manual_seed(0)
+    model = ref_render_config.get_model(cfg, mode="test", checkpoint_path=fake)
+    model.load_state_dict(sd, strict=False)
+    model.train()
+    for k in ("rgb_weight", "perceptual_weight", "eikonal_weight", "mask_weight", "off_surface_weight", "inside_weight",
+              "params_weight", "skinning_weight", "rgb_loss_type"):
+        assert cfg["training"][k] == my_cfg["training"][k], (k, cfg["training"][k], my_cfg["training"][k])
+    inputs = scene.make_inputs(128, 128, frame_idx=2, max_rays=2048, eval_mode=False)
+    ang = np.deg2rad(15.0)
+    view_noise = torch.tensor([[[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]]], dtype=torch.float32)
+    inputs["pose_cond"]["view_noise"] = view_noise
+    draws, orig = [], torch.rand
+
+    def recording_rand(*a, **k):
+        t = orig(*a, **k)
+        draws.append(t.detach().clone())
+        return t
+
+    torch.manual_seed(1234)
+    torch.rand = recording_rand
+    try:
+        out = model(inputs)
+    finally:
+        torch.rand = orig
+    assert [tuple(d.shape) for d in draws] == [(1, 2048, 64), (1, 2048, 17), (1, 2048, 16), (1, 1024, 3)], \
+        [tuple(d.shape) for d in draws]
+    t = cfg["training"]
+    crit = IDHRLoss(t["rgb_weight"], t["perceptual_weight"], t["eikonal_weight"], t["mask_weight"], t["off_surface_weight"],
+                    t["inside_weight"], t["params_weight"], t["skinning_weight"], t["rgb_loss_type"])
+    loss = crit(out, {"rgb": inputs["rgb_values"], "sampled_weights": inputs["sampled_weights"]})
+    loss["loss"].backward()
+    grads = {"grad." + n: p.grad.norm() for n, p in model.named_parameters() if p.grad is not None}
+    n_no_grad = sum(1 for n, p in model.named_parameters() if p.grad is None)
+    print("parameters with / without gradient:", len(grads), n_no_grad)
+    save("f8_train_step_zju313.npz", frame_idx=2, H=128, W=128, max_rays=2048, view_noise=view_noise,
+         rand_steps=draws[0][0], rand_near=draws[1][0], rand_far=draws[2][0], rand_eikonal=draws[3][0],
+         rgb_values=out["rgb_values"][0], sdf_output=out["sdf_output"][0], network_body_mask=out["network_body_mask"][0],
+         off_surface_sdf=out["off_surface_sdf"][0], grad_theta=out["grad_theta"], pred_weights=out["pred_weights"][0],
+         inside_sdf=out["inside_sdf"], **{"loss." + k: v.reshape(-1)[0] for k, v in loss.items()}, **grads)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f8":
+        return make_f8()
     torch.set_num_threads(os.cpu_count())
     scene = synthetic.SyntheticScene(seed=0)
     model, cfg = build_reference_model("zju377_mono")

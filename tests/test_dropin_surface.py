@@ -52,14 +52,3 @@ def test_state_dict_names_and_checkpoint_roundtrip(tmp_path):
     a = lm.model.state_dict()["color_decoder.lin2.bias"]
     b = model.state_dict()["color_decoder.lin2.bias"] + 1.0
     assert torch.equal(a, b) and lm.model.latent.weight.shape == (3, 128)
-
-
-def test_training_mode_refuses_instead_of_falling_back():
-    from arah_release_amd import config
-    model, cfg = config.build_synthetic_model("zju377_mono")
-    model.train()
-    try:
-        model.idhr_network({})
-    except NotImplementedError:
-        return
-    raise AssertionError("training path must raise until it is implemented")
