@@ -53,6 +53,21 @@ def aggregate(local_rays, local_seconds, dist=None):
     return float(r.item()), float(t.item())
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json,
+    made by tools/rocpd_pmc.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent.
+    PMC counters cannot be read from inside the process, so this is the one figure that is not measured live."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return (k["hbm_bytes_avg"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
+    except Exception:
+        return None, None
+
+
 def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays):
     """Oracle on `sample_rays` rays spread evenly over frame 0 of the benchmark workload."""
     from arah_release_amd import config
@@ -168,6 +183,8 @@ def main():
         avg_ms = sum(shade_ms) / n_launch
         achieved_full = samples_per_launch * flops_per_sample / (avg_ms * 1e-3) / 1e12
         total_flops = path_flops(counters)
+        dens_traffic, traffic_src = pmc_traffic("k_density")
+        shade_traffic, _ = pmc_traffic("k_shade<%s>" % ("true" if mode == "idr" else "false"))
         line = {
             "metric": "rendered rays/sec", "value": total_rays / t_max, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / max(args.steps, 1),
@@ -178,7 +195,8 @@ def main():
                        "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
                        "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": dens_traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples, "flops_per_sample": F_SDF},
             "full_shading": {"note": "same frames with lazy shading off (normal + colour for EVERY valid sample, as "
                                      "the reference does); bit-identical images",
@@ -187,7 +205,7 @@ def main():
                              "algorithmic_mflop_per_ray": path_flops(counters_full) / max(n_rays_local, 1) / 1e6,
                              "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": achieved_full,
                                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": achieved_full / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                                          "frac": achieved_full / PEAK_F32_MFMA_TFLOPS, "traffic": shade_traffic,
                                           "avg_launch_ms": avg_ms, "samples_per_launch": samples_per_launch,
                                           "flops_per_sample": flops_per_sample}},
             "work": {"per_ray": {k: v / max(n_rays_local, 1) for k, v in counters.items()},
