@@ -63,26 +63,32 @@ __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, 
         }
         return;
     }
-    f32x4 a_cur[MT], a_nxt[MT];
+    // software pipeline, one 16-chunk deep on both operands: the A fragments (global/L2) and the B fragments
+    // (LDS) of chunk kc+1 are in flight while the 4*MT*NT MFMAs of chunk kc issue, so that a single wave per
+    // SIMD keeps the matrix pipe busy (the ping-pong kernels rely on that)
+    f32x4 a_cur[MT], a_nxt[MT], b_cur[kNT], b_nxt[kNT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_cur[m] = aptr[(m * KC) * 64];
+#pragma unroll
+    for (int n = 0; n < kNT; ++n) b_cur[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld);
 #pragma unroll 1
     for (int kc = 0; kc < KC; ++kc) {
         const int kn = (kc + 1 < KC) ? kc + 1 : kc;
 #pragma unroll
         for (int m = 0; m < MT; ++m) a_nxt[m] = aptr[(m * KC + kn) * 64];
-        f32x4 b[kNT];
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) b[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kc * 16);
+        for (int n = 0; n < kNT; ++n) b_nxt[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kn * 16);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < kNT; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][t], b[n][t], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][t], b_cur[n][t], acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) b_cur[n] = b_nxt[n];
     }
 }
 
