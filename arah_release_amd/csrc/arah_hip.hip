@@ -29,7 +29,7 @@ constexpr int kBroydenSteps = 50;      // broyden.py:4
 constexpr float kDvg = 1.0f;
 constexpr int kMaxVerts = 6912;
 constexpr int kKnnThreads = 512;
-constexpr int kMaxGrid = 1024;         // persistent grid cap for the MFMA kernels
+constexpr int kMaxGrid = 512;          // persistent grid cap for the MFMA kernels: 256 CUs x (at most) 2 resident workgroups
 
 // ------------------------------------------------------------------------------------------
 // device-side frame view
@@ -691,20 +691,25 @@ struct TraceState {
     uint8_t* diverged;   // [N]
 };
 
-__global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState st, const int* list, const int* count,
-                                                         int* next_list, int* next_count,
-                                                         unsigned long long* ctr_fwd) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+// Lists shorter than this are processed in 16-point tiles (NT = 1): a 64-point tile keeps one CU busy for
+// ~100 us, and the tail iterations of the loops (a handful of stragglers) are pure latency.  Per-point
+// results are bit-identical for both tile widths (same per-accumulator k-order, same reductions).
+constexpr int kNarrowBelow = 16 * 512;
+
+template <int NT>
+__device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceState& st, const int* list, int n,
+                                                int* next_list, int* next_count, unsigned long long* ctr_fwd,
+                                                float* smem) {
+    constexpr int TW = 16 * NT;
     float* xin = smem;
     float* outv = xin + 64 * 4;
     int* ids = reinterpret_cast<int*>(outv + 64 * 4);
     float* actA = reinterpret_cast<float*>(ids + 64);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = *count;
     const float scale = sdf_scale(fr.bc);
-    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
-        if (tid < kTile) {
-            const int i = tile * kTile + tid;
+    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
+        if (tid < TW) {
+            const int i = tile * TW + tid;
             const int id = i < n ? list[i] : -1;
             ids[tid] = id;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
@@ -712,13 +717,13 @@ __global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState 
             reinterpret_cast<f32x4*>(xin)[tid] = x;
         }
         __syncthreads();
-        f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<false>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
-        sdf_head(fr.sdf, actA, kSdfLd, outv, 4, tid);
+        f32x4 dlast[kSdfMT][NT];
+        sdf_trunk<false, NT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head(fr.sdf, actA, kSdfLd, outv, 4, tid, TW);
         __syncthreads();
-        if (tid == 0) count_add(ctr_fwd, min(kTile, n - tile * kTile));
-        if (tid < kTile) {
-            const int id = ids[tid];
+        if (tid == 0) count_add(ctr_fwd, min(TW, n - tile * TW));
+        if (tid < 64) {   // whole wave 0 takes part in the ballot
+            const int id = tid < TW ? ids[tid] : -1;
             bool keep = false;
             if (id >= 0) {
                 const float sdf = outv[tid * 4] * scale;                       // RT:528
@@ -736,6 +741,15 @@ __global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState 
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState st, const int* list, const int* count,
+                                                         int* next_list, int* next_count,
+                                                         unsigned long long* ctr_fwd) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = *count;
+    if (n < kNarrowBelow) sdf_march_tiles<1>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
+    else sdf_march_tiles<kNT>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -942,23 +956,21 @@ __device__ __forceinline__ void canon_flush(const CanonOut& o, int id, const f32
     o.err[id] = eb;
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(kThreads, 4) void k_canon_iter(FrameDev fr, const CanonRec* __restrict__ rin,
-                                                             CanonRec* __restrict__ rout, const int* count,
-                                                             int* next_count, TargetSrc ts, CanonOut outp,
-                                                             unsigned long long* ctr) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <bool FIRST, int NT>
+__device__ __forceinline__ void canon_tiles(const FrameDev& fr, const CanonRec* __restrict__ rin,
+                                            CanonRec* __restrict__ rout, int n, int* next_count, const TargetSrc& ts,
+                                            const CanonOut& outp, unsigned long long* ctr, float* smem) {
+    constexpr int TW = 16 * NT;
     float* xin = smem;                        // [64][4] normalised
     float* xraw = xin + 64 * 4;               // [64][4] raw x + id
     float* sbones = xraw + 64 * 4;            // [24][16]
     float* logits = sbones + 24 * 16 + 64;    // [64][33]
     float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = *count;
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
-    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
-        if (tid < kTile) {
-            const int i = tile * kTile + tid;
+    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
+        if (tid < TW) {
+            const int i = tile * TW + tid;
             f32x4 r0 = {0.f, 0.f, 0.f, __int_as_float(-1)};
             if (i < n) r0 = rin[i].r[0];
             const V3 q = normalize_pt(fr.bc, V3{r0[0], r0[1], r0[2]});
@@ -966,11 +978,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_iter(FrameDev fr, const C
             reinterpret_cast<f32x4*>(xraw)[tid] = r0;
         }
         __syncthreads();
-        skin_mlp(fr.skin, xin, act, logits, wave, lane);
-        if (tid == 0) count_add(ctr, min(kTile, n - tile * kTile));
-        if (tid < kTile) {
-            const int i = tile * kTile + tid;
-            const f32x4 r0 = reinterpret_cast<const f32x4*>(xraw)[tid];
+        skin_mlp<NT>(fr.skin, xin, act, logits, wave, lane);
+        if (tid == 0) count_add(ctr, min(TW, n - tile * TW));
+        if (tid < 64) {   // whole wave 0 takes part in the ballot; lanes >= TW carry no point
+            const int i = tile * TW + tid;
+            const f32x4 r0 = tid < TW ? reinterpret_cast<const f32x4*>(xraw)[tid] : f32x4{0.f, 0.f, 0.f, __int_as_float(-1)};
             const int id = __float_as_int(r0[3]);
             const V3 x = V3{r0[0], r0[1], r0[2]};
             bool keep = false, improved = false;
@@ -1059,6 +1071,17 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_iter(FrameDev fr, const C
     }
 }
 
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads, 4) void k_canon_iter(FrameDev fr, const CanonRec* __restrict__ rin,
+                                                             CanonRec* __restrict__ rout, const int* count,
+                                                             int* next_count, TargetSrc ts, CanonOut outp,
+                                                             unsigned long long* ctr) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = *count;
+    if (n < kNarrowBelow) canon_tiles<FIRST, 1>(fr, rin, rout, n, next_count, ts, outp, ctr, smem);
+    else canon_tiles<FIRST, kNT>(fr, rin, rout, n, next_count, ts, outp, ctr, smem);
+}
+
 // records still alive after the last iteration hand in their best iterate
 __global__ void k_canon_drain(const CanonRec* __restrict__ rin, const int* count, CanonOut outp) {
     const int n = *count;
@@ -1131,12 +1154,11 @@ __global__ void k_joint_init(FrameDev fr, Broyden4State st, RaySet rs, const int
     }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
-                                                          const int* count, int* next_list, int* next_count,
-                                                          unsigned long long* ctr_skin,
-                                                          unsigned long long* ctr_sdf) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+template <bool FIRST, int NT>
+__device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4State& st, const RaySet& rs, const int* list,
+                                            int n, int* next_list, int* next_count, unsigned long long* ctr_skin,
+                                            unsigned long long* ctr_sdf, float* smem) {
+    constexpr int TW = 16 * NT;
     float* xin = smem;                        // [64][4] normalised
     float* xraw = xin + 64 * 4;               // [64][4] raw x_hat + depth
     float* outv = xraw + 64 * 4;              // [64][4]
@@ -1145,12 +1167,11 @@ __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4St
     float* logits = reinterpret_cast<float*>(ids + 64);    // [64][33]
     float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer   // [64][260]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int n = *count;
     const float scale = sdf_scale(fr.bc);
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
-    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
-        if (tid < kTile) {
-            const int i = tile * kTile + tid;
+    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
+        if (tid < TW) {
+            const int i = tile * TW + tid;
             const int id = i < n ? list[i] : -1;
             ids[tid] = id;
             f32x4 u = {0.f, 0.f, 0.f, 0.f};
@@ -1160,18 +1181,18 @@ __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4St
             reinterpret_cast<f32x4*>(xraw)[tid] = u;
         }
         __syncthreads();
-        skin_mlp(fr.skin, xin, act, logits, wave, lane);
-        f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<false>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
-        sdf_head(fr.sdf, act, kSdfLd, outv, 4, tid);
+        skin_mlp<NT>(fr.skin, xin, act, logits, wave, lane);
+        f32x4 dlast[kSdfMT][NT];
+        sdf_trunk<false, NT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head(fr.sdf, act, kSdfLd, outv, 4, tid, TW);
         __syncthreads();
         if (tid == 0) {
-            const int cnt = min(kTile, n - tile * kTile);
+            const int cnt = min(TW, n - tile * TW);
             count_add(ctr_skin, cnt);
             count_add(ctr_sdf, cnt);
         }
-        if (tid < kTile) {
-            const int id = ids[tid];
+        if (tid < 64) {   // whole wave 0 takes part in the ballot
+            const int id = tid < TW ? ids[tid] : -1;
             bool keep = false;
             if (id >= 0) {
                 float T[16];
@@ -1233,6 +1254,17 @@ __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4St
         }
         __syncthreads();
     }
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
+                                                          const int* count, int* next_list, int* next_count,
+                                                          unsigned long long* ctr_skin,
+                                                          unsigned long long* ctr_sdf) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n = *count;
+    if (n < kNarrowBelow) joint_tiles<FIRST, 1>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
+    else joint_tiles<FIRST, kNT>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
 }
 
 // ------------------------------------------------------------------------------------------

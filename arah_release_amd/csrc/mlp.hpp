@@ -34,9 +34,9 @@ constexpr int kNT = 4;        // N-tiles (16 points each) per wave
 __device__ __forceinline__ void zero_acc(f32x4& a) { a = f32x4{0.f, 0.f, 0.f, 0.f}; }
 
 // acc[m][n] += Wp(rows of M-tiles mt0..mt0+MT-1, KC 16-chunks) * act(64 points)
-template <int KC, int MT>
+template <int KC, int MT, int NT = kNT>
 __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, const float* act, int ld,
-                                         f32x4 (&acc)[MT][kNT], int lane) {
+                                         f32x4 (&acc)[MT][NT], int lane) {
     const int j = lane & 15, g = lane >> 4;
     const float* bptr = act + j * ld + 4 * g;
     const f32x4* aptr = reinterpret_cast<const f32x4*>(wp) + (size_t)mt0 * KC * 64 + lane;
@@ -50,15 +50,15 @@ __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, 
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             __builtin_amdgcn_sched_barrier(0);   // keep the B fragments of later chunks from being hoisted (VGPRs)
-            f32x4 b[kNT];
+            f32x4 b[NT];
 #pragma unroll
-            for (int n = 0; n < kNT; ++n) b[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kc * 16);
+            for (int n = 0; n < NT; ++n) b[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kc * 16);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < kNT; ++n)
+                    for (int n = 0; n < NT; ++n)
                         acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_all[m][kc][t], b[n][t], acc[m][n], 0, 0, 0);
         }
         return;
@@ -66,29 +66,29 @@ __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, 
     // software pipeline, one 16-chunk deep on both operands: the A fragments (global/L2) and the B fragments
     // (LDS) of chunk kc+1 are in flight while the 4*MT*NT MFMAs of chunk kc issue, so that a single wave per
     // SIMD keeps the matrix pipe busy (the ping-pong kernels rely on that)
-    f32x4 a_cur[MT], a_nxt[MT], b_cur[kNT], b_nxt[kNT];
+    f32x4 a_cur[MT], a_nxt[MT], b_cur[NT], b_nxt[NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) a_cur[m] = aptr[(m * KC) * 64];
 #pragma unroll
-    for (int n = 0; n < kNT; ++n) b_cur[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld);
+    for (int n = 0; n < NT; ++n) b_cur[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld);
 #pragma unroll 1
     for (int kc = 0; kc < KC; ++kc) {
         const int kn = (kc + 1 < KC) ? kc + 1 : kc;
 #pragma unroll
         for (int m = 0; m < MT; ++m) a_nxt[m] = aptr[(m * KC + kn) * 64];
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) b_nxt[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kn * 16);
+        for (int n = 0; n < NT; ++n) b_nxt[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kn * 16);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < kNT; ++n)
+                for (int n = 0; n < NT; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[m][t], b_cur[n][t], acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < MT; ++m) a_cur[m] = a_nxt[m];
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) b_cur[n] = b_nxt[n];
+        for (int n = 0; n < NT; ++n) b_cur[n] = b_nxt[n];
     }
 }
 
@@ -171,16 +171,16 @@ __device__ __forceinline__ void film_sine(const f32x4 v, const f32x4 b, const f3
 // Forward trunk on a 64-point tile.  xin: LDS [64][4] normalised coords.  act: LDS [64][ld], receives h6.
 // GRAD: dact factors of layers 1..5 go to `spill` (global, this workgroup's private slab of
 // 5*8*8*64 f32x4), layer 6's stay in `dlast`.
-template <bool GRAD>
+template <bool GRAD, int NT = kNT>
 __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
-                                          f32x4 (&dlast)[kSdfMT][kNT], int wave, int lane) {
+                                          f32x4 (&dlast)[kSdfMT][NT], int wave, int lane) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
     // layer 1: K = 3 on the vector ALU, same accumulator ownership as the MFMA layers
     {
-        f32x4 x[kNT];
+        f32x4 x[NT];
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) x[n] = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
+        for (int n = 0; n < NT; ++n) x[n] = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
@@ -191,25 +191,25 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + ch0);
             const f32x4 p = *reinterpret_cast<const f32x4*>(net.phase + ch0);
 #pragma unroll
-            for (int n = 0; n < kNT; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 v, h, d;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = w[r][0] * x[n][0] + w[r][1] * x[n][1] + w[r][2] * x[n][2];
                 film_sine(v, b, f, p, h, d, GRAD);
                 *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
-                if (GRAD) spill[((0 * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane] = d;
+                if (GRAD) spill[((0 * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
             }
         }
     }
     __syncthreads();
 #pragma unroll 1
     for (int k = 1; k < 6; ++k) {
-        f32x4 acc[kSdfMT][kNT];
+        f32x4 acc[kSdfMT][NT];
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
-            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<16, kSdfMT>(net.wp[k - 1], mt0, act, ld, acc, lane);
+            for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
+        gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
         __syncthreads();   // everyone is done reading the layer input
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
@@ -218,12 +218,12 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0);
             const f32x4 p = *reinterpret_cast<const f32x4*>(net.phase + k * 256 + ch0);
 #pragma unroll
-            for (int n = 0; n < kNT; ++n) {
+            for (int n = 0; n < NT; ++n) {
                 f32x4 h, d;
                 film_sine(acc[m][n], b, f, p, h, d, GRAD);
                 *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
                 if (GRAD) {
-                    if (k < 5) spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane] = d;
+                    if (k < 5) spill[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
                     else dlast[m][n] = d;
                 }
             }
@@ -232,10 +232,11 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
     }
 }
 
-// sdf[pt] = w6 . h6[pt] + b6  -> out[pt*ostride]; 8 threads per point.
+// sdf[pt] = w6 . h6[pt] + b6  -> out[pt*ostride]; 8 threads per point (the first 8*n_pts threads work).
 __device__ __forceinline__ void sdf_head(const SdfNet& net, const float* act, int ld, float* out, int ostride,
-                                         int tid) {
+                                         int tid, int n_pts = kTile) {
     const int pt = tid >> 3, part = tid & 7;
+    if (pt >= n_pts) return;   // whole waves drop out: 8 lanes per point, n_pts is a multiple of 8
     float s = 0.f;
 #pragma unroll 8
     for (int i = 0; i < 32; ++i) {
@@ -329,7 +330,8 @@ __device__ __forceinline__ float softplus100(float x) {
     return fmaxf(x, 0.f) + __builtin_amdgcn_logf(1.0f + e) * 6.93147180559945e-3f;
 }
 
-// xin LDS [64][4] normalised coords -> logits LDS [64][kLogitLd] (25 valid, un-scaled)
+// xin LDS [16*NT][4] normalised coords -> logits LDS [16*NT][kLogitLd] (25 valid, un-scaled)
+template <int NT = kNT>
 __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, float* act, float* logits, int wave,
                                          int lane) {
     const int j = lane & 15, g = lane >> 4;
@@ -341,7 +343,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + ch0);
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) {
+        for (int n = 0; n < NT; ++n) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
             f32x4 h;
 #pragma unroll
@@ -352,15 +354,15 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
     __syncthreads();
 #pragma unroll 1
     for (int k = 1; k < 4; ++k) {
-        f32x4 acc[1][kNT];
+        f32x4 acc[1][NT];
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
-        gemm_acc<8, 1>(net.wp[k - 1], wave, act, ld, acc, lane);
+        for (int n = 0; n < NT; ++n) zero_acc(acc[0][n]);
+        gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
         __syncthreads();
         const int ch0 = wave * 16 + 4 * g;
         const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
 #pragma unroll
-        for (int n = 0; n < kNT; ++n) {
+        for (int n = 0; n < NT; ++n) {
             f32x4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[r] = softplus100(acc[0][n][r] + b[r]);
@@ -370,11 +372,13 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
     }
     {   // output layer 128 -> 25 (padded 32): wave w computes M-tile (w & 1) of N-tile (w >> 1)
         const int mt = wave & 1, nt = wave >> 1;
-        const f32x4 acc = gemm_one<8>(net.w4p, mt, nt, act, ld, lane);
-        const int ch0 = mt * 16 + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + 4 * 128 + ch0);
+        if (nt < NT) {
+            const f32x4 acc = gemm_one<8>(net.w4p, mt, nt, act, ld, lane);
+            const int ch0 = mt * 16 + 4 * g;
+            const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + 4 * 128 + ch0);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) logits[(nt * 16 + j) * kLogitLd + ch0 + r] = acc[r] + b[r];
+            for (int r = 0; r < 4; ++r) logits[(nt * 16 + j) * kLogitLd + ch0 + r] = acc[r] + b[r];
+        }
     }
     __syncthreads();
 }
