@@ -148,6 +148,13 @@ def test_nearest_inverse_lbs(ctx, scene):
     x_ref, T_ref = O.nn_inverse_lbs(fr, pts)
     np.testing.assert_allclose(x0.cpu().numpy()[same], x_ref.numpy()[same], rtol=1e-4, atol=2e-5)
     np.testing.assert_allclose(T0.cpu().numpy()[same], T_ref.numpy()[same], rtol=1e-4, atol=2e-5)
+    # short lists take the one-wave-per-query path (no LDS staging): identical answers, incl. far-away points
+    far = pts[:1500] + torch.randn(1500, 3, generator=gen) * 0.4
+    both = torch.cat([far, pts[:2596]])                       # 4096 points -> bulk path
+    idx_bulk, x_bulk, T_bulk = hip.nearest_inverse_lbs(ctx["frame"], ctx["ws"], both.to(ctx["dev"]))
+    idx_wave, x_wave, T_wave = hip.nearest_inverse_lbs(ctx["frame"], ctx["ws"], far.to(ctx["dev"]))
+    assert torch.equal(idx_wave, idx_bulk[:1500]) and torch.equal(x_wave, x_bulk[:1500]) and torch.equal(T_wave, T_bulk[:1500])
+    assert (idx_wave.cpu().long() == O.nearest_vertex(fr, far)).float().mean() >= 0.999
 
 
 @gpu
