@@ -53,6 +53,7 @@ struct FrameDev {
     BodyConst bc;
     float beta;
     int n_verts;
+    int split;   // 1: forward SDF trunks run on the f16-split engine (ARAH_PRECISION_SPLIT_F16)
 };
 
 FrameDev to_dev(const ArahFrame& f) {
@@ -67,6 +68,11 @@ FrameDev to_dev(const ArahFrame& f) {
     d.sdf.freq = f.sdf_freq;
     d.sdf.phase = f.sdf_phase;
     d.sdf.b6 = f.sdf_b6;   // device pointer
+    d.sdf.fw = f.sdf_fw;
+    d.sdf.pw = f.sdf_pw;
+    d.sdf.fws = f.sdf_fws;
+    for (int i = 0; i < 5; ++i) d.sdf.wps[i] = reinterpret_cast<const f16x8*>(f.sdf_wps[i]);
+    d.split = f.precision == ARAH_PRECISION_SPLIT_F16 ? 1 : 0;
     d.skin.w0 = f.skin_w0;
     for (int i = 0; i < 3; ++i) d.skin.wp[i] = f.skin_wp[i];
     d.skin.w4p = f.skin_w4p;
@@ -134,6 +140,64 @@ __global__ void k_pack(float* __restrict__ dst, const float* __restrict__ src, i
         if (sc >= 0 && row < M) v[t] = transpose ? src[(size_t)sc * ld + row] : src[(size_t)row * ld + sc];
     }
     reinterpret_cast<f32x4*>(dst)[idx] = v;
+}
+
+// max |src| as float bits (non-negative floats order like unsigned ints); *amax must start at 0
+__global__ void k_absmax(const float* __restrict__ src, int n, unsigned* amax) {
+    float m = 0.f;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float a = fabsf(src[i]);
+        if (a == a) m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(amax, __float_as_uint(m));
+}
+
+// power-of-two weight scale that puts the largest |w| of the layer in [2^13, 2^14): hi never overflows f16
+// (max 65504), and lo parts flushed as f16 subnormals cost < 2^-28 of the largest weight
+__device__ __forceinline__ float split_weight_scale(unsigned amax_bits) {
+    const float a = __uint_as_float(amax_bits);
+    if (!(a > 0.f) || a > 3.0e38f) return 1.0f;
+    int e;
+    frexpf(a, &e);   // a = m 2^e, m in [0.5, 1)
+    return ldexpf(1.0f, 14 - e);
+}
+
+// split-engine A operand of one 256x256 layer: dst[((mt*8 + kc)*2 + s)*64 + lane] holds 8 halves (s = 0 hi, 1 lo)
+// of scale * src[mt*16 + (lane&15)][kc*32 + 8 (lane>>4) .. +7]
+__global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ src, int ld, int m_tiles, int KC32,
+                             const unsigned* amax) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m_tiles * KC32 * 64) return;
+    const float scale = split_weight_scale(*amax);
+    const int lane = idx & 63, tile = idx >> 6, kc = tile % KC32, mt = tile / KC32;
+    const int row = mt * 16 + (lane & 15);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float w = src[(size_t)row * ld + kc * 32 + (lane >> 4) * 8 + e] * scale;
+        const _Float16 h = (_Float16)w;
+        hi[e] = h;
+        lo[e] = (_Float16)(w - (float)h);
+    }
+    dst[(size_t)(tile * 2 + 0) * 64 + lane] = hi;
+    dst[(size_t)(tile * 2 + 1) * 64 + lane] = lo;
+}
+
+// FiLM constants in half-revolutions: z = 30 (f (v + b) + phi) = pi (fw v + pw); fws = fw / (weight scale * act scale)
+// of the split layer that produces v (layer 0 runs on the vector ALU: fws = fw)
+__global__ void k_fold_film(const float* __restrict__ freq, const float* __restrict__ phase, const float* __restrict__ bias,
+                            const unsigned* amax, float* fw, float* pw, float* fws) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 6 * 256) return;
+    const int k = i >> 8;
+    const double c = 30.0 / 3.14159265358979323846;
+    const double f = freq[i];
+    fw[i] = (float)(f * c);
+    pw[i] = (float)((f * (double)bias[i] + (double)phase[i]) * c);
+    const float inv = k == 0 ? 1.0f : 1.0f / (split_weight_scale(amax[k - 1]) * kActScale);
+    fws[i] = (float)(f * c) * inv;
 }
 
 // dst[r][0..3] = {src[r][0..ncol-1], 0...}
@@ -740,7 +804,7 @@ __device__ __forceinline__ void store_T(float* dst, const float (&T)[16]) {
 // ------------------------------------------------------------------------------------------
 constexpr int kSpillPerWg = 5 * kWaves * (kSdfMT * kNT) * 64;   // f32x4 elements
 
-template <bool GRAD>
+template <bool GRAD, bool SPLIT>
 __global__ __launch_bounds__(kThreads) void k_sdf_eval(FrameDev fr, const float* x_norm, const int* list,
                                                         const int* count, int n_direct, float* sdf_out,
                                                         float* feat_out, float* grad_out, f32x4* spill_all,
@@ -765,8 +829,8 @@ __global__ __launch_bounds__(kThreads) void k_sdf_eval(FrameDev fr, const float*
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<GRAD>(fr.sdf, xin, actA, kSdfLd, spill, dlast, wave, lane);
-        sdf_head(fr.sdf, actA, kSdfLd, outv, 4, tid);
+        sdf_trunk<GRAD, kNT, SPLIT>(fr.sdf, xin, actA, kSdfLd, spill, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid);
         if (GRAD) sdf_backward(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
         __syncthreads();
         if (tid == 0) {
@@ -784,6 +848,10 @@ __global__ __launch_bounds__(kThreads) void k_sdf_eval(FrameDev fr, const float*
             }
         }
         if (feat_out) {
+            if (SPLIT) {
+                unsplit_rows(actA, kSdfLd, tid);
+                __syncthreads();
+            }
             for (int e = tid; e < kTile * 64; e += kThreads) {   // 64 float4 per point
                 const int pt = e >> 6, c4 = e & 63;
                 if (ids[pt] >= 0)
@@ -810,7 +878,7 @@ struct TraceState {
 // results are bit-identical for both tile widths (same per-accumulator k-order, same reductions).
 constexpr int kNarrowBelow = 16 * 512;
 
-template <int NT>
+template <int NT, bool SPLIT>
 __device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceState& st, const int* list, int n,
                                                 int* next_list, int* next_count, unsigned long long* ctr_fwd,
                                                 float* smem) {
@@ -832,8 +900,8 @@ __device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceS
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][NT];
-        sdf_trunk<false, NT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
-        sdf_head(fr.sdf, actA, kSdfLd, outv, 4, tid, TW);
+        sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid, TW);
         __syncthreads();
         if (tid == 0) count_add(ctr_fwd, min(TW, n - tile * TW));
         if (tid < 64) {   // whole wave 0 takes part in the ballot
@@ -857,13 +925,14 @@ __device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceS
     }
 }
 
+template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState st, const int* list, const int* count,
                                                          int* next_list, int* next_count,
                                                          unsigned long long* ctr_fwd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *count;
-    if (n < kNarrowBelow) sdf_march_tiles<1>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
-    else sdf_march_tiles<kNT>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
+    if (n < kNarrowBelow) sdf_march_tiles<1, SPLIT>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
+    else sdf_march_tiles<kNT, SPLIT>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1268,7 +1337,7 @@ __global__ void k_joint_init(FrameDev fr, Broyden4State st, RaySet rs, const int
     }
 }
 
-template <bool FIRST, int NT>
+template <bool FIRST, int NT, bool SPLIT>
 __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4State& st, const RaySet& rs, const int* list,
                                             int n, int* next_list, int* next_count, unsigned long long* ctr_skin,
                                             unsigned long long* ctr_sdf, float* smem) {
@@ -1297,8 +1366,8 @@ __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4St
         __syncthreads();
         skin_mlp<NT>(fr.skin, xin, act, logits, wave, lane);
         f32x4 dlast[kSdfMT][NT];
-        sdf_trunk<false, NT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
-        sdf_head(fr.sdf, act, kSdfLd, outv, 4, tid, TW);
+        sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, act, kSdfLd, outv, 4, tid, TW);
         __syncthreads();
         if (tid == 0) {
             const int cnt = min(TW, n - tile * TW);
@@ -1370,15 +1439,15 @@ __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4St
     }
 }
 
-template <bool FIRST>
+template <bool FIRST, bool SPLIT>
 __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
                                                           const int* count, int* next_list, int* next_count,
                                                           unsigned long long* ctr_skin,
                                                           unsigned long long* ctr_sdf) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *count;
-    if (n < kNarrowBelow) joint_tiles<FIRST, 1>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
-    else joint_tiles<FIRST, kNT>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
+    if (n < kNarrowBelow) joint_tiles<FIRST, 1, SPLIT>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
+    else joint_tiles<FIRST, kNT, SPLIT>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1584,6 +1653,7 @@ __device__ __forceinline__ float volsdf_density(float sdf, float inv_beta) {
 // values: only samples with density > 0 go on to pass 2 (k_shade).  The composited image is
 // bit-identical to shading everything (tests/test_hip_parity.py::test_lazy_shading_is_exact).
 // ------------------------------------------------------------------------------------------
+template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
                                                        f32x4* shaded, int* next_list, int* next_count,
                                                        unsigned long long* ctr_fwd) {
@@ -1607,8 +1677,8 @@ __global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* 
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<false>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
-        sdf_head(fr.sdf, actA, kSdfLd, outv, 4, tid);
+        sdf_trunk<false, kNT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid);
         __syncthreads();
         if (tid == 0) count_add(ctr_fwd, min(kTile, n - tile * kTile));
         if (tid < kTile) {
@@ -1629,7 +1699,7 @@ __global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* 
 // loop D: SDF value + normal (reverse sweep) + colour MLP + VolSDF density per valid sample
 // (IDR:291-368), then per-ray compositing (IDR:370-394)
 // ------------------------------------------------------------------------------------------
-template <bool IDR>
+template <bool IDR, bool SPLIT>
 __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano_view_dirs, const float* dirs,
                                                      const float* pts, const float* T, const int* list,
                                                      const int* count, int n_direct, f32x4* shaded,
@@ -1660,8 +1730,9 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<true>(fr.sdf, xin, actA, D::kLdA, spill, dlast, wave, lane);
-        sdf_head(fr.sdf, actA, D::kLdA, outv, 4, tid);
+        sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, D::kLdA, spill, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, actA, D::kLdA, outv, 4, tid);
+        if (SPLIT) unsplit_rows(actA, D::kLdA, tid);   // the colour MLP (exact engine) reads the feature as fp32
         sdf_backward(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
         __syncthreads();
         if (tid < kTile) {   // colour-input extras behind the feature: x(3), n(3), [PE4(view) 27], zero pad
@@ -1950,7 +2021,12 @@ Workspace carve(void* base, int n_rays, int n_steps) {
 inline int grid_for(long long n_items, int per_block) {
     long long g = (n_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
-    if (g > kMaxGrid) g = kMaxGrid;
+    static const int cap = [] {   // ARAH_MAX_GRID: debugging / tuning knob (<= kMaxGrid, the spill slab is sized for it)
+        const char* e = getenv("ARAH_MAX_GRID");
+        const int v = e ? atoi(e) : kMaxGrid;
+        return v >= 1 && v <= kMaxGrid ? v : kMaxGrid;
+    }();
+    if (g > cap) g = cap;
     return (int)g;
 }
 
@@ -1971,6 +2047,20 @@ constexpr size_t lds_color() {
     return (64 * 4) * 4 + (size_t)64 * ColDims<IDR>::kLdA * 4 + (size_t)64 * kSdfLd * 4;
 }
 
+// Launch KS when the frame was prepared for the split engine, KE (exact fp32) otherwise.
+// A split-engine kernel must be ALONE on its CU: with two workgroups of it co-resident (4 waves per SIMD) results
+// became irreproducible on MI355X / ROCm 7.2 -- whole 16-point groups of a tile wrong, run to run, while the same
+// binary is bit-reproducible with one workgroup per CU (tools/ubench/trunk_repro.hip isolates it).  The launch
+// therefore asks for at least kLdsSplitSolo bytes of LDS, more than half of the CU's 160 KB.
+constexpr size_t kLdsSplitSolo = 84 * 1024;
+#define LAUNCH_ENGINE(split, KS, KE, GRID, BLOCK, LDS, ...)                                             \
+    do {                                                                                                \
+        if (split)                                                                                      \
+            hipLaunchKernelGGL(KS, GRID, BLOCK, (LDS) > kLdsSplitSolo ? (LDS) : kLdsSplitSolo, __VA_ARGS__); \
+        else                                                                                            \
+            hipLaunchKernelGGL(KE, GRID, BLOCK, LDS, __VA_ARGS__);                                      \
+    } while (0)
+
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -1983,18 +2073,26 @@ void setup_attributes() {
     allow_lds(k_nearest_invlbs<SRC_POINTS>, kLdsKnn);
     allow_lds(k_nearest_invlbs<SRC_RAYS>, kLdsKnn);
     allow_lds(k_nearest_invlbs<SRC_SAMPLES>, kLdsKnn);
-    allow_lds(k_sdf_eval<false>, kLdsSdfFwd);
-    allow_lds(k_sdf_eval<true>, kLdsSdfGrad);
-    allow_lds(k_sdf_march, kLdsSdfFwd);
-    allow_lds(k_density, kLdsSdfFwd);
+    allow_lds(k_sdf_eval<false, false>, kLdsSdfFwd);
+    allow_lds(k_sdf_eval<false, true>, kLdsSplitSolo);
+    allow_lds(k_sdf_eval<true, false>, kLdsSdfGrad);
+    allow_lds(k_sdf_eval<true, true>, kLdsSdfGrad);
+    allow_lds(k_sdf_march<false>, kLdsSdfFwd);
+    allow_lds(k_sdf_march<true>, kLdsSplitSolo);
+    allow_lds(k_density<false>, kLdsSdfFwd);
+    allow_lds(k_density<true>, kLdsSplitSolo);
     allow_lds(k_skin_eval, kLdsSkin);
     allow_lds(k_skin_jac, kLdsSkin);
     allow_lds(k_canon_iter<true>, kLdsSkin);
     allow_lds(k_canon_iter<false>, kLdsSkin);
-    allow_lds(k_joint_iter<true>, kLdsJoint);
-    allow_lds(k_joint_iter<false>, kLdsJoint);
-    allow_lds(k_shade<false>, lds_shade<false>());
-    allow_lds(k_shade<true>, lds_shade<true>());
+    allow_lds(k_joint_iter<true, false>, kLdsJoint);
+    allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
+    allow_lds(k_joint_iter<false, false>, kLdsJoint);
+    allow_lds(k_joint_iter<false, true>, kLdsSplitSolo);
+    allow_lds(k_shade<false, false>, lds_shade<false>());
+    allow_lds(k_shade<false, true>, lds_shade<false>());
+    allow_lds(k_shade<true, false>, lds_shade<true>());
+    allow_lds(k_shade<true, true>, lds_shade<true>());
     allow_lds(k_color_eval<false>, lds_color<false>());
     allow_lds(k_color_eval<true>, lds_color<true>());
 }
@@ -2017,6 +2115,7 @@ RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
 // ---- frame buffer layout -----------------------------------------------------------------
 struct FrameLayout {
     size_t sdf_w0, sdf_wp[5], sdf_wpT[5], sdf_w6, sdf_b6, sdf_bias, sdf_freq, sdf_phase;
+    size_t sdf_wps[5], sdf_fw, sdf_pw, sdf_fws, sdf_amax;
     size_t skin_w0, skin_wp[3], skin_w4p, skin_bias;
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
     size_t verts4, knn_spheres, knn_grid, knn_cells;
@@ -2041,6 +2140,11 @@ FrameLayout frame_layout(int col_mode) {
     L.sdf_bias = take(6 * 256);
     L.sdf_freq = take(6 * 256);
     L.sdf_phase = take(6 * 256);
+    for (int i = 0; i < 5; ++i) L.sdf_wps[i] = take(256 * 256);   // hi + lo halves = 4 bytes per weight
+    L.sdf_fw = take(6 * 256);
+    L.sdf_pw = take(6 * 256);
+    L.sdf_fws = take(6 * 256);
+    L.sdf_amax = take(64);
     L.skin_w0 = take(128 * 4);
     for (int i = 0; i < 3; ++i) L.skin_wp[i] = take(128 * 128);
     L.skin_w4p = take(32 * 128);
@@ -2108,6 +2212,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     if (!nets || !body || !frame_buf || !out) return ARAH_E_BADARG;
     if (nets->col_mode != ARAH_COLOR_IDR && nets->col_mode != ARAH_COLOR_NO_VIEW_DIR) return ARAH_E_SHAPE;
     if (body->n_verts <= 0 || body->n_verts > kMaxVerts || nets->n_pose < 0) return ARAH_E_SHAPE;
+    if (nets->precision != ARAH_PRECISION_SPLIT_F16 && nets->precision != ARAH_PRECISION_FP32) return ARAH_E_BADARG;
     const FrameLayout L = frame_layout(nets->col_mode);
     if (frame_bytes < L.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
@@ -2131,6 +2236,18 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     hipLaunchKernelGGL(k_copy, dim3(6), dim3(256), 0, s, P(L.sdf_freq), nets->film_freq, 6 * 256, 6 * 256);
     hipLaunchKernelGGL(k_copy, dim3(6), dim3(256), 0, s, P(L.sdf_phase), nets->film_phase, 6 * 256, 6 * 256);
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(64), 0, s, P(L.sdf_b6), nets->sdf_b[6], 1, 64);
+    {
+        unsigned* amax = reinterpret_cast<unsigned*>(base + L.sdf_amax);
+        if (hipMemsetAsync(amax, 0, 64 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
+        for (int i = 0; i < 5; ++i) {
+            hipLaunchKernelGGL(k_absmax, dim3(16), dim3(256), 0, s, nets->sdf_w[i + 1], 256 * 256, amax + i);
+            hipLaunchKernelGGL(k_pack_split, dim3(16 * 8 * 64 / 256), dim3(256), 0, s,
+                               reinterpret_cast<f16x8*>(base + L.sdf_wps[i]), nets->sdf_w[i + 1], 256, 16, 8,
+                               (const unsigned*)(amax + i));
+        }
+        hipLaunchKernelGGL(k_fold_film, dim3(6), dim3(256), 0, s, (const float*)P(L.sdf_freq), (const float*)P(L.sdf_phase),
+                           (const float*)P(L.sdf_bias), (const unsigned*)amax, P(L.sdf_fw), P(L.sdf_pw), P(L.sdf_fws));
+    }
     // ---- skinning MLP
     hipLaunchKernelGGL(k_pad_rows4, dim3(1), dim3(128), 0, s, P(L.skin_w0), nets->skin_w[0], 128, 128, 3, 0.f);
     for (int i = 0; i < 3; ++i) launch_pack(P(L.skin_wp[i]), nets->skin_w[i + 1], 128, 128, 8, 8, one_seg(128), 0, s);
@@ -2185,6 +2302,11 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->sdf_bias = P(L.sdf_bias);
     out->sdf_freq = P(L.sdf_freq);
     out->sdf_phase = P(L.sdf_phase);
+    for (int i = 0; i < 5; ++i) out->sdf_wps[i] = base + L.sdf_wps[i];
+    out->sdf_fw = P(L.sdf_fw);
+    out->sdf_pw = P(L.sdf_pw);
+    out->sdf_fws = P(L.sdf_fws);
+    out->precision = nets->precision;
     out->skin_w0 = P(L.skin_w0);
     for (int i = 0; i < 3; ++i) out->skin_wp[i] = P(L.skin_wp[i]);
     out->skin_w4p = P(L.skin_w4p);
@@ -2249,12 +2371,13 @@ int arah_sdf_eval(const ArahFrame* f, const float* x_norm, int32_t n, float* sdf
     const FrameDev fd = to_dev(*f);
     const int g = grid_for(n, kTile);
     if (grad)
-        hipLaunchKernelGGL(k_sdf_eval<true>, dim3(g), dim3(kThreads), kLdsSdfGrad, s, fd, x_norm, (const int*)nullptr,
-                           (const int*)nullptr, n, sdf, feat, grad, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
+        LAUNCH_ENGINE(fd.split, (k_sdf_eval<true, true>), (k_sdf_eval<true, false>), dim3(g), dim3(kThreads), kLdsSdfGrad,
+                      s, fd, x_norm, (const int*)nullptr, (const int*)nullptr, n, sdf, feat, grad, w.spill,
+                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
     else
-        hipLaunchKernelGGL(k_sdf_eval<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, x_norm, (const int*)nullptr,
-                           (const int*)nullptr, n, sdf, feat, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd,
-                           (unsigned long long*)nullptr);
+        LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(g), dim3(kThreads),
+                      kLdsSdfFwd, s, fd, x_norm, (const int*)nullptr, (const int*)nullptr, n, sdf, feat, (float*)nullptr,
+                      (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr);
     return check_launch();
 }
 
@@ -2385,8 +2508,8 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
         hipLaunchKernelGGL(k_nearest_invlbs<SRC_RAYS>, dim3(gk), dim3(kKnnThreads), kLdsKnn, s, fd, knn_of(fd),
                            (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin, (const int*)&cntA[it], 0,
                            w.nn_idx, w.xcur, w.Tcur, (CanonRec*)nullptr, &w.ctr->n_knn);
-        hipLaunchKernelGGL(k_sdf_march, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts, (const int*)lin,
-                           (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
+        LAUNCH_ENGINE(fd.split, k_sdf_march<true>, k_sdf_march<false>, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts,
+                      (const int*)lin, (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
     }
     // joint root find on the non-diverged rays; best-iterate arrays: x -> xbest_ray, depth -> zbest_ray, T -> T (output)
     hipLaunchKernelGGL(k_joint_select, dim3(gb), dim3(256), 0, s, fd, n, (const float*)w.xcur, (const float*)w.Tcur,
@@ -2395,9 +2518,9 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     hipLaunchKernelGGL(k_skin_jac, dim3(grid_for(n, 16)), dim3(kThreads), kLdsSkin, s, fd, (const float*)w.x0raw,
                        (const int*)w.listA, (const int*)&cntB[0], 0, w.jac_lbs, &w.ctr->n_skin_jac);
     // d sdf / d x at the normalised start point == d(metric sdf)/d(metric x)  (RFU:408-413)
-    hipLaunchKernelGGL(k_sdf_eval<true>, dim3(gm), dim3(kThreads), kLdsSdfGrad, s, fd, (const float*)w.xcur,
-                       (const int*)w.listA, (const int*)&cntB[0], 0, w.u_gx /*scratch: sdf*/, (float*)nullptr,
-                       w.grad_sdf, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<true, true>), (k_sdf_eval<true, false>), dim3(gm), dim3(kThreads), kLdsSdfGrad, s,
+                  fd, (const float*)w.xcur, (const int*)w.listA, (const int*)&cntB[0], 0, w.u_gx /*scratch: sdf*/,
+                  (float*)nullptr, w.grad_sdf, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
     Broyden4State st{w.u_eval, w.u_step, w.u_gx, w.u_Jinv, w.err_best_ray, w.xbest_ray, w.zbest_ray, T};
     hipLaunchKernelGGL(k_joint_init, dim3(grid_for(n, 256)), dim3(256), 0, s, fd, st, rs, (const int*)w.listA,
                        (const int*)&cntB[0], (const float*)w.grad_sdf, (const float*)w.jac_lbs, (const float*)w.xcur,
@@ -2406,11 +2529,13 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
         if (it == 0)
-            hipLaunchKernelGGL(k_joint_iter<true>, dim3(gm), dim3(kThreads), kLdsJoint, s, fd, st, rs, (const int*)lin,
-                               (const int*)&cntB[it], lout, &cntB[it + 1], &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+            LAUNCH_ENGINE(fd.split, (k_joint_iter<true, true>), (k_joint_iter<true, false>), dim3(gm), dim3(kThreads),
+                          kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
+                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
         else
-            hipLaunchKernelGGL(k_joint_iter<false>, dim3(gm), dim3(kThreads), kLdsJoint, s, fd, st, rs, (const int*)lin,
-                               (const int*)&cntB[it], lout, &cntB[it + 1], &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+            LAUNCH_ENGINE(fd.split, (k_joint_iter<false, true>), (k_joint_iter<false, false>), dim3(gm), dim3(kThreads),
+                          kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
+                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
     }
     hipLaunchKernelGGL(k_trace_finalize, dim3(gb), dim3(256), 0, s, fd, n, near_far, (const float*)w.xbest_ray,
                        (const float*)w.zbest_ray, (const float*)w.err_best_ray, points_hat_norm, conv, start, end);
@@ -2501,21 +2626,21 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     const int* scount = &w.counts[0];
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
         if (g_density_ev0) hipEventRecord(g_density_ev0, s);
-        hipLaunchKernelGGL(k_density, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts, (const int*)w.listA,
-                           (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd);
+        LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
+                      (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd);
         if (g_density_ev1) hipEventRecord(g_density_ev1, s);
         slist = w.listB;
         scount = &w.counts[1];
     }
     if (g_shade_ev0) hipEventRecord(g_shade_ev0, s);
     if (f->col_mode == ARAH_COLOR_IDR)
-        hipLaunchKernelGGL(k_shade<true>, dim3(g), dim3(kThreads), lds_shade<true>(), s, fd, S, cfg->cano_view_dirs, dirs,
-                           pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad,
-                           &w.ctr->n_col);
+        LAUNCH_ENGINE(fd.split, (k_shade<true, true>), (k_shade<true, false>), dim3(g), dim3(kThreads), lds_shade<true>(),
+                      s, fd, S, cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
+                      &w.ctr->n_sdf_grad, &w.ctr->n_col);
     else
-        hipLaunchKernelGGL(k_shade<false>, dim3(g), dim3(kThreads), lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs,
-                           pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad,
-                           &w.ctr->n_col);
+        LAUNCH_ENGINE(fd.split, (k_shade<false, true>), (k_shade<false, false>), dim3(g), dim3(kThreads),
+                      lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill,
+                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col);
     if (g_shade_ev1) hipEventRecord(g_shade_ev1, s);
     hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);

@@ -5,8 +5,15 @@
 //     a slice of the layer's output channels (M-tiles of 16): 2 M-tiles for a 256-wide layer,
 //     1 for a 128-wide one.  8 independent f32x4 accumulators per wave hide the 40-cycle
 //     dependent latency of v_mfma_f32_16x16x4_f32 (issue 32 cycles).
-//   * arithmetic is exact fp32 (v_mfma_f32_16x16x4_f32 == fmaf chain): root finding needs
-//     |residual| < 1e-5 m and sin(30 x) amplifies input error, so no bf16/fp16 inputs here.
+//   * arithmetic is fp32-class everywhere: root finding needs |residual| < 1e-5 m and sin(30 x) amplifies
+//     input error, so plain bf16/fp16 inputs are out.  Two GEMM engines with the same accumulator ownership:
+//       - exact: v_mfma_f32_16x16x4_f32 (== an fmaf chain), used by every reverse sweep and, when the frame
+//         was prepared with ARAH_PRECISION_FP32, by everything;
+//       - split: every fp32 operand is carried as hi + lo, two f16 pre-scaled by a power of two (22 significant
+//         bits), and W x = W_lo x_hi + W_hi x_lo + W_hi x_hi runs as three v_mfma_f32_16x16x32_f16 with fp32
+//         accumulation (the dropped lo*lo term is 2^-22 relative).  Measured against an fp64 chain of five
+//         SIREN layers its error is BELOW the exact-fp32 engine's (tools/ubench/gemm_f16x3.hip) at 3/16 of
+//         the matrix-pipe time.  Split activations live in LDS as [point][hi: K halves | lo: K halves].
 //   * activations live in LDS as act[point][K] (row stride K+4 floats); B fragments are
 //     ds_read_b128: lane (j = lane&15, g = lane>>4) reads act[n*16+j][kc*16 + 4g .. +3].
 //   * weights stream from L2 in a layout packed once per frame so that the matching A fragment
@@ -112,6 +119,91 @@ __device__ __forceinline__ f32x4 gemm_one(const float* __restrict__ wp, int mt, 
     return acc0 + acc1;
 }
 
+// ---- split engine ------------------------------------------------------------------------
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kActScale = 1024.0f;       // activations are stored as f16 pairs of 1024 h
+constexpr float kInvActScale = 1.0f / 1024.0f;
+
+// acc[m][n] += Wsplit(M-tiles mt0..mt0+MT-1, KC32 32-chunks) * act(16 NT points)
+//   weights : wp[((mt*KC32 + kc)*2 + s)*64 + lane]  (s = 0 hi, 1 lo), lane (j, g) holds W[mt*16 + j][kc*32 + 8g .. +7]
+//   act     : LDS rows of ld floats; hi plane at byte 0, lo plane at byte lo_off; lane reads k = kc*32 + 8g .. +7
+template <int KC32, int MT, int NT>
+__device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int mt0, const float* act, int ld,
+                                               int lo_off, f32x4 (&acc)[MT][NT], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + g * 16;
+    const f16x8* aptr = wp + (size_t)mt0 * KC32 * 2 * 64 + lane;
+    f16x8 ah[MT], al[MT], ahn[MT], aln[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ah[m] = aptr[((m * KC32) * 2 + 0) * 64];
+        al[m] = aptr[((m * KC32) * 2 + 1) * 64];
+    }
+#pragma unroll 1
+    for (int kc = 0; kc < KC32; ++kc) {
+        const int kn = kc + 1 < KC32 ? kc + 1 : kc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {   // weights of the next chunk (L2) fly during this chunk's MFMAs
+            ahn[m] = aptr[((m * KC32 + kn) * 2 + 0) * 64];
+            aln[m] = aptr[((m * KC32 + kn) * 2 + 1) * 64];
+        }
+        f16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
+            bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + kc * 64);
+        }
+        // every operand load of the chunk is issued before its first MFMA, and (below) the chunk's last MFMA has
+        // left the pipe before the next chunk's loads are issued: operand registers are never re-loaded while an
+        // MFMA that reads them can still be pending (see the split-engine note in DESIGN.md)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)   // small terms first, three passes over the MT*NT independent accumulators
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(__float_as_int(acc[MT - 1][NT - 1][0]))));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[m] = ahn[m];
+            al[m] = aln[m];
+        }
+    }
+}
+
+// 4 consecutive channels of one point, already multiplied by kActScale -> hi/lo planes
+__device__ __forceinline__ void store_split4(float* act, int ld, int lo_off, int pt, int ch0, const f32x4 hs) {
+    f16x4 hi, lo;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        hi[r] = (_Float16)hs[r];
+        lo[r] = (_Float16)(hs[r] - (float)hi[r]);
+    }
+    char* row = reinterpret_cast<char*>(act) + pt * ld * 4;
+    *reinterpret_cast<f16x4*>(row + ch0 * 2) = hi;
+    *reinterpret_cast<f16x4*>(row + lo_off + ch0 * 2) = lo;
+}
+
+__device__ __forceinline__ float load_split(const float* act, int ld, int lo_off, int pt, int ch) {
+    const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4;
+    return ((float)*reinterpret_cast<const _Float16*>(row + ch * 2) +
+            (float)*reinterpret_cast<const _Float16*>(row + lo_off + ch * 2)) * kInvActScale;
+}
+
 // ------------------------------------------------------------------------------------------
 // SDF network: FiLM-SIREN 3 -> 256 x6 -> 1
 // ------------------------------------------------------------------------------------------
@@ -124,58 +216,80 @@ struct SdfNet {
     const float* freq;     // [6][256]
     const float* phase;    // [6][256]
     const float* b6;       // [1]
+    const float* fw;       // [6][256]  30 f / pi                 (z = pi (fw v + pw), v = W h)
+    const float* pw;       // [6][256]  30 (f b + phi) / pi
+    const float* fws;      // [6][256]  fw / (weight scale * kActScale) of the split layers (row 0 = fw)
+    const f16x8* wps[5];   // split-packed 256x256
 };
 
 constexpr int kSdfLd = 260;   // 256 + 4
 constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
 
-// sin/cos with a 3-term Cody-Waite reduction by pi/2 (exact product for |q| < 512) and the
-// classic single-precision minimax kernels on [-pi/4, pi/4]; ~1-2 ulp for |x| < 800, which covers
-// every SIREN pre-activation (|30 z| is O(10..100)); larger arguments take the libm path.
-__device__ __forceinline__ void sincos_cw(float x, float& s, float& c) {
-    if (fabsf(x) > 500.0f) {
-        sincosf(x, &s, &c);
-        return;
-    }
-    const float q = rintf(x * 0.63661977236758134308f);
-    float r = fmaf(q, -1.57073974609375f, x);
-    r = fmaf(q, -5.657970905303955078125e-05f, r);
-    r = fmaf(q, -9.920936294705029468e-10f, r);
+// sin(pi w), cos(pi w) for w in half-revolutions, branch-free (the epilogue must stay straight-line code so
+// that the compiler can pack it into v_pk_* and interleave it): q = rint(w), r = w - q in [-1/2, 1/2] exactly,
+// sin(pi w) = (-1)^q r S(r^2), cos(pi w) = (-1)^q C(r^2); S, C minimax fits (|err| 3.4e-9 / 2.2e-10 before
+// rounding, ~1.5 ulp evaluated in fp32).  |w| >= 2^23 gives r = 0 (sin 0, cos 1): such arguments carry no
+// fractional information in fp32 any more.
+__device__ __forceinline__ float sinpi_amp(float w, float amp) {
+    const float q = rintf(w);
+    const float r = w - q;
     const float r2 = r * r;
-    float ps = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
-    ps = fmaf(ps, r2, -1.6666654611e-1f);
-    ps = fmaf(ps * r2, r, r);
-    float pc = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
-    pc = fmaf(pc, r2, 4.166664568298827e-2f);
-    pc = fmaf(pc * r2, r2, fmaf(-0.5f, r2, 1.0f));
-    const int qi = (int)q;
-    const float ss = (qi & 1) ? pc : ps;
-    const float cc = (qi & 1) ? ps : pc;
-    s = (qi & 2) ? -ss : ss;
-    c = ((qi + 1) & 2) ? -cc : cc;
+    float p = fmaf(r2, 0.0772201280771219f * amp, -0.5980451736306471f * amp);
+    p = fmaf(p, r2, 2.550031377188653f * amp);
+    p = fmaf(p, r2, -5.167706878920042f * amp);
+    p = fmaf(p, r2, 3.1415925800446054f * amp);
+    const unsigned sgn = (unsigned)(int)q << 31;
+    return __uint_as_float(__float_as_uint(p * r) ^ sgn);
 }
 
-// h = sin(30 (f (v + b) + phi)),   dh/dv = 30 f cos(.)
-__device__ __forceinline__ void film_sine(const f32x4 v, const f32x4 b, const f32x4 f, const f32x4 p, f32x4& h,
-                                          f32x4& d, bool want_d) {
+__device__ __forceinline__ void sincospi_amp(float w, float amp, float& s, float& c) {
+    const float q = rintf(w);
+    const float r = w - q;
+    const float r2 = r * r;
+    float p = fmaf(r2, 0.0772201280771219f * amp, -0.5980451736306471f * amp);
+    p = fmaf(p, r2, 2.550031377188653f * amp);
+    p = fmaf(p, r2, -5.167706878920042f * amp);
+    p = fmaf(p, r2, 3.1415925800446054f * amp);
+    float pc = fmaf(r2, -0.02439671639064982f, 0.23493755882145678f);
+    pc = fmaf(pc, r2, -1.335212056639698f);
+    pc = fmaf(pc, r2, 4.058709164340391f);
+    pc = fmaf(pc, r2, -4.9348021372282975f);
+    pc = fmaf(pc, r2, 0.9999999997806512f);
+    const unsigned sgn = (unsigned)(int)q << 31;
+    s = __uint_as_float(__float_as_uint(p * r) ^ sgn);
+    c = __uint_as_float(__float_as_uint(pc) ^ sgn);
+}
+
+// FiLM-SIREN activation of 4 channels: h = amp sin(z), z = 30 (f (v + b) + phi) = pi (fw v + pw);
+// GRAD: d = dh/dv / amp = 30 f cos(z)
+template <bool GRAD>
+__device__ __forceinline__ void film_sine(const f32x4 v, const f32x4 fw, const f32x4 pw, const f32x4 f, float amp,
+                                          f32x4& h, f32x4& d) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float z = 30.0f * (f[r] * (v[r] + b[r]) + p[r]);
-        float s, c;
-        sincos_cw(z, s, c);
-        if (want_d) d[r] = c * (30.0f * f[r]);
-        h[r] = s;
+        const float w = fmaf(v[r], fw[r], pw[r]);
+        if (GRAD) {
+            float sn, c;
+            sincospi_amp(w, amp, sn, c);
+            h[r] = sn;
+            d[r] = c * (30.0f * f[r]);
+        } else {
+            h[r] = sinpi_amp(w, amp);
+        }
     }
 }
 
-// Forward trunk on a 64-point tile.  xin: LDS [64][4] normalised coords.  act: LDS [64][ld], receives h6.
+// Forward trunk on a tile of 16 NT points.  xin: LDS [16 NT][4] normalised coords.  act: LDS rows of ld floats,
+// receives h6 -- as fp32 [256] (exact engine) or as split planes (hi at byte 0, lo at byte 512; SPLIT).
 // GRAD: dact factors of layers 1..5 go to `spill` (global, this workgroup's private slab of
 // 5*8*8*64 f32x4), layer 6's stay in `dlast`.
-template <bool GRAD, int NT = kNT>
+template <bool GRAD, int NT = kNT, bool SPLIT = false>
 __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
                                           f32x4 (&dlast)[kSdfMT][NT], int wave, int lane) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
+    constexpr float amp = SPLIT ? kActScale : 1.0f;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     // layer 1: K = 3 on the vector ALU, same accumulator ownership as the MFMA layers
     {
         f32x4 x[NT];
@@ -187,16 +301,18 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             f32x4 w[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + ch0);
-            const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + ch0);
-            const f32x4 p = *reinterpret_cast<const f32x4*>(net.phase + ch0);
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+            const f32x4 f = GRAD ? *reinterpret_cast<const f32x4*>(net.freq + ch0) : zero4;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 f32x4 v, h, d;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = w[r][0] * x[n][0] + w[r][1] * x[n][1] + w[r][2] * x[n][2];
-                film_sine(v, b, f, p, h, d, GRAD);
-                *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+                for (int r = 0; r < 4; ++r)   // explicit chain: every instantiation must round identically
+                    v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
+                film_sine<GRAD>(v, fw, pw, f, amp, h, d);
+                if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
+                else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
                 if (GRAD) spill[((0 * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
             }
         }
@@ -209,19 +325,21 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
+        if (SPLIT) gemm_acc_split<8, kSdfMT, NT>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+        else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
         __syncthreads();   // everyone is done reading the layer input
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
-            const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 256 + ch0);
-            const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0);
-            const f32x4 p = *reinterpret_cast<const f32x4*>(net.phase + k * 256 + ch0);
+            const f32x4 fw = *reinterpret_cast<const f32x4*>((SPLIT ? net.fws : net.fw) + k * 256 + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+            const f32x4 f = GRAD ? *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0) : zero4;
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 f32x4 h, d;
-                film_sine(acc[m][n], b, f, p, h, d, GRAD);
-                *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+                film_sine<GRAD>(acc[m][n], fw, pw, f, amp, h, d);
+                if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
+                else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
                 if (GRAD) {
                     if (k < 5) spill[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
                     else dlast[m][n] = d;
@@ -232,21 +350,39 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
     }
 }
 
+// split planes -> fp32 in place for the first n_pts rows (through registers: the fp32 row overlays both planes)
+__device__ __forceinline__ void unsplit_rows(float* act, int ld, int tid) {
+    float v[32];
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int e = tid + i * kThreads;
+        v[i] = load_split(act, ld, 512, e >> 8, e & 255);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const int e = tid + i * kThreads;
+        act[(e >> 8) * ld + (e & 255)] = v[i];
+    }
+}
+
 // sdf[pt] = w6 . h6[pt] + b6  -> out[pt*ostride]; 8 threads per point (the first 8*n_pts threads work).
+template <bool SPLIT = false>
 __device__ __forceinline__ void sdf_head(const SdfNet& net, const float* act, int ld, float* out, int ostride,
                                          int tid, int n_pts = kTile) {
-    const int pt = tid >> 3, part = tid & 7;
-    if (pt >= n_pts) return;   // whole waves drop out: 8 lanes per point, n_pts is a multiple of 8
-    float s = 0.f;
+    const int part = tid & 7;
+    for (int pt = tid >> 3; pt < n_pts; pt += kThreads / 8) {   // whole waves drop out: n_pts is a multiple of 8
+        float s = 0.f;
 #pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        const int ch = part + 8 * i;
-        s += net.w6[ch] * act[pt * ld + ch];
+        for (int i = 0; i < 32; ++i) {
+            const int ch = part + 8 * i;
+            s = fmaf(net.w6[ch], SPLIT ? load_split(act, ld, 512, pt, ch) : act[pt * ld + ch], s);
+        }
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (part == 0) out[pt * ostride] = s + net.b6[0];
     }
-    s += __shfl_xor(s, 1);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 4);
-    if (part == 0) out[pt * ostride] = s + net.b6[0];
 }
 
 // Reverse sweep for d sdf / d x on the tile (needs sdf_trunk<true> first).

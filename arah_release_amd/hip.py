@@ -15,6 +15,18 @@ LIB_PATH = os.path.join(_HERE, "libarah_hip.so")
 ARAH_MAX_STEPS = 128
 COLOR_NO_VIEW_DIR = 0
 COLOR_IDR = 1
+PRECISION_SPLIT_F16 = 0   # fp32 carried as hi + lo f16 pairs on the f16 matrix pipe (default)
+PRECISION_FP32 = 1        # v_mfma_f32_16x16x4_f32 everywhere
+
+
+def default_precision():
+    """ARAH_PRECISION=fp32 selects the exact engine for every GEMM; default is the split engine."""
+    v = os.environ.get("ARAH_PRECISION", "split").lower()
+    if v in ("split", "split_f16", "f16x3", "0"):
+        return PRECISION_SPLIT_F16
+    if v in ("fp32", "f32", "exact", "1"):
+        return PRECISION_FP32
+    raise ValueError("ARAH_PRECISION must be 'split' or 'fp32', got %r" % v)
 
 _ERRORS = {-1: "ARAH_E_BADARG", -2: "ARAH_E_SHAPE", -3: "ARAH_E_WORKSPACE", -4: "ARAH_E_LAUNCH",
            -5: "ARAH_E_SAMPLING"}
@@ -25,7 +37,8 @@ _fp = C.c_void_p  # device float*
 class ArahNets(C.Structure):
     _fields_ = [("sdf_w", _fp * 7), ("sdf_b", _fp * 7), ("film_freq", _fp), ("film_phase", _fp),
                 ("skin_w", _fp * 5), ("skin_b", _fp * 5), ("col_w", _fp * 6), ("col_b", _fp * 6),
-                ("pose_vec", _fp), ("col_mode", C.c_int32), ("n_pose", C.c_int32), ("beta", C.c_float)]
+                ("pose_vec", _fp), ("col_mode", C.c_int32), ("n_pose", C.c_int32), ("beta", C.c_float),
+                ("precision", C.c_int32)]
 
 
 class ArahBody(C.Structure):
@@ -43,6 +56,7 @@ class ArahSampling(C.Structure):
 class ArahFrame(C.Structure):
     _fields_ = [("sdf_w0", _fp), ("sdf_wp", _fp * 5), ("sdf_wpT", _fp * 5), ("sdf_w6", _fp), ("sdf_b6", _fp),
                 ("sdf_bias", _fp), ("sdf_freq", _fp), ("sdf_phase", _fp),
+                ("sdf_wps", _fp * 5), ("sdf_fw", _fp), ("sdf_pw", _fp), ("sdf_fws", _fp),
                 ("skin_w0", _fp), ("skin_wp", _fp * 3), ("skin_w4p", _fp), ("skin_bias", _fp),
                 ("col_w0p", _fp), ("col_w1p", _fp), ("col_w2p", _fp), ("col_w3ap", _fp), ("col_w3bp", _fp),
                 ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
@@ -50,7 +64,7 @@ class ArahFrame(C.Structure):
                 ("verts", _fp), ("vert_weights", _fp), ("bones", _fp),
                 ("beta", C.c_float), ("trans", C.c_float * 3), ("center", C.c_float * 3),
                 ("coord_min", C.c_float), ("coord_max", C.c_float), ("n_verts", C.c_int32),
-                ("col_mode", C.c_int32)]
+                ("col_mode", C.c_int32), ("precision", C.c_int32)]
 
 
 class ArahCounters(C.Structure):
@@ -140,7 +154,7 @@ class Frame:
     """Packed per-frame state on the device (MFMA-ordered weights, padded vertices)."""
 
     def __init__(self, sdf_layers, film_freq, film_phase, skin_layers, color_layers, color_mode, pose_vec, beta,
-                 verts, vert_weights, bones, trans, center, coord_min, coord_max):
+                 verts, vert_weights, bones, trans, center, coord_min, coord_max, precision=None):
         require_gpu()
         lib = load_library()
         dev = verts.device
@@ -184,6 +198,8 @@ class Frame:
         nets.col_mode = int(color_mode)
         nets.n_pose = n_pose
         nets.beta = float(beta)
+        nets.precision = default_precision() if precision is None else int(precision)
+        self.precision = nets.precision
         body = ArahBody()
         self.verts, self.vert_weights, self.bones = own(verts), own(vert_weights), own(bones.reshape(24, 16))
         body.verts, body.vert_weights, body.bones = _ptr(self.verts), _ptr(self.vert_weights), _ptr(self.bones)

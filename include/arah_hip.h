@@ -55,6 +55,13 @@ extern "C" {
 #define ARAH_COLOR_NO_VIEW_DIR 0 /* input [x, n, feat, pose]         (ZJUMOCAP-377-mono) */
 #define ARAH_COLOR_IDR 1         /* input [x, PE4(view), n, feat, pose] (ZJUMOCAP-313, H36M) */
 
+/* GEMM engine of the forward SDF trunks (every result stays fp32-class, see csrc/mlp.hpp):
+ *   SPLIT_F16: fp32 operands carried as hi + lo f16 pairs, three v_mfma_f32_16x16x32_f16 per product, fp32
+ *              accumulation (22 significant bits per operand; error vs fp64 at or below the exact engine's);
+ *   FP32     : v_mfma_f32_16x16x4_f32 everywhere (bit-for-bit an fmaf chain), 16/3 x the matrix-pipe time. */
+#define ARAH_PRECISION_SPLIT_F16 0
+#define ARAH_PRECISION_FP32 1
+
 /* Row-major, un-packed network weights as PyTorch holds them (weight-norm already folded:
  * W = g * v / |v|).  Shapes are the ones every ARAH config uses; arah_prepare_frame rejects
  * anything else with ARAH_E_SHAPE. */
@@ -74,6 +81,7 @@ typedef struct ArahNets {
     int32_t col_mode;           /* ARAH_COLOR_* */
     int32_t n_pose;             /* 128 for color_pose_encoder 'latent' */
     float beta;                 /* |variance|, un-clipped */
+    int32_t precision;          /* ARAH_PRECISION_* */
 } ArahNets;
 
 /* Per-frame body (lightning_model.py:581-632 keys smpl_verts, skinning_weights, bone_transforms,
@@ -113,6 +121,10 @@ typedef struct ArahFrame {
     const float* sdf_bias;      /* [6][256] */
     const float* sdf_freq;      /* [6][256] */
     const float* sdf_phase;     /* [6][256] */
+    const void* sdf_wps[5];     /* split-packed fwd: hi/lo f16 planes, pre-scaled by a power of two per layer */
+    const float* sdf_fw;        /* [6][256] 30 f / pi */
+    const float* sdf_pw;        /* [6][256] 30 (f b + phi) / pi */
+    const float* sdf_fws;       /* [6][256] fw divided by the split scales of the producing layer */
     const float* skin_w0;       /* [128][4] */
     const float* skin_wp[3];    /* packed 128x128 */
     const float* skin_w4p;      /* packed [32][128] */
@@ -138,6 +150,7 @@ typedef struct ArahFrame {
     float coord_min, coord_max;
     int32_t n_verts;
     int32_t col_mode;
+    int32_t precision;          /* ARAH_PRECISION_* the frame was prepared for */
 } ArahFrame;
 
 /* Work counters (points evaluated), SURVEY 8(d). */

@@ -1,0 +1,295 @@
+// Reproducibility of the product SDF trunk (mlp.hpp) under load: same inputs, repeated launches, bitwise compare.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#include "../../arah_release_amd/csrc/mlp.hpp"
+using namespace arah;
+
+template <bool SPLIT>
+__global__ __launch_bounds__(kThreads, 4) void k_trunk(SdfNet net, const float* __restrict__ x, int n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;
+    float* outv = xin + 64 * 4;
+    float* act = outv + 64 * 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+        if (tid < kTile) {
+            const int i = tile * kTile + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = v;
+        }
+        __syncthreads();
+        f32x4 dlast[kSdfMT][kNT];
+        sdf_trunk<false, kNT, SPLIT>(net, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<SPLIT>(net, act, kSdfLd, outv, 4, tid);
+        __syncthreads();
+        if (tid < kTile && tile * kTile + tid < n) out[tile * kTile + tid] = outv[tid * 4];
+        __syncthreads();
+    }
+}
+
+__global__ void k_pack32(float* __restrict__ dst, const float* __restrict__ src) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 16 * 16 * 64) return;
+    const int lane = idx & 63, tile = idx >> 6, kc = tile % 16, mt = tile / 16;
+    f32x4 v;
+    for (int t = 0; t < 4; ++t) v[t] = src[(mt * 16 + (lane & 15)) * 256 + kc * 16 + 4 * (lane >> 4) + t];
+    reinterpret_cast<f32x4*>(dst)[idx] = v;
+}
+__global__ void k_packs(f16x8* __restrict__ dst, const float* __restrict__ src, float wscale) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 16 * 8 * 64) return;
+    const int lane = idx & 63, kc = (idx >> 6) & 7, mt = idx >> 9;
+    f16x8 hi, lo;
+    for (int e = 0; e < 8; ++e) {
+        const float w = src[(mt * 16 + (lane & 15)) * 256 + kc * 32 + (lane >> 4) * 8 + e] * wscale;
+        hi[e] = (_Float16)w;
+        lo[e] = (_Float16)(w - (float)hi[e]);
+    }
+    dst[((mt * 8 + kc) * 2 + 0) * 64 + lane] = hi;
+    dst[((mt * 8 + kc) * 2 + 1) * 64 + lane] = lo;
+}
+
+// local copy of the split trunk with bisection switches
+//   1: layer 1 activations = cheap function of x (no FiLM sine)      2: skip FiLM sine in the MFMA layers
+//   4: head reads one channel only                                   8: no MFMA loop (acc = small constant)
+template <int FL>
+__device__ __forceinline__ void trunk_dbg(const SdfNet& net, const float* xin, float* act, int ld, int wave, int lane) {
+    constexpr int NT = kNT;
+    const int j = lane & 15, g = lane >> 4;
+    const int mt0 = wave * kSdfMT;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 x[NT];
+        for (int n = 0; n < NT; ++n) x[n] = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            f32x4 w[4];
+            for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+            for (int n = 0; n < NT; ++n) {
+                f32x4 v, h, d;
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
+                if (FL & 1) {
+                    for (int r = 0; r < 4; ++r) h[r] = fminf(fmaxf(v[r] * 3.0f, -1.0f), 1.0f) * kActScale;
+                }
+                else film_sine<false>(v, fw, pw, zero4, kActScale, h, d);
+                store_split4(act, ld, 512, n * 16 + j, ch0, h);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 1; k < 6; ++k) {
+        f32x4 acc[kSdfMT][NT];
+        for (int m = 0; m < kSdfMT; ++m)
+            for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
+        if (FL & 8) {
+            for (int m = 0; m < kSdfMT; ++m)
+                for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{1.f, 2.f, 3.f, 4.f} * (float)(k + m + n + j);
+        } else {
+            gemm_acc_split<8, kSdfMT, NT>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+        }
+        __syncthreads();
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fws + k * 256 + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+            for (int n = 0; n < NT; ++n) {
+                f32x4 h, d;
+                if (FL & 2) {
+                    for (int r = 0; r < 4; ++r) h[r] = fminf(fmaxf(acc[m][n][r] * fw[r] * 3.0f, -1.0f), 1.0f) * kActScale;
+                }
+                else film_sine<false>(acc[m][n], fw, pw, zero4, kActScale, h, d);
+                store_split4(act, ld, 512, n * 16 + j, ch0, h);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int FL>
+__global__ __launch_bounds__(kThreads, 4) void k_trunk_dbg(SdfNet net, const float* __restrict__ x, int n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* act = (FL & 16) ? smem : smem + 64 * 8;
+    float* xin = (FL & 16) ? smem + 64 * kSdfLd : smem;
+    float* outv = xin + 64 * 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+        if (tid < kTile) {
+            const int i = tile * kTile + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = v;
+        }
+        __syncthreads();
+        trunk_dbg<FL>(net, xin, act, kSdfLd, wave, lane);
+        if (FL & 4) {
+            if (tid < kTile) outv[tid * 4] = load_split(act, kSdfLd, 512, tid, 7);
+        } else {
+            sdf_head<true>(net, act, kSdfLd, outv, 4, tid);
+        }
+        __syncthreads();
+        if (tid < kTile && tile * kTile + tid < n) out[tile * kTile + tid] = outv[tid * 4];
+        __syncthreads();
+    }
+}
+
+template <int FL>
+void run_dbg(const char* name, SdfNet net, const float* dX, int n, float* dO, size_t lds) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_dbg<FL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<float> r0(n), r1(n);
+    auto launch = [&] { k_trunk_dbg<FL><<<512, kThreads, lds>>>(net, dX, n, dO); };
+    launch(); hipDeviceSynchronize();
+    hipMemcpy(r0.data(), dO, n * 4, hipMemcpyDeviceToHost);
+    size_t worst = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+        launch(); hipDeviceSynchronize();
+        hipMemcpy(r1.data(), dO, n * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (int i = 0; i < n; ++i) bad += memcmp(&r0[i], &r1[i], 4) != 0;
+        worst = bad > worst ? bad : worst;
+        if (FL == 4 && bad) {
+            // are the wrong values some OTHER point's right value (stale or foreign LDS rows)?
+            std::vector<float> sorted(r0);
+            std::sort(sorted.begin(), sorted.end());
+            size_t found = 0;
+            for (int i = 0; i < n; ++i)
+                if (memcmp(&r0[i], &r1[i], 4) && std::binary_search(sorted.begin(), sorted.end(), r1[i])) ++found;
+            printf("  rep %d: %zu wrong values, %zu of them equal some other point's reference value\n", rep, bad, found);
+        }
+        if (FL == 0 && rep == 0) {
+            int shown = 0, last_tile = -1, tiles = 0;
+            for (int i = 0; i < n; ++i)
+                if (memcmp(&r0[i], &r1[i], 4)) {
+                    if (i / 64 != last_tile) { ++tiles; last_tile = i / 64; }
+                    if (shown++ < 48) printf("  idx %d (tile %d, pt %d): %.6f vs %.6f\n", i, i / 64, i % 64, r0[i], r1[i]);
+                }
+            printf("  %zu mismatches in %d tiles\n", bad, tiles);
+        }
+    }
+    printf("dbg flags %2d (%s): worst rerun differs in %zu of %d\n", FL, name, worst, n);
+}
+
+// product split trunk on 16*NT-point tiles; lds_pad forces one workgroup per CU
+template <int NT>
+__global__ __launch_bounds__(kThreads) void k_trunk_nt(SdfNet net, const float* __restrict__ x, int n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int TW = 16 * NT;
+    float* xin = smem;
+    float* outv = xin + TW * 4;
+    float* act = outv + TW * 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
+        if (tid < TW) {
+            const int i = tile * TW + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = v;
+        }
+        __syncthreads();
+        f32x4 dlast[kSdfMT][NT];
+        sdf_trunk<false, NT, true>(net, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<true>(net, act, kSdfLd, outv, 4, tid, TW);
+        __syncthreads();
+        if (tid < TW && tile * TW + tid < n) out[tile * TW + tid] = outv[tid * 4];
+        __syncthreads();
+    }
+}
+
+template <int NT>
+void run_nt(const char* name, SdfNet net, const float* dX, int n, float* dO, size_t lds, int grid, const std::vector<float>& ref) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_nt<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<float> r0(n), r1(n);
+    auto launch = [&] { k_trunk_nt<NT><<<grid, kThreads, lds>>>(net, dX, n, dO); };
+    launch(); hipDeviceSynchronize();
+    hipMemcpy(r0.data(), dO, n * 4, hipMemcpyDeviceToHost);
+    size_t worst = 0, vs_ref = 0;
+    for (int i = 0; i < n; ++i) vs_ref += memcmp(&r0[i], &ref[i], 4) != 0;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float ms = 0;
+    for (int rep = 0; rep < 4; ++rep) {
+        hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        hipMemcpy(r1.data(), dO, n * 4, hipMemcpyDeviceToHost);
+        size_t bad = 0;
+        for (int i = 0; i < n; ++i) bad += memcmp(&r0[i], &r1[i], 4) != 0;
+        worst = bad > worst ? bad : worst;
+    }
+    printf("%-44s grid %3d: %.3f ms (%.0f TF algorithmic), worst rerun differs in %zu, differs from 1-WG/CU reference in %zu\n", name, grid, ms,
+           (double)n * 657408 / ms / 1e9, worst, vs_ref);
+}
+
+int main(int argc, char** argv) {
+    const int n = 400000;
+    unsigned s = 777;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) / 8388608.0f - 1.0f; };
+    std::vector<float> W(5 * 65536), w0(256 * 4), w6(256), cst(6 * 256), X(n * 3);
+    const float wmax = sqrtf(6.0f / 256.0f) / 30.0f * 2.0f;
+    for (auto& v : W) v = rnd() * wmax;
+    for (auto& v : w0) v = rnd() * 0.3f;
+    for (auto& v : w6) v = rnd() * 0.05f;
+    for (auto& v : X) v = rnd();
+    auto dev = [&](const std::vector<float>& h) { float* d; hipMalloc(&d, h.size() * 4); hipMemcpy(d, h.data(), h.size() * 4, hipMemcpyHostToDevice); return d; };
+    float *dW = dev(W), *dX = dev(X);
+    SdfNet net;
+    net.w0 = dev(w0);
+    net.w6 = dev(w6);
+    std::vector<float> fw(6 * 256), pw(6 * 256), fws(6 * 256), fr(6 * 256, 1.0f), b6(4, 0.01f);
+    const float c = 30.0f / 3.14159265f, wscale = exp2f(14.0f - ceilf(log2f(wmax)));
+    for (int i = 0; i < 6 * 256; ++i) { fw[i] = c; pw[i] = rnd() * 0.02f * c; fws[i] = i < 256 ? c : c / (wscale * kActScale); }
+    net.fw = dev(fw); net.pw = dev(pw); net.fws = dev(fws); net.freq = dev(fr); net.phase = net.freq; net.bias = net.freq; net.b6 = dev(b6);
+    float* p32; f16x8* ps;
+    hipMalloc(&p32, W.size() * 4); hipMalloc(&ps, W.size() * 4);
+    for (int l = 0; l < 5; ++l) {
+        k_pack32<<<64, 256>>>(p32 + (size_t)l * 65536, dW + (size_t)l * 65536);
+        k_packs<<<32, 256>>>(ps + (size_t)l * 16 * 8 * 2 * 64, dW + (size_t)l * 65536, wscale);
+        net.wp[l] = p32 + (size_t)l * 65536; net.wpT[l] = net.wp[l]; net.wps[l] = ps + (size_t)l * 16 * 8 * 2 * 64;
+    }
+    float* dO; hipMalloc(&dO, n * 4);
+    const size_t lds = (64 * 4 * 2) * 4 + (size_t)64 * kSdfLd * 4;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    std::vector<float> r0(n), r1(n);
+    for (int grid : {256, 512}) {
+        for (int split = 0; split < 2; ++split) {
+            auto launch = [&] { if (split) k_trunk<true><<<grid, kThreads, lds>>>(net, dX, n, dO); else k_trunk<false><<<grid, kThreads, lds>>>(net, dX, n, dO); };
+            launch(); hipDeviceSynchronize();
+            hipMemcpy(r0.data(), dO, n * 4, hipMemcpyDeviceToHost);
+            size_t worst = 0; float md = 0;
+            for (int rep = 0; rep < 4; ++rep) {
+                launch(); hipDeviceSynchronize();
+                hipMemcpy(r1.data(), dO, n * 4, hipMemcpyDeviceToHost);
+                size_t bad = 0;
+                for (int i = 0; i < n; ++i) if (memcmp(&r0[i], &r1[i], 4)) { ++bad; md = fmaxf(md, fabsf(r0[i] - r1[i])); }
+                worst = bad > worst ? bad : worst;
+            }
+            printf("grid %3d  %-6s trunk: worst rerun differs in %zu of %d (max |diff| %.3g)  sample out %.6f\n", grid, split ? "split" : "exact", worst, n, md, r0[12345]);
+        }
+    }
+    run_dbg<0>("copy of product trunk", net, dX, n, dO, lds);
+    {
+        std::vector<float> ref(n);
+        k_trunk<true><<<256, kThreads, lds>>>(net, dX, n, dO);
+        hipDeviceSynchronize();
+        hipMemcpy(ref.data(), dO, n * 4, hipMemcpyDeviceToHost);
+        const size_t l4 = (64 * 4 * 2) * 4 + (size_t)64 * kSdfLd * 4, l8 = (128 * 4 * 2) * 4 + (size_t)128 * kSdfLd * 4;
+        run_nt<4>("64-pt tiles, 2 WG/CU", net, dX, n, dO, l4, 512, ref);
+        run_nt<4>("64-pt tiles, LDS padded to 1 WG/CU", net, dX, n, dO, 90 * 1024, 512, ref);
+        run_nt<4>("64-pt tiles, LDS padded to 1 WG/CU", net, dX, n, dO, 90 * 1024, 256, ref);
+        run_nt<8>("128-pt tiles (1 WG/CU)", net, dX, n, dO, l8, 256, ref);
+        run_nt<8>("128-pt tiles (1 WG/CU)", net, dX, n, dO, l8, 512, ref);
+    }
+    run_dbg<4>("one-channel head", net, dX, n, dO, lds);
+    run_dbg<1>("clamp instead of sine in layer 1", net, dX, n, dO, lds);
+    run_dbg<2>("clamp instead of sine in MFMA layers", net, dX, n, dO, lds);
+    run_dbg<3>("clamp everywhere", net, dX, n, dO, lds);
+    run_dbg<7>("clamp everywhere, 1-channel head", net, dX, n, dO, lds);
+    run_dbg<0>("copy of product trunk", net, dX, n, dO, lds);
+    return 0;
+}
