@@ -77,6 +77,8 @@ FrameDev to_dev(const ArahFrame& f) {
     for (int i = 0; i < 3; ++i) d.skin.wp[i] = f.skin_wp[i];
     d.skin.w4p = f.skin_w4p;
     d.skin.bias = f.skin_bias;
+    for (int i = 0; i < 4; ++i) d.skin.wps[i] = reinterpret_cast<const f16x8*>(f.skin_wps[i]);
+    d.skin.scales = f.skin_scales;
     d.col.w0p = f.col_w0p;
     d.col.w1p = f.col_w1p;
     d.col.w2p = f.col_w2p;
@@ -166,8 +168,8 @@ __device__ __forceinline__ float split_weight_scale(unsigned amax_bits) {
 
 // split-engine A operand of one 256x256 layer: dst[((mt*8 + kc)*2 + s)*64 + lane] holds 8 halves (s = 0 hi, 1 lo)
 // of scale * src[mt*16 + (lane&15)][kc*32 + 8 (lane>>4) .. +7]
-__global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ src, int ld, int m_tiles, int KC32,
-                             const unsigned* amax) {
+__global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ src, int M, int ld, int m_tiles,
+                             int KC32, const unsigned* amax) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= m_tiles * KC32 * 64) return;
     const float scale = split_weight_scale(*amax);
@@ -176,7 +178,7 @@ __global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ 
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float w = src[(size_t)row * ld + kc * 32 + (lane >> 4) * 8 + e] * scale;
+        const float w = row < M ? src[(size_t)row * ld + kc * 32 + (lane >> 4) * 8 + e] * scale : 0.f;
         const _Float16 h = (_Float16)w;
         hi[e] = h;
         lo[e] = (_Float16)(w - (float)h);
@@ -198,6 +200,55 @@ __global__ void k_fold_film(const float* __restrict__ freq, const float* __restr
     pw[i] = (float)((f * (double)bias[i] + (double)phase[i]) * c);
     const float inv = k == 0 ? 1.0f : 1.0f / (split_weight_scale(amax[k - 1]) * kActScale);
     fws[i] = (float)(f * c) * inv;
+}
+
+// Largest hidden activation of the skinning MLP (Softplus: h >= 0) per layer over a 17^3 lattice of the normalised
+// cube [-1.5, 1.5]^3 -- query points are normalised to [-1, 1] over the padded body box (RFU:37-51), root-finding
+// iterates stray a little beyond.  One thread per lattice point, plain fp32 loops over the raw row-major weights.
+struct SkinRaw {
+    const float* w[4];   // [128,3], 3 x [128,128]
+    const float* b[4];
+};
+__global__ __launch_bounds__(128) void k_skin_probe(SkinRaw net, unsigned* amax) {
+    __shared__ float h[2][128];
+    const int pt = blockIdx.x, c = threadIdx.x;
+    const float x = -1.5f + 3.0f * (float)(pt % 17) / 16.0f, y = -1.5f + 3.0f * (float)((pt / 17) % 17) / 16.0f,
+                z = -1.5f + 3.0f * (float)(pt / 289) / 16.0f;
+    float v = softplus100(net.w[0][c * 3] * x + net.w[0][c * 3 + 1] * y + net.w[0][c * 3 + 2] * z + net.b[0][c]);
+    h[0][c] = v;
+    float m = v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((c & 63) == 0) atomicMax(amax + 0, __float_as_uint(m));
+    __syncthreads();
+    for (int k = 1; k < 4; ++k) {
+        const float* hin = h[(k - 1) & 1];
+        float s = net.b[k][c];
+        for (int i = 0; i < 128; ++i) s += net.w[k][c * 128 + i] * hin[i];
+        v = softplus100(s);
+        h[k & 1][c] = v;
+        m = v == v ? v : 0.f;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        if ((c & 63) == 0) atomicMax(amax + k, __float_as_uint(m));
+        __syncthreads();
+    }
+}
+
+// scales[0..3]: S_k = power of two with S_k * probed max in [2^10, 2^11) (32x headroom below the f16 limit);
+// scales[4..7]: 1 / (weight scale of layer k+1 * S_k).  amax[0..3] probed activations, amax[4..7] |W| of layers 1..4.
+__global__ void k_skin_scales(const unsigned* amax, float* scales) {
+    const int k = threadIdx.x;
+    if (k >= 4) return;
+    const float a = __uint_as_float(amax[k]);
+    float S = 1.0f;
+    if (a > 0.f && a < 3.0e38f) {
+        int e;
+        frexpf(a, &e);
+        S = ldexpf(1.0f, 11 - e);
+    }
+    scales[k] = S;
+    scales[4 + k] = 1.0f / (split_weight_scale(amax[4 + k]) * S);
 }
 
 // dst[r][0..3] = {src[r][0..ncol-1], 0...}
@@ -1139,130 +1190,161 @@ __device__ __forceinline__ void canon_flush(const CanonOut& o, int id, const f32
     o.err[id] = eb;
 }
 
-template <bool FIRST, int NT>
-__device__ __forceinline__ void canon_tiles(const FrameDev& fr, const CanonRec* __restrict__ rin,
-                                            CanonRec* __restrict__ rout, int n, int* next_count, const TargetSrc& ts,
-                                            const CanonOut& outp, unsigned long long* ctr, float* smem) {
+constexpr int kLogitOut = 28;   // floats per point in the logit stream (25 valid; 7 x 16 bytes)
+
+// Pass 1 of an iteration -- the matrix-core part: skinning-MLP logits of every live record, in list order.
+template <int NT, bool SPLIT>
+__device__ __forceinline__ void canon_mlp_tiles(const FrameDev& fr, const CanonRec* __restrict__ rin, int n,
+                                                float* __restrict__ lg, unsigned long long* ctr, float* smem) {
     constexpr int TW = 16 * NT;
     float* xin = smem;                        // [64][4] normalised
-    float* xraw = xin + 64 * 4;               // [64][4] raw x + id
-    float* sbones = xraw + 64 * 4;            // [24][16]
-    float* logits = sbones + 24 * 16 + 64;    // [64][33]
-    float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer
+    float* logits = xin + 64 * 4;             // [64][33]
+    float* act = logits + 64 * kLogitLd;      // 64*33 floats is a multiple of 4: stays 16-byte aligned
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
         if (tid < TW) {
             const int i = tile * TW + tid;
-            f32x4 r0 = {0.f, 0.f, 0.f, __int_as_float(-1)};
+            f32x4 r0 = {0.f, 0.f, 0.f, 0.f};
             if (i < n) r0 = rin[i].r[0];
             const V3 q = normalize_pt(fr.bc, V3{r0[0], r0[1], r0[2]});
             reinterpret_cast<f32x4*>(xin)[tid] = f32x4{q.x, q.y, q.z, 0.f};
-            reinterpret_cast<f32x4*>(xraw)[tid] = r0;
         }
         __syncthreads();
-        skin_mlp<NT>(fr.skin, xin, act, logits, wave, lane);
+        skin_mlp<NT, SPLIT>(fr.skin, xin, act, logits, wave, lane);
         if (tid == 0) count_add(ctr, min(TW, n - tile * TW));
-        if (tid < 64) {   // whole wave 0 takes part in the ballot; lanes >= TW carry no point
-            const int i = tile * TW + tid;
-            const f32x4 r0 = tid < TW ? reinterpret_cast<const f32x4*>(xraw)[tid] : f32x4{0.f, 0.f, 0.f, __int_as_float(-1)};
-            const int id = __float_as_int(r0[3]);
-            const V3 x = V3{r0[0], r0[1], r0[2]};
-            bool keep = false, improved = false;
-            float T[16], gx[3], dg[3], dx[3], eb = 0.f;
-            if (id >= 0) {
-                f32x4 r1, r2;
-                if (!FIRST) {   // issued before the softmax/blend below, consumed after it
-                    r1 = rin[i].r[1];
-                    r2 = rin[i].r[2];
-                }
-                V3 xbar;
-                skin_tail(logits + tid * kLogitLd, sbones, x, T, xbar);
-                const V3 tg = target_of(ts, fr.bc, id);
-                const float gnew[3] = {xbar.x - tg.x, xbar.y - tg.y, xbar.z - tg.z};
-                if (FIRST) {
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
-                    eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                    keep = true;                                        // every point takes at least one step
-                } else {
-                    eb = r1[3];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        dx[r] = r1[r];
-                        dg[r] = gnew[r] - r2[r];
-                        gx[r] = r2[r] + dg[r];                          // broyden.py:50-51
-                    }
-                    const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                    improved = err < eb;                                // broyden.py:54-61
-                    if (improved) eb = err;
-                    keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
-                }
-            }
-            // survivors get their slot in the output stream now, so that the record can be written
-            // piece by piece (short register live ranges)
-            const unsigned long long m = __ballot(keep);
-            int base = 0;
-            if (lane == 0 && m) base = atomicAdd(next_count, __popcll(m));
-            base = __shfl(base, 0);
-            CanonRec* dst = rout + base + __popcll(m & ((1ull << lane) - 1ull));
-            if (id >= 0) {
-                // best iterate: the new one if it improved, else carried over (FIRST: x0 and the
-                // nearest-vertex T0, broyden.py:41); retiring points hand it in
-                f32x4 xb, Tb[4];
-                if (improved) {
-                    xb = f32x4{x.x, x.y, x.z, 0.f};
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) Tb[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
-                } else {
-                    xb = rin[i].r[5];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) Tb[c] = rin[i].r[6 + c];
-                }
-                if (keep) {
-                    dst->r[5] = xb;
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) dst->r[6 + c] = Tb[c];
-                } else {
-                    canon_flush(outp, id, xb, Tb, eb);
-                }
-            }
-            if (keep) {
-                float J[9], stp[3];
-                if (FIRST) {
-                    inv3_of44(T, J);                                    // RFU:327-328
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
-                } else {
-                    const f32x4 r2 = rin[i].r[2], r3 = rin[i].r[3], r4 = rin[i].r[4];
-                    J[0] = r2[3];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        J[1 + e] = r3[e];
-                        J[5 + e] = r4[e];
-                    }
-                    broyden_update<3>(J, dx, dg, gx, stp);
-                }
-                dst->r[0] = f32x4{x.x + stp[0], x.y + stp[1], x.z + stp[2], r0[3]};
-                dst->r[1] = f32x4{stp[0], stp[1], stp[2], eb};
-                dst->r[2] = f32x4{gx[0], gx[1], gx[2], J[0]};
-                dst->r[3] = f32x4{J[1], J[2], J[3], J[4]};
-                dst->r[4] = f32x4{J[5], J[6], J[7], J[8]};
-            }
-        }
+        const int cnt = min(TW, n - tile * TW) * kLogitOut;
+        float* dst = lg + (size_t)tile * TW * kLogitOut;
+        for (int e = tid; e < cnt; e += kThreads) dst[e] = logits[(e / kLogitOut) * kLogitLd + e % kLogitOut];
         __syncthreads();
     }
 }
 
-template <bool FIRST>
-__global__ __launch_bounds__(kThreads, 4) void k_canon_iter(FrameDev fr, const CanonRec* __restrict__ rin,
-                                                             CanonRec* __restrict__ rout, const int* count,
-                                                             int* next_count, TargetSrc ts, CanonOut outp,
-                                                             unsigned long long* ctr) {
+template <bool SPLIT>
+__global__ __launch_bounds__(kThreads, SPLIT ? 2 : 4) void k_canon_mlp(FrameDev fr, const CanonRec* __restrict__ rin,
+                                                                       const int* count, float* __restrict__ lg,
+                                                                       unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *count;
-    if (n < kNarrowBelow) canon_tiles<FIRST, 1>(fr, rin, rout, n, next_count, ts, outp, ctr, smem);
-    else canon_tiles<FIRST, kNT>(fr, rin, rout, n, next_count, ts, outp, ctr, smem);
+    if (n < kNarrowBelow) canon_mlp_tiles<1, SPLIT>(fr, rin, n, lg, ctr, smem);
+    else canon_mlp_tiles<kNT, SPLIT>(fr, rin, n, lg, ctr, smem);
+}
+
+// Pass 2 -- one thread per record, at full occupancy: weights, blended transform, residual, Broyden bookkeeping,
+// and the ballot-compacted stream of survivors (broyden.py:41-75).  The per-point code is latency-bound
+// (sequential softmax tree, 24-joint blend, dependent record reads); run by one wave per 64-point MFMA tile it
+// kept the matrix pipe idle for a third of loop C.
+constexpr int kUpdThreads = 256;
+template <bool FIRST>
+__global__ __launch_bounds__(kUpdThreads) void k_canon_update(FrameDev fr, const CanonRec* __restrict__ rin,
+                                                              CanonRec* __restrict__ rout,
+                                                              const float* __restrict__ lg, const int* count,
+                                                              int* next_count, TargetSrc ts, CanonOut outp) {
+    __shared__ float sbones[24 * 16];
+    __shared__ float srow[kUpdThreads * kLogitLd];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 24 * 16; i += kUpdThreads) sbones[i] = fr.bones[i];
+    __syncthreads();
+    const int n = *count;
+    float* row = srow + tid * kLogitLd;
+    for (int base_i = blockIdx.x * kUpdThreads; base_i < n; base_i += gridDim.x * kUpdThreads) {   // wave-uniform trip count
+        const int i = base_i + tid;
+        const bool live = i < n;
+        f32x4 r0 = {0.f, 0.f, 0.f, __int_as_float(-1)};
+        if (live) {
+            r0 = rin[i].r[0];
+            const f32x4* src = reinterpret_cast<const f32x4*>(lg + (size_t)i * kLogitOut);
+#pragma unroll
+            for (int c = 0; c < kLogitOut / 4; ++c) {
+                const f32x4 v = src[c];
+                row[c * 4] = v[0];
+                row[c * 4 + 1] = v[1];
+                row[c * 4 + 2] = v[2];
+                row[c * 4 + 3] = v[3];
+            }
+        }
+        const int id = live ? __float_as_int(r0[3]) : -1;
+        const V3 x = V3{r0[0], r0[1], r0[2]};
+        bool keep = false, improved = false;
+        float T[16], gx[3], dg[3], dx[3], eb = 0.f;
+        if (id >= 0) {
+            f32x4 r1, r2;
+            if (!FIRST) {
+                r1 = rin[i].r[1];
+                r2 = rin[i].r[2];
+            }
+            V3 xbar;
+            skin_tail(row, sbones, x, T, xbar);
+            const V3 tg = target_of(ts, fr.bc, id);
+            const float gnew[3] = {xbar.x - tg.x, xbar.y - tg.y, xbar.z - tg.z};
+            if (FIRST) {
+#pragma unroll
+                for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
+                eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                keep = true;                                        // every point takes at least one step
+            } else {
+                eb = r1[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    dx[r] = r1[r];
+                    dg[r] = gnew[r] - r2[r];
+                    gx[r] = r2[r] + dg[r];                          // broyden.py:50-51
+                }
+                const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                improved = err < eb;                                // broyden.py:54-61
+                if (improved) eb = err;
+                keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
+            }
+        }
+        // survivors get their slot in the output stream now, so that the record can be written piece by piece
+        const unsigned long long m = __ballot(keep);
+        int base = 0;
+        if (lane == 0 && m) base = atomicAdd(next_count, __popcll(m));
+        base = __shfl(base, 0);
+        CanonRec* dst = rout + base + __popcll(m & ((1ull << lane) - 1ull));
+        if (id >= 0) {
+            // best iterate: the new one if it improved, else carried over (FIRST: x0 and the nearest-vertex T0,
+            // broyden.py:41); retiring points hand it in
+            f32x4 xb, Tb[4];
+            if (improved) {
+                xb = f32x4{x.x, x.y, x.z, 0.f};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Tb[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
+            } else {
+                xb = rin[i].r[5];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Tb[c] = rin[i].r[6 + c];
+            }
+            if (keep) {
+                dst->r[5] = xb;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) dst->r[6 + c] = Tb[c];
+            } else {
+                canon_flush(outp, id, xb, Tb, eb);
+            }
+        }
+        if (keep) {
+            float J[9], stp[3];
+            if (FIRST) {
+                inv3_of44(T, J);                                    // RFU:327-328
+#pragma unroll
+                for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
+            } else {
+                const f32x4 r2 = rin[i].r[2], r3 = rin[i].r[3], r4 = rin[i].r[4];
+                J[0] = r2[3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    J[1 + e] = r3[e];
+                    J[5 + e] = r4[e];
+                }
+                broyden_update<3>(J, dx, dg, gx, stp);
+            }
+            dst->r[0] = f32x4{x.x + stp[0], x.y + stp[1], x.z + stp[2], r0[3]};
+            dst->r[1] = f32x4{stp[0], stp[1], stp[2], eb};
+            dst->r[2] = f32x4{gx[0], gx[1], gx[2], J[0]};
+            dst->r[3] = f32x4{J[1], J[2], J[3], J[4]};
+            dst->r[4] = f32x4{J[5], J[6], J[7], J[8]};
+        }
+    }
 }
 
 // records still alive after the last iteration hand in their best iterate
@@ -1657,18 +1739,19 @@ template <bool SPLIT>
 __global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
                                                        f32x4* shaded, int* next_list, int* next_count,
                                                        unsigned long long* ctr_fwd) {
+    constexpr int TW = kTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xin = smem;
-    float* outv = xin + 64 * 4;
-    int* ids = reinterpret_cast<int*>(outv + 64 * 4);
-    float* actA = reinterpret_cast<float*>(ids + 64);
+    float* xin = smem;                                   // [TW][4]
+    float* outv = xin + TW * 4;                          // [TW][4]
+    int* ids = reinterpret_cast<int*>(outv + TW * 4);    // [TW]
+    float* actA = reinterpret_cast<float*>(ids + TW);    // [64][260]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = *count;
     const float scale = sdf_scale(fr.bc);
     const float inv_beta = 1.0f / fminf(fmaxf(fabsf(fr.beta), 1e-6f), 1e6f);
-    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
-        if (tid < kTile) {
-            const int i = tile * kTile + tid;
+    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
+        if (tid < TW) {
+            const int i = tile * TW + tid;
             const int id = i < n ? list[i] : -1;
             ids[tid] = id;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
@@ -1680,8 +1763,8 @@ __global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* 
         sdf_trunk<false, kNT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
         sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid);
         __syncthreads();
-        if (tid == 0) count_add(ctr_fwd, min(kTile, n - tile * kTile));
-        if (tid < kTile) {
+        if (tid == 0) count_add(ctr_fwd, min(TW, n - tile * TW));
+        if (tid < TW) {   // whole waves: TW is a multiple of 64
             const int id = ids[tid];
             bool keep = false;
             if (id >= 0) {
@@ -1965,6 +2048,7 @@ struct Workspace {
     // per sample
     float* q_err;
     CanonRec *recA, *recB;
+    float* logit;         // [Q][kLogitOut] logit stream between the two passes of a loop-C iteration
     float *o_z, *o_pts, *o_T;
     uint8_t* o_mask;
     uint8_t* q_smask;
@@ -2008,6 +2092,7 @@ Workspace carve(void* base, int n_rays, int n_steps) {
     w.q_err = c.take<float>(Q);
     w.recA = c.take<CanonRec>(Q);
     w.recB = c.take<CanonRec>(Q);
+    w.logit = c.take<float>(Q * kLogitOut);
     w.o_z = c.take<float>(Q);
     w.o_pts = c.take<float>(Q * 3);
     w.o_T = c.take<float>(Q * 16);
@@ -2035,6 +2120,7 @@ inline int check_launch() { return hipGetLastError() == hipSuccess ? ARAH_OK : A
 // dynamic LDS sizes (bytes)
 constexpr size_t kLdsSdfFwd = (64 * 4 * 2 + 64) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsSdfGrad = kLdsSdfFwd + (size_t)64 * kSdfLd * 4;
+constexpr size_t kLdsCanonMlp = (64 * 4 + 64 * kLogitLd) * 4 + (size_t)64 * kSkinLd * 4;
 constexpr size_t kLdsSkin = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSkinLd * 4;
 constexpr size_t kLdsJoint = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsKnn = ((size_t)kMaxClusters * kClusterLds * 4 + kMaxClusters * 4 + 24 * 16) * 4;
@@ -2083,8 +2169,8 @@ void setup_attributes() {
     allow_lds(k_density<true>, kLdsSplitSolo);
     allow_lds(k_skin_eval, kLdsSkin);
     allow_lds(k_skin_jac, kLdsSkin);
-    allow_lds(k_canon_iter<true>, kLdsSkin);
-    allow_lds(k_canon_iter<false>, kLdsSkin);
+    allow_lds(k_canon_mlp<false>, kLdsCanonMlp);
+    allow_lds(k_canon_mlp<true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<true, false>, kLdsJoint);
     allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<false, false>, kLdsJoint);
@@ -2116,7 +2202,7 @@ RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
 struct FrameLayout {
     size_t sdf_w0, sdf_wp[5], sdf_wpT[5], sdf_w6, sdf_b6, sdf_bias, sdf_freq, sdf_phase;
     size_t sdf_wps[5], sdf_fw, sdf_pw, sdf_fws, sdf_amax;
-    size_t skin_w0, skin_wp[3], skin_w4p, skin_bias;
+    size_t skin_w0, skin_wp[3], skin_w4p, skin_bias, skin_wps[4], skin_scales, skin_amax;
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
     size_t verts4, knn_spheres, knn_grid, knn_cells;
     size_t bytes;
@@ -2149,6 +2235,10 @@ FrameLayout frame_layout(int col_mode) {
     for (int i = 0; i < 3; ++i) L.skin_wp[i] = take(128 * 128);
     L.skin_w4p = take(32 * 128);
     L.skin_bias = take(4 * 128 + 32);
+    for (int i = 0; i < 3; ++i) L.skin_wps[i] = take(128 * 128);
+    L.skin_wps[3] = take(32 * 128);
+    L.skin_scales = take(64);
+    L.skin_amax = take(64);
     L.col_w0p = take((size_t)256 * kin_pad);
     L.col_w1p = take(256 * 256);
     L.col_w2p = take(128 * 256);
@@ -2242,7 +2332,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         for (int i = 0; i < 5; ++i) {
             hipLaunchKernelGGL(k_absmax, dim3(16), dim3(256), 0, s, nets->sdf_w[i + 1], 256 * 256, amax + i);
             hipLaunchKernelGGL(k_pack_split, dim3(16 * 8 * 64 / 256), dim3(256), 0, s,
-                               reinterpret_cast<f16x8*>(base + L.sdf_wps[i]), nets->sdf_w[i + 1], 256, 16, 8,
+                               reinterpret_cast<f16x8*>(base + L.sdf_wps[i]), nets->sdf_w[i + 1], 256, 256, 16, 8,
                                (const unsigned*)(amax + i));
         }
         hipLaunchKernelGGL(k_fold_film, dim3(6), dim3(256), 0, s, (const float*)P(L.sdf_freq), (const float*)P(L.sdf_phase),
@@ -2255,6 +2345,24 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     for (int i = 0; i < 4; ++i)
         hipLaunchKernelGGL(k_copy, dim3(1), dim3(128), 0, s, P(L.skin_bias) + i * 128, nets->skin_b[i], 128, 128);
     hipLaunchKernelGGL(k_copy, dim3(1), dim3(32), 0, s, P(L.skin_bias) + 512, nets->skin_b[4], 25, 32);
+    {
+        unsigned* amax = reinterpret_cast<unsigned*>(base + L.skin_amax);
+        if (hipMemsetAsync(amax, 0, 64 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
+        SkinRaw raw;
+        for (int i = 0; i < 4; ++i) {
+            raw.w[i] = nets->skin_w[i];
+            raw.b[i] = nets->skin_b[i];
+        }
+        hipLaunchKernelGGL(k_skin_probe, dim3(17 * 17 * 17), dim3(128), 0, s, raw, amax);
+        for (int i = 0; i < 4; ++i) {
+            const int M = i < 3 ? 128 : 25, mt = i < 3 ? 8 : 2;
+            hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, s, nets->skin_w[i + 1], M * 128, amax + 4 + i);
+            hipLaunchKernelGGL(k_pack_split, dim3((mt * 4 * 64 + 255) / 256), dim3(256), 0, s,
+                               reinterpret_cast<f16x8*>(base + L.skin_wps[i]), nets->skin_w[i + 1], M, 128, mt, 4,
+                               (const unsigned*)(amax + 4 + i));
+        }
+        hipLaunchKernelGGL(k_skin_scales, dim3(1), dim3(64), 0, s, (const unsigned*)amax, P(L.skin_scales));
+    }
     // ---- colour MLP: permute input columns to [feat(256), x(3), n(3), view(27)], fold the pose tail
     {
         ColSegs sg;
@@ -2311,6 +2419,8 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     for (int i = 0; i < 3; ++i) out->skin_wp[i] = P(L.skin_wp[i]);
     out->skin_w4p = P(L.skin_w4p);
     out->skin_bias = P(L.skin_bias);
+    for (int i = 0; i < 4; ++i) out->skin_wps[i] = base + L.skin_wps[i];
+    out->skin_scales = P(L.skin_scales);
     out->col_w0p = P(L.col_w0p);
     out->col_w1p = P(L.col_w1p);
     out->col_w2p = P(L.col_w2p);
@@ -2444,18 +2554,22 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, TargetSrc ts, CanonOut
                         bool seeded, hipStream_t s) {
     int* cnt = w.counts;   // cnt[it] = number of records consumed by iteration it
     const int g = grid_for(max_pts, kTile);
+    long long gu_ll = (max_pts + kUpdThreads - 1) / kUpdThreads;
+    const int gu = (int)(gu_ll < 1 ? 1 : (gu_ll > 4096 ? 4096 : gu_ll));
     if (!seeded)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
                            (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, w.recA);
     for (int it = 0; it <= kBroydenSteps; ++it) {
         const CanonRec* rin = (it & 1) ? w.recB : w.recA;
         CanonRec* rout = (it & 1) ? w.recA : w.recB;
+        LAUNCH_ENGINE(fd.split, k_canon_mlp<true>, k_canon_mlp<false>, dim3(g), dim3(kThreads), kLdsCanonMlp, s, fd, rin,
+                      (const int*)&cnt[it], w.logit, &w.ctr->n_skin_fwd);
         if (it == 0)
-            hipLaunchKernelGGL(k_canon_iter<true>, dim3(g), dim3(kThreads), kLdsSkin, s, fd, rin, rout,
-                               (const int*)&cnt[it], &cnt[it + 1], ts, outp, &w.ctr->n_skin_fwd);
+            hipLaunchKernelGGL(k_canon_update<true>, dim3(gu), dim3(kUpdThreads), 0, s, fd, rin, rout,
+                               (const float*)w.logit, (const int*)&cnt[it], &cnt[it + 1], ts, outp);
         else
-            hipLaunchKernelGGL(k_canon_iter<false>, dim3(g), dim3(kThreads), kLdsSkin, s, fd, rin, rout,
-                               (const int*)&cnt[it], &cnt[it + 1], ts, outp, &w.ctr->n_skin_fwd);
+            hipLaunchKernelGGL(k_canon_update<false>, dim3(gu), dim3(kUpdThreads), 0, s, fd, rin, rout,
+                               (const float*)w.logit, (const int*)&cnt[it], &cnt[it + 1], ts, outp);
     }
     const int last = kBroydenSteps + 1;
     hipLaunchKernelGGL(k_canon_drain, dim3(grid_for(max_pts, 256)), dim3(256), 0, s,

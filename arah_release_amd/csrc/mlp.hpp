@@ -135,53 +135,52 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
     const int j = lane & 15, g = lane >> 4;
     const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + g * 16;
     const f16x8* aptr = wp + (size_t)mt0 * KC32 * 2 * 64 + lane;
-    f16x8 ah[MT], al[MT], ahn[MT], aln[MT];
+    // Fully unrolled and software-pipelined one chunk deep on BOTH operands: a CU-owning workgroup has only two
+    // waves per SIMD, so a wave must keep the matrix pipe fed by itself (measured: with the B fragments loaded
+    // at the top of each chunk one wave's 192 MFMAs took 7k cycles instead of 3.1k).
+    f16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        ah[m] = aptr[((m * KC32) * 2 + 0) * 64];
-        al[m] = aptr[((m * KC32) * 2 + 1) * 64];
+        ah[0][m] = aptr[((m * KC32) * 2 + 0) * 64];
+        al[0][m] = aptr[((m * KC32) * 2 + 1) * 64];
     }
-#pragma unroll 1
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bh[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4);
+        bl[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off);
+    }
+#pragma unroll
     for (int kc = 0; kc < KC32; ++kc) {
-        const int kn = kc + 1 < KC32 ? kc + 1 : kc;
+        const int c = kc & 1, x = c ^ 1;
+        if (kc + 1 < KC32) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m) {   // weights of the next chunk (L2) fly during this chunk's MFMAs
-            ahn[m] = aptr[((m * KC32 + kn) * 2 + 0) * 64];
-            aln[m] = aptr[((m * KC32 + kn) * 2 + 1) * 64];
-        }
-        f16x8 bh[NT], bl[NT];
+            for (int m = 0; m < MT; ++m) {
+                ah[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 0) * 64];
+                al[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 1) * 64];
+            }
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
-            bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + kc * 64);
+            for (int n = 0; n < NT; ++n) {
+                bh[x][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + (kc + 1) * 64);
+                bl[x][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + (kc + 1) * 64);
+            }
         }
-        // every operand load of the chunk is issued before its first MFMA, and (below) the chunk's last MFMA has
-        // left the pipe before the next chunk's loads are issued: operand registers are never re-loaded while an
-        // MFMA that reads them can still be pending (see the split-engine note in DESIGN.md)
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)   // small terms first, three passes over the MT*NT independent accumulators
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c][m], bh[c][n], acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bl[c][n], acc[m][n], 0, 0, 0);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+        // keep the scheduler from sinking the next chunk's loads below this chunk's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("" ::"s"(__builtin_amdgcn_readfirstlane(__float_as_int(acc[MT - 1][NT - 1][0]))));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            ah[m] = ahn[m];
-            al[m] = aln[m];
-        }
     }
 }
 
@@ -202,6 +201,31 @@ __device__ __forceinline__ float load_split(const float* act, int ld, int lo_off
     const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4;
     return ((float)*reinterpret_cast<const _Float16*>(row + ch * 2) +
             (float)*reinterpret_cast<const _Float16*>(row + lo_off + ch * 2)) * kInvActScale;
+}
+
+// One 16x16 output tile (M-tile mt, N-tile nt) on the split engine: narrow output layers split over waves.
+template <int KC32>
+__device__ __forceinline__ f32x4 gemm_one_split(const f16x8* __restrict__ wp, int mt, int nt, const float* act, int ld,
+                                                int lo_off, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const char* bptr = reinterpret_cast<const char*>(act) + (nt * 16 + j) * ld * 4 + g * 16;
+    const f16x8* aptr = wp + (size_t)mt * KC32 * 2 * 64 + lane;
+    f16x8 ah[KC32], al[KC32], bh[KC32], bl[KC32];
+#pragma unroll
+    for (int kc = 0; kc < KC32; ++kc) {
+        ah[kc] = aptr[(kc * 2 + 0) * 64];
+        al[kc] = aptr[(kc * 2 + 1) * 64];
+        bh[kc] = *reinterpret_cast<const f16x8*>(bptr + kc * 64);
+        bl[kc] = *reinterpret_cast<const f16x8*>(bptr + lo_off + kc * 64);
+    }
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kc = 0; kc < KC32; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kc], bh[kc], acc, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < KC32; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bl[kc], acc, 0, 0, 0);
+#pragma unroll
+    for (int kc = 0; kc < KC32; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bh[kc], acc, 0, 0, 0);
+    return acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -453,6 +477,9 @@ struct SkinNet {
     const float* wp[3];   // packed 128x128
     const float* w4p;     // packed [32][128]
     const float* bias;    // [4][128] + [32]
+    const f16x8* wps[4];  // split-packed 128x128 x3, [32][128]
+    const float* scales;  // [0..3] activation scale S_k of layer k's output (power of two)
+                          // [4..7] 1 / (weight scale of layer k+1 * S_k): turns the split accumulator into W h
 };
 
 constexpr int kSkinLd = 132;
@@ -466,25 +493,36 @@ __device__ __forceinline__ float softplus100(float x) {
     return fmaxf(x, 0.f) + __builtin_amdgcn_logf(1.0f + e) * 6.93147180559945e-3f;
 }
 
-// xin LDS [16*NT][4] normalised coords -> logits LDS [16*NT][kLogitLd] (25 valid, un-scaled)
-template <int NT = kNT>
+// xin LDS [16*NT][4] normalised coords -> logits LDS [16*NT][kLogitLd] (25 valid, un-scaled).
+// SPLIT: hidden activations h >= 0 live in LDS as hi/lo f16 planes of S_k h (row = 256 B hi | 256 B lo); S_k comes
+// from a per-frame probe of the network (arah_prepare_frame) with 32x headroom, conversions saturate.
+template <int NT = kNT, bool SPLIT = false>
 __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, float* act, float* logits, int wave,
                                          int lane) {
     const int j = lane & 15, g = lane >> 4;
     const int ld = kSkinLd;
+    constexpr float kSat = 65504.0f;
     {
         const int ch0 = wave * 16 + 4 * g;
         f32x4 w[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + ch0);
+        const float S = SPLIT ? net.scales[0] : 1.0f;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
             f32x4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = softplus100(w[r][0] * x[0] + w[r][1] * x[1] + w[r][2] * x[2] + b[r]);
-            *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+            for (int r = 0; r < 4; ++r)   // explicit chain: every instantiation must round identically
+                h[r] = softplus100(fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], fmaf(w[r][0], x[0], b[r]))));
+            if (SPLIT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = fminf(h[r] * S, kSat);
+                store_split4(act, ld, 256, n * 16 + j, ch0, h);
+            } else {
+                *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+            }
         }
     }
     __syncthreads();
@@ -493,23 +531,37 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         f32x4 acc[1][NT];
 #pragma unroll
         for (int n = 0; n < NT; ++n) zero_acc(acc[0][n]);
-        gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
+        if (SPLIT) gemm_acc_split<4, 1, NT>(net.wps[k - 1], wave, act, ld, 256, acc, lane);
+        else gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
         __syncthreads();
         const int ch0 = wave * 16 + 4 * g;
         const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
+        const float inv = SPLIT ? net.scales[4 + k - 1] : 1.0f;
+        const float S = SPLIT ? net.scales[k] : 1.0f;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x4 h;
+            if (SPLIT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = softplus100(acc[0][n][r] + b[r]);
-            *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+                for (int r = 0; r < 4; ++r) h[r] = fminf(softplus100(fmaf(acc[0][n][r], inv, b[r])) * S, kSat);
+                store_split4(act, ld, 256, n * 16 + j, ch0, h);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = softplus100(acc[0][n][r] + b[r]);
+                *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+            }
         }
         __syncthreads();
     }
     {   // output layer 128 -> 25 (padded 32): wave w computes M-tile (w & 1) of N-tile (w >> 1)
         const int mt = wave & 1, nt = wave >> 1;
         if (nt < NT) {
-            const f32x4 acc = gemm_one<8>(net.w4p, mt, nt, act, ld, lane);
+            f32x4 acc;
+            if (SPLIT) {
+                acc = gemm_one_split<4>(net.wps[3], mt, nt, act, ld, 256, lane) * net.scales[7];
+            } else {
+                acc = gemm_one<8>(net.w4p, mt, nt, act, ld, lane);
+            }
             const int ch0 = mt * 16 + 4 * g;
             const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + 4 * 128 + ch0);
 #pragma unroll

@@ -58,6 +58,7 @@ class ArahFrame(C.Structure):
                 ("sdf_bias", _fp), ("sdf_freq", _fp), ("sdf_phase", _fp),
                 ("sdf_wps", _fp * 5), ("sdf_fw", _fp), ("sdf_pw", _fp), ("sdf_fws", _fp),
                 ("skin_w0", _fp), ("skin_wp", _fp * 3), ("skin_w4p", _fp), ("skin_bias", _fp),
+                ("skin_wps", _fp * 4), ("skin_scales", _fp),
                 ("col_w0p", _fp), ("col_w1p", _fp), ("col_w2p", _fp), ("col_w3ap", _fp), ("col_w3bp", _fp),
                 ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
                 ("verts4", _fp), ("knn_spheres", _fp), ("knn_grid", _fp), ("knn_cells", _fp),
@@ -147,7 +148,10 @@ class Workspace:
     def counters(self):
         out = ArahCounters()
         _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream()), "arah_counters_read")
-        return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn")}
+        d = {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn")}
+        if out.reserved[0] or out.reserved[1]:   # only a -DARAH_PROFILE_CANON build writes these (phase clocks)
+            d["reserved"] = [int(out.reserved[0]), int(out.reserved[1])]
+        return d
 
 
 class Frame:

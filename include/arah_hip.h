@@ -129,6 +129,8 @@ typedef struct ArahFrame {
     const float* skin_wp[3];    /* packed 128x128 */
     const float* skin_w4p;      /* packed [32][128] */
     const float* skin_bias;     /* [4][128] + [32] */
+    const void* skin_wps[4];    /* split-packed 128x128 x3 and [32][128] */
+    const float* skin_scales;   /* [8] activation scales S_k (probed per frame) and accumulator un-scales */
     const float* col_w0p;       /* packed [256][KIN_PAD] (columns permuted to [feat,x,n,view]) */
     const float* col_w1p;       /* packed [256][256] */
     const float* col_w2p;       /* packed [128][256] */

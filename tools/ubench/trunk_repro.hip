@@ -225,6 +225,183 @@ void run_nt(const char* name, SdfNet net, const float* dX, int n, float* dO, siz
            (double)n * 657408 / ms / 1e9, worst, vs_ref);
 }
 
+// phase clocks of the split trunk on a CU-owning workgroup (s_memtime ticks, wave 0)
+__global__ __launch_bounds__(kThreads) void k_trunk_clk(SdfNet net, const float* __restrict__ x, int n, float* out, float* clk) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;
+    float* outv = xin + 64 * 4;
+    float* act = outv + 64 * 4;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, mt0 = wave * 2;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long tg = 0, tb1 = 0, te = 0, tb2 = 0, t0 = 0, tl0 = 0, th = 0;
+    int tiles = 0;
+    for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
+        ++tiles;
+        if (tid < kTile) {
+            const int i = tile * kTile + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = v;
+        }
+        __syncthreads();
+        t0 = __builtin_amdgcn_s_memtime();
+        {
+            f32x4 xx[4];
+            for (int nn = 0; nn < 4; ++nn) xx[nn] = *reinterpret_cast<const f32x4*>(xin + (nn * 16 + j) * 4);
+            for (int m = 0; m < 2; ++m) {
+                const int ch0 = (mt0 + m) * 16 + 4 * g;
+                f32x4 w[4];
+                for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+                const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+                const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+                for (int nn = 0; nn < 4; ++nn) {
+                    f32x4 v, h, d;
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], xx[nn][2], fmaf(w[r][1], xx[nn][1], w[r][0] * xx[nn][0]));
+                    film_sine<false>(v, fw, pw, zero4, kActScale, h, d);
+                    store_split4(act, kSdfLd, 512, nn * 16 + j, ch0, h);
+                }
+            }
+        }
+        __syncthreads();
+        tl0 += __builtin_amdgcn_s_memtime() - t0;
+#pragma unroll 1
+        for (int k = 1; k < 6; ++k) {
+            f32x4 acc[2][4];
+            for (int m = 0; m < 2; ++m) for (int nn = 0; nn < 4; ++nn) zero_acc(acc[m][nn]);
+            unsigned long long a = __builtin_amdgcn_s_memtime();
+            gemm_acc_split<8, 2, 4>(net.wps[k - 1], mt0, act, kSdfLd, 512, acc, lane);
+            unsigned long long b = __builtin_amdgcn_s_memtime();
+            tg += b - a;
+            __syncthreads();
+            a = __builtin_amdgcn_s_memtime();
+            tb1 += a - b;
+            for (int m = 0; m < 2; ++m) {
+                const int ch0 = (mt0 + m) * 16 + 4 * g;
+                const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fws + k * 256 + ch0);
+                const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+                for (int nn = 0; nn < 4; ++nn) {
+                    f32x4 h, d;
+                    film_sine<false>(acc[m][nn], fw, pw, zero4, kActScale, h, d);
+                    store_split4(act, kSdfLd, 512, nn * 16 + j, ch0, h);
+                }
+            }
+            b = __builtin_amdgcn_s_memtime();
+            te += b - a;
+            __syncthreads();
+            tb2 += __builtin_amdgcn_s_memtime() - b;
+        }
+        t0 = __builtin_amdgcn_s_memtime();
+        sdf_head<true>(net, act, kSdfLd, outv, 4, tid);
+        __syncthreads();
+        if (tid < kTile && tile * kTile + tid < n) out[tile * kTile + tid] = outv[tid * 4];
+        __syncthreads();
+        th += __builtin_amdgcn_s_memtime() - t0;
+    }
+    if (lane == 0 && (wave == 0 || wave == 5) && tiles) {
+        float* c = clk + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        c[0] = (float)tg / tiles / 5; c[1] = (float)tb1 / tiles / 5; c[2] = (float)te / tiles / 5; c[3] = (float)tb2 / tiles / 5;
+        c[4] = (float)tl0 / tiles; c[5] = (float)th / tiles; c[6] = (float)tiles;
+    }
+}
+
+// the de-phased two-tile trunk (copy of sdf_trunk_pair_split with clocks): per phase, time of the epilogue part,
+// of the GEMM part, and of the barrier wait
+__global__ __launch_bounds__(kThreads) void k_pair_clk(SdfNet net, const float* __restrict__ x, int n, float* out, float* clk, int mode) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;
+    float* outv = xin + 128 * 4;
+    float* actA = outv + 128 * 4;
+    float* actB = actA + 64 * kSdfLd;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, mt0 = wave * 2;
+    const int ld = kSdfLd;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned long long tE = 0, tG = 0, tB = 0;
+    int steps = 0;
+    auto layer0 = [&](const float* xi, float* act) {
+        f32x4 xx[4];
+        for (int nn = 0; nn < 4; ++nn) xx[nn] = *reinterpret_cast<const f32x4*>(xi + (nn * 16 + j) * 4);
+        for (int m = 0; m < 2; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            f32x4 w[4];
+            for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+            for (int nn = 0; nn < 4; ++nn) {
+                f32x4 v, h, d;
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], xx[nn][2], fmaf(w[r][1], xx[nn][1], w[r][0] * xx[nn][0]));
+                film_sine<false>(v, fw, pw, zero4, kActScale, h, d);
+                store_split4(act, ld, 512, nn * 16 + j, ch0, h);
+            }
+        }
+    };
+    auto gemm = [&](int k, const float* act, f32x4 (&acc)[2][4]) {
+        const unsigned long long a = __builtin_amdgcn_s_memtime();
+        for (int m = 0; m < 2; ++m) for (int nn = 0; nn < 4; ++nn) zero_acc(acc[m][nn]);
+        gemm_acc_split<8, 2, 4>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+        tG += __builtin_amdgcn_s_memtime() - a;
+    };
+    auto epi = [&](int k, const f32x4 (&acc)[2][4], float* act) {
+        const unsigned long long a = __builtin_amdgcn_s_memtime();
+        for (int m = 0; m < 2; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fws + k * 256 + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+            for (int nn = 0; nn < 4; ++nn) {
+                f32x4 h, d;
+                film_sine<false>(acc[m][nn], fw, pw, zero4, kActScale, h, d);
+                store_split4(act, ld, 512, nn * 16 + j, ch0, h);
+            }
+        }
+        tE += __builtin_amdgcn_s_memtime() - a;
+    };
+    auto bar = [&]() {
+        const unsigned long long a = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        tB += __builtin_amdgcn_s_memtime() - a;
+    };
+    const bool epi_first = mode == 0 ? (wave < 4) : (mode == 1 ? (wave & 1) : (mode == 2 ? ((__builtin_amdgcn_s_getreg((3 << 11) | 4) & 1) != 0) : true));
+    for (int tile = blockIdx.x; tile * 128 < n; tile += gridDim.x) {
+        ++steps;
+        if (tid < 128) {
+            const int i = tile * 128 + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = v;
+        }
+        __syncthreads();
+        layer0(xin, actA);
+        layer0(xin + 256, actB);
+        __syncthreads();
+        f32x4 accA[2][4], accB[2][4];
+        gemm(1, actA, accA);
+        bar();
+#pragma unroll 1
+        for (int k = 1; k < 6; ++k) {
+#pragma unroll 1
+            for (int step = 0; step < 2; ++step) {
+                if ((step == 0) == epi_first) epi(k, accA, actA);
+                else gemm(k, actB, accB);
+            }
+            bar();
+#pragma unroll 1
+            for (int step = 0; step < 2; ++step) {
+                if ((step == 0) == epi_first) epi(k, accB, actB);
+                else if (k < 5) gemm(k + 1, actA, accA);
+            }
+            bar();
+        }
+        sdf_head<true>(net, actA, ld, outv, 4, tid);
+        sdf_head<true>(net, actB, ld, outv + 256, 4, tid);
+        __syncthreads();
+        if (tid < 128 && tile * 128 + tid < n) out[tile * 128 + tid] = outv[tid * 4];
+        __syncthreads();
+    }
+    if (lane == 0 && (wave == 0 || wave == 5) && steps) {
+        float* c = clk + (blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        c[0] = (float)tE / steps / 10; c[1] = (float)tG / steps / 10; c[2] = (float)tB / steps / 11; c[6] = (float)steps;
+    }
+}
+
 int main(int argc, char** argv) {
     const int n = 400000;
     unsigned s = 777;
@@ -284,6 +461,44 @@ int main(int argc, char** argv) {
         run_nt<4>("64-pt tiles, LDS padded to 1 WG/CU", net, dX, n, dO, 90 * 1024, 256, ref);
         run_nt<8>("128-pt tiles (1 WG/CU)", net, dX, n, dO, l8, 256, ref);
         run_nt<8>("128-pt tiles (1 WG/CU)", net, dX, n, dO, l8, 512, ref);
+    }
+    {
+        float* dC; hipMalloc(&dC, 512 * 2 * 8 * 4);
+        for (int grid : {256, 512}) {
+            hipMemset(dC, 0, 512 * 2 * 8 * 4);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_clk), hipFuncAttributeMaxDynamicSharedMemorySize, 90 * 1024);
+            k_trunk_clk<<<grid, kThreads, 90 * 1024>>>(net, dX, n, dO, dC);
+            hipDeviceSynchronize();
+            std::vector<float> c(grid * 16);
+            hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
+            for (int wv = 0; wv < 2; ++wv) {
+                double a[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < grid; ++b) for (int k = 0; k < 7; ++k) a[k] += c[(b * 2 + wv) * 8 + k] / grid;
+                printf("1 WG/CU, grid %d, wave %d: per layer gemm %.0f  barrier %.0f  epilogue %.0f  barrier %.0f | layer-1 %.0f  head+io %.0f ticks, %.1f tiles/WG\n",
+                       grid, wv ? 5 : 0, a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+            }
+        }
+    }
+    {
+        float* dC; hipMalloc(&dC, 512 * 2 * 8 * 4);
+        const size_t lp = (128 * 4 * 2) * 4 + (size_t)128 * kSdfLd * 4;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_clk), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
+        for (int mode = 0; mode < 4; ++mode) {
+            hipMemset(dC, 0, 512 * 2 * 8 * 4);
+            hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+            k_pair_clk<<<512, kThreads, lp>>>(net, dX, n, dO, dC, mode);
+            hipEventRecord(e0);
+            k_pair_clk<<<512, kThreads, lp>>>(net, dX, n, dO, dC, mode);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            std::vector<float> c(512 * 16);
+            hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
+            for (int wv = 0; wv < 2; ++wv) {
+                double a[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int b = 0; b < 512; ++b) for (int k = 0; k < 7; ++k) a[k] += c[(b * 2 + wv) * 8 + k] / 512;
+                printf("pair mode %d (%.3f ms), wave %d: per phase epilogue %.0f  gemm %.0f  barrier %.0f ticks\n", mode, ms, wv ? 5 : 0, a[0], a[1], a[2]);
+            }
+        }
     }
     run_dbg<4>("one-channel head", net, dX, n, dO, lds);
     run_dbg<1>("clamp instead of sine in layer 1", net, dX, n, dO, lds);
