@@ -51,8 +51,9 @@ def _mlp_layers(module):
 
 
 def build_frame(sdf_network, skinning_model, rendering_network, deviation_network, pose_cond, smpl_verts,
-                skinning_weights, bone_transforms, trans, coord_min, coord_max, center):
-    """Pack one temporal frame for the kernels (weights emitted by the hypernetwork + body)."""
+                skinning_weights, bone_transforms, trans, coord_min, coord_max, center, precision=None):
+    """Pack one temporal frame for the kernels (weights emitted by the hypernetwork + body).
+    precision: hip.PRECISION_SPLIT_F16 / hip.PRECISION_FP32; None = env ARAH_PRECISION (default split)."""
     with torch.no_grad():
         sdf_layers, freq, phase = _emitted_sdf_layers(sdf_network)
         skin_layers = _mlp_layers(skinning_model.skinning_decoder_fwd)
@@ -77,7 +78,7 @@ def build_frame(sdf_network, skinning_model, rendering_network, deviation_networ
         return hip.Frame(sdf_layers, freq, phase, skin_layers, color_layers, mode, pose_vec, beta,
                          smpl_verts[0], skinning_weights[0], bone_transforms[0], trans.reshape(-1)[:3].tolist(),
                          center.reshape(-1)[:3].tolist(), float(coord_min.reshape(-1)[0]),
-                         float(coord_max.reshape(-1)[0]))
+                         float(coord_max.reshape(-1)[0]), precision=precision)
 
 
 class BodyRayTracing(nn.Module):

@@ -11,8 +11,12 @@ i -> rank i mod N): no data-path collective, weak scaling, value = al
 / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (loop D's k_shade): algorithmic MFMA flops per launch / HIP-event
-                duration vs the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  roofline      largest single launch of the default path (k_density: the SDF MLP forward on every valid sample):
+                algorithmic MFMA flops per launch / HIP-event duration.  Peak: the default GEMM engine carries each
+                fp32 operand as two f16 and spends three v_mfma_f32_16x16x32_f16 per product, so its ceiling in
+                algorithmic fp32 flops is the dense f16 MFMA peak / 3 = 833 TFLOP/s; the exact engine
+                (ARAH_PRECISION=fp32) is priced against the fp32 MFMA peak, 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  exact_fp32_engine  the same frames with v_mfma_f32_16x16x4_f32 everywhere.
   cpu_baseline  the oracle (a torch-CPU restatement of the reference, pinned against it) on a bounded
                 sample of the same frame's rays, on the host cores of this box; rank 0, N == 1 only.
 """
@@ -32,6 +36,13 @@ F_SDF = 657408          # 2*(3*256 + 5*256^2 + 256)
 F_SDF_GRAD = 657408
 F_COL = {"no_view_dir": 794112, "idr": 821760}
 PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F16_MFMA_TFLOPS = 2500.0
+PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # three f16 MFMAs per fp32 product
+
+
+def mixed_peak(parts):
+    """Time-weighted peak of a kernel whose GEMM classes run on different engines: parts = [(flops, peak), ...]."""
+    return sum(f for f, _ in parts) / sum(f / p for f, p in parts)
 
 
 def shard_frames(rank, world, steps, warmup):
@@ -62,7 +73,8 @@ def pmc_traffic(kernel):
     if not files:
         return None, None
     try:
-        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        ks = json.load(open(files[-1]))["kernels"]
+        k = ks.get(kernel) or next((v for n, v in sorted(ks.items()) if n.startswith(kernel)), None)
         return (k["hbm_bytes_avg"], os.path.relpath(files[-1], ROOT)) if k else (None, None)
     except Exception:
         return None, None
@@ -158,13 +170,20 @@ def main():
         setter(None, None)
         return dt, ctr, ms
 
+    split = hip.default_precision() == hip.PRECISION_SPLIT_F16
     with torch.no_grad():
         elapsed, counters, dens_ms = timed_pass(False)          # the product's default path
         elapsed_full, counters_full, shade_ms = timed_pass(True)  # shade every valid sample, like the reference
+        elapsed_exact = None
+        if split:                                               # same frames on the exact fp32 MFMA engine
+            os.environ["ARAH_PRECISION"] = "fp32"
+            elapsed_exact, _, _ = timed_pass(False)
+            os.environ["ARAH_PRECISION"] = "split"
         tracer.full_shading = False
 
     total_rays, t_max = aggregate(n_rays_local, elapsed, dist if world > 1 else None)
     _, t_max_full = aggregate(n_rays_local, elapsed_full, dist if world > 1 else None)
+    t_max_exact = aggregate(n_rays_local, elapsed_exact, dist if world > 1 else None)[1] if elapsed_exact else None
     if rank == 0:
         mode = cfg["model"]["renderer_kwargs"]["mode"]
         n_launch = max(len(shade_ms), 1)
@@ -183,35 +202,52 @@ def main():
         avg_ms = sum(shade_ms) / n_launch
         achieved_full = samples_per_launch * flops_per_sample / (avg_ms * 1e-3) / 1e12
         total_flops = path_flops(counters)
-        dens_traffic, traffic_src = pmc_traffic("k_density")
-        shade_traffic, _ = pmc_traffic("k_shade<%s>" % ("true" if mode == "idr" else "false"))
+        tf = {True: "true", False: "false"}
+        dens_traffic, traffic_src = pmc_traffic("k_density<%s>" % tf[split])
+        shade_traffic, _ = pmc_traffic("k_shade<%s, %s>" % (tf[mode == "idr"], tf[split]))
+        peak_fwd = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
+        # k_shade: forward trunk on the default engine, reverse sweep and colour MLP on the exact engine
+        peak_shade = mixed_peak([(F_SDF, peak_fwd), (F_SDF_GRAD + F_COL[mode], PEAK_F32_MFMA_TFLOPS)])
+        engine = ("fp32 operands as hi+lo f16 pairs, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate "
+                  "(forward SDF trunks, loop-C skinning MLP); v_mfma_f32_16x16x4_f32 for reverse sweeps and the "
+                  "colour MLP" if split else "v_mfma_f32_16x16x4_f32 everywhere")
         line = {
             "metric": "rendered rays/sec", "value": total_rays / t_max, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "precision": engine,
             "config": {"workload": "ZJUMOCAP-377-mono test.py inference, %dx%d, %d samples/ray (near %d / far %d), "
                                    "synthetic capsule body + fitted SIREN, one frame per step" %
                                    (args.size, args.size, args.n_steps, near, far),
                        "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
                        "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": dens_traffic,
+            "roofline": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
+                         "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
-                         "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples, "flops_per_sample": F_SDF},
+                         "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples, "flops_per_sample": F_SDF,
+                         "peak_note": ("algorithmic fp32 flops against dense f16 MFMA peak / 3 (three f16 MFMAs per "
+                                       "fp32 product); executed f16 MFMA rate = 3 x achieved" if split else
+                                       "dense fp32 MFMA peak")},
             "full_shading": {"note": "same frames with lazy shading off (normal + colour for EVERY valid sample, as "
                                      "the reference does); bit-identical images",
                              "value": total_rays / t_max_full, "unit": "rays/s",
                              "ms_per_step": 1e3 * t_max_full / max(args.steps, 1),
                              "algorithmic_mflop_per_ray": path_flops(counters_full) / max(n_rays_local, 1) / 1e6,
                              "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": achieved_full,
-                                          "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                                          "frac": achieved_full / PEAK_F32_MFMA_TFLOPS, "traffic": shade_traffic,
+                                          "peak": peak_shade, "unit": "TFLOP/s",
+                                          "frac": achieved_full / peak_shade, "traffic": shade_traffic,
+                                          "peak_note": "time-weighted over the kernel's GEMM classes and their engines",
                                           "avg_launch_ms": avg_ms, "samples_per_launch": samples_per_launch,
                                           "flops_per_sample": flops_per_sample}},
             "work": {"per_ray": {k: v / max(n_rays_local, 1) for k, v in counters.items()},
                      "algorithmic_mflop_per_ray": total_flops / max(n_rays_local, 1) / 1e6,
                      "whole_path_tflops_rank0": total_flops / elapsed / 1e12},
         }
+        if t_max_exact:
+            line["exact_fp32_engine"] = {"note": "same frames with ARAH_PRECISION=fp32 (v_mfma_f32_16x16x4_f32 for every "
+                                                 "GEMM, two workgroups per CU)",
+                                         "value": total_rays / t_max_exact, "unit": "rays/s",
+                                         "ms_per_step": 1e3 * t_max_exact / max(args.steps, 1)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, args.config, args.size, args.n_steps, near, far,
                                                 args.cpu_sample_rays)

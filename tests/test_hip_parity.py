@@ -50,7 +50,9 @@ def test_struct_sizes_match_header():
     """ctypes mirrors of the POD structs must have the C layout (pointer + int32/float fields)."""
     import ctypes as C
     from arah_release_amd import hip
-    assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 4 * 3 + 4   # padded to 8
+    assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 4 * 4   # col_mode, n_pose, beta, precision
+    n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 8 + 4 + 3   # sdf, skin, colour, knn, body pointers
+    assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * (1 + 3 + 3 + 2 + 3)   # beta, trans, center, min/max, 3 ints
     assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
     assert C.sizeof(hip.ArahCounters) == 64
 
@@ -390,6 +392,68 @@ def test_training_step_against_reference(scene):
         n += 1
         ok += abs(float(p.grad.norm()) - ref) <= 0.05 * ref + 1e-7
     assert n == 211 and ok / n >= 0.97, (ok, n)
+
+
+def _frame_for(scene, name, res, frame_idx, precision, dev):
+    from arah_release_amd import config, renderer
+    model, cfg = config.build_synthetic_model(name, device=dev)
+    inputs = scene.make_inputs(res, res, frame_idx=frame_idx, device=dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"], precision=precision)
+    return frame, inputs, cfg
+
+
+@gpu
+def test_split_engine_matches_exact_fp32_engine(scene):
+    """The default GEMM engine carries fp32 operands as hi + lo f16 pairs (three f16 MFMAs per product); the exact
+    engine is v_mfma_f32_16x16x4_f32 everywhere.  Same frame, same rays: unit seams agree to fp32 round-off
+    class, the images to > 60 dB, hit masks on > 99.9 % of the rays."""
+    from arah_release_amd import hip
+    dev = torch.device("cuda:0")
+    fs, inputs, cfg = _frame_for(scene, "zju377_mono", 128, 3, hip.PRECISION_SPLIT_F16, dev)
+    fe, _, _ = _frame_for(scene, "zju377_mono", 128, 3, hip.PRECISION_FP32, dev)
+    assert fs.precision == hip.PRECISION_SPLIT_F16 and fe.precision == hip.PRECISION_FP32
+    ws = hip.Workspace(dev)
+    x = (torch.rand(20000, 3, generator=torch.Generator().manual_seed(5)) * 2 - 1).to(dev)
+    ss, feat_s, gs = hip.sdf_eval(fs, ws, x, want_feat=True, want_grad=True)
+    se, feat_e, ge = hip.sdf_eval(fe, ws, x, want_feat=True, want_grad=True)
+    np.testing.assert_allclose(ss.cpu().numpy(), se.cpu().numpy(), rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(feat_s.cpu().numpy(), feat_e.cpu().numpy(), rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(gs.cpu().numpy(), ge.cpu().numpy(), rtol=2e-3, atol=5e-4)
+    samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
+    pose = torch.eye(4)[:3]
+    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+    rs = hip.render(fs, ws, samp, cam, d, nf, pose)
+    re_ = hip.render(fe, ws, samp, cam, d, nf, pose)
+    assert float((rs[5] == re_[5]).float().mean()) >= 0.999          # converged-ray masks
+    assert psnr(rs[0].cpu().numpy(), re_[0].cpu().numpy()) >= 60.0
+    both = (rs[5] & re_[5]).cpu().numpy().astype(bool)
+    assert_rows_close(rs[4].cpu().numpy()[both], re_[4].cpu().numpy()[both], atol=1e-4, frac=0.999)   # depths
+
+
+@gpu
+def test_render_is_reproducible_under_load(scene):
+    """Full-size frame, three renders with the same inputs: bit-identical.  (Guards the launch discipline of the
+    split engine -- one workgroup per CU; two co-resident workgroups gave irreproducible 16-point groups.)"""
+    from arah_release_amd import hip
+    dev = torch.device("cuda:0")
+    frame, inputs, cfg = _frame_for(scene, "zju377_mono", 512, 11, None, dev)
+    ws = hip.Workspace(dev)
+    samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
+    pose = torch.eye(4)[:3]
+    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+    ref = hip.render(frame, ws, samp, cam, d, nf, pose)
+    for _ in range(2):
+        again = hip.render(frame, ws, samp, cam, d, nf, pose)
+        for a, b in zip(ref, again):
+            assert torch.equal(a, b)
 
 
 @gpu

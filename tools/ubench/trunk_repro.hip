@@ -402,6 +402,96 @@ __global__ __launch_bounds__(kThreads) void k_pair_clk(SdfNet net, const float* 
     }
 }
 
+// 16 waves in ONE workgroup (4 per SIMD): waves 0-7 run tile A, waves 8-15 tile B, same code, shared barriers.
+// Is the irreproducibility about four f16-MFMA waves per SIMD, or about two workgroups on a CU?
+__global__ __launch_bounds__(1024) void k_trunk_16w(SdfNet net, const float* __restrict__ x, int n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, half = tid >> 9, t9 = tid & 511, wave = t9 >> 6, lane = tid & 63;
+    float* xin = smem + half * 64 * 4;
+    float* outv = smem + 128 * 4 + half * 64 * 4;
+    float* act = smem + 256 * 4 + half * 64 * kSdfLd;
+    for (int tile = blockIdx.x * 2 + half; (tile - half) * kTile < n; tile += gridDim.x * 2) {
+        if (t9 < kTile) {
+            const int i = tile * kTile + t9;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[t9] = v;
+        }
+        __syncthreads();
+        f32x4 dlast[kSdfMT][kNT];
+        sdf_trunk<false, kNT, true>(net, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<true>(net, act, kSdfLd, outv, 4, t9);
+        __syncthreads();
+        if (t9 < kTile && tile * kTile + t9 < n) out[tile * kTile + t9] = outv[t9 * 4];
+        __syncthreads();
+    }
+}
+
+// 16 waves, two tiles, the second half-workgroup one step behind the first: while waves 0-7 run a GEMM, waves 8-15
+// run the previous epilogue of their own tile (and vice versa) -- matrix pipe and vector ALU busy together.
+__global__ __launch_bounds__(1024) void k_trunk_16w_skew(SdfNet net, const float* __restrict__ x, int n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, half = tid >> 9, t9 = tid & 511, wave = t9 >> 6, lane = tid & 63;
+    const int j = lane & 15, g = lane >> 4, mt0 = wave * 2, ld = kSdfLd;
+    float* xin = smem + half * 64 * 4;
+    float* outv = smem + 128 * 4 + half * 64 * 4;
+    float* act = smem + 256 * 4 + half * 64 * kSdfLd;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = blockIdx.x * 2 + half; (tile - half) * kTile < n; tile += gridDim.x * 2) {
+        if (t9 < kTile) {
+            const int i = tile * kTile + t9;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[t9] = v;
+        }
+        __syncthreads();
+        f32x4 acc[2][4];
+#pragma unroll 1
+        for (int p = 0; p < 12; ++p) {
+            const int st = p - half;   // this half's step: 0 = layer 1 (VALU), 2k-1 = GEMM k, 2k = epilogue k
+            if (st == 0) {
+                f32x4 xx[4];
+                for (int nn = 0; nn < 4; ++nn) xx[nn] = *reinterpret_cast<const f32x4*>(xin + (nn * 16 + j) * 4);
+                for (int m = 0; m < 2; ++m) {
+                    const int ch0 = (mt0 + m) * 16 + 4 * g;
+                    f32x4 w[4];
+                    for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+                    const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+                    const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+                    for (int nn = 0; nn < 4; ++nn) {
+                        f32x4 v, h, d;
+                        for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], xx[nn][2], fmaf(w[r][1], xx[nn][1], w[r][0] * xx[nn][0]));
+                        film_sine<false>(v, fw, pw, zero4, kActScale, h, d);
+                        store_split4(act, ld, 512, nn * 16 + j, ch0, h);
+                    }
+                }
+            } else if (st >= 1 && st <= 10) {
+                const int k = (st + 1) >> 1;
+                if (st & 1) {
+                    for (int m = 0; m < 2; ++m) for (int nn = 0; nn < 4; ++nn) zero_acc(acc[m][nn]);
+                    gemm_acc_split<8, 2, 4>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+                } else {
+                    for (int m = 0; m < 2; ++m) {
+                        const int ch0 = (mt0 + m) * 16 + 4 * g;
+                        const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fws + k * 256 + ch0);
+                        const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+                        for (int nn = 0; nn < 4; ++nn) {
+                            f32x4 h, d;
+                            film_sine<false>(acc[m][nn], fw, pw, zero4, kActScale, h, d);
+                            store_split4(act, ld, 512, nn * 16 + j, ch0, h);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        sdf_head<true>(net, act, kSdfLd, outv, 4, t9);
+        __syncthreads();
+        if (t9 < kTile && tile * kTile + t9 < n) out[tile * kTile + t9] = outv[t9 * 4];
+        __syncthreads();
+    }
+}
+
 int main(int argc, char** argv) {
     const int n = 400000;
     unsigned s = 777;
@@ -498,6 +588,38 @@ int main(int argc, char** argv) {
                 for (int b = 0; b < 512; ++b) for (int k = 0; k < 7; ++k) a[k] += c[(b * 2 + wv) * 8 + k] / 512;
                 printf("pair mode %d (%.3f ms), wave %d: per phase epilogue %.0f  gemm %.0f  barrier %.0f ticks\n", mode, ms, wv ? 5 : 0, a[0], a[1], a[2]);
             }
+        }
+    }
+    {
+        const size_t l16 = (256 * 4) * 4 + (size_t)128 * kSdfLd * 4;
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_16w), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);
+        std::vector<float> ref(n), r1(n);
+        k_trunk<true><<<256, kThreads, lds>>>(net, dX, n, dO);
+        hipDeviceSynchronize();
+        hipMemcpy(ref.data(), dO, n * 4, hipMemcpyDeviceToHost);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int rep = 0; rep < 4; ++rep) {
+            hipMemset(dO, 0, n * 4);
+            hipEventRecord(e0);
+            k_trunk_16w<<<256, 1024, l16>>>(net, dX, n, dO);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(r1.data(), dO, n * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0;
+            for (int i = 0; i < n; ++i) bad += memcmp(&ref[i], &r1[i], 4) != 0;
+            printf("16 waves in one workgroup (4 per SIMD): %.3f ms, differs from the 1-WG/CU reference in %zu of %d\n", ms, bad, n);
+        }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_16w_skew), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l16);
+        for (int rep = 0; rep < 4; ++rep) {
+            hipMemset(dO, 0, n * 4);
+            hipEventRecord(e0);
+            k_trunk_16w_skew<<<256, 1024, l16>>>(net, dX, n, dO);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            hipMemcpy(r1.data(), dO, n * 4, hipMemcpyDeviceToHost);
+            size_t bad = 0;
+            for (int i = 0; i < n; ++i) bad += memcmp(&ref[i], &r1[i], 4) != 0;
+            printf("16 waves, halves skewed by one step: %.3f ms, differs from the 1-WG/CU reference in %zu of %d\n", ms, bad, n);
         }
     }
     run_dbg<4>("one-channel head", net, dX, n, dO, lds);
