@@ -9,7 +9,8 @@ reference's functions are called directly and their inputs/outputs are stored.
     python tests/golden/make_golden.py f8         # writes F8 (training step, about 1 MB)
 
 Fixtures:
-  f1_broyden.npz       broyden() KATs, D=3 (g = LBS(x) - target) and D=4 (joint residual)
+  f1_broyden3.npz      broyden() KAT, D=3 (g = LBS(x) - target)
+  f1_broyden4.npz      D=4: search_iso_surface_depth (joint residual, Jacobian assembly, broyden) -- `make_golden.py f1d4`
   f2_pointwise.npz     hierarchical_softmax, (un)normalize, skinning, Deformer fwd, query_weights,
                        forward_skinning, forward_skinning_jac
   f3_sdf.npz           emitted SDF MLP: value, feature, autograd gradient
@@ -150,7 +151,53 @@ def make_f8():
          inside_sdf=out["inside_sdf"], **{"loss." + k: v.reshape(-1)[0] for k, v in loss.items()}, **grads)
 
 
+def make_f1_d4():
+    """F1, D = 4: the reference's joint root find (search_iso_surface_depth: Jacobian assembly, residual closure and
+    broyden() on u = (x_hat, depth), root_finding_utils.py:365-484) on 256 rays with perturbed starts."""
+    torch.set_num_threads(os.cpu_count())
+    scene = synthetic.SyntheticScene(seed=0)
+    model, cfg = build_reference_model("zju377_mono")
+    inputs = scene.make_inputs(64, 64, frame_idx=0)
+    ft = frame_tensors(model, inputs)
+    sdf_network, loc, sc, vol = ft["sdf_network"], ft["loc"], ft["sc_factor"], ft["vol_feat"]
+    cmin, cmax, center = inputs["coord_min"], inputs["coord_max"], inputs["center"]
+    bones, trans = inputs["bone_transforms"], inputs["trans"]
+    skin = model.skinning_model
+    g = torch.Generator().manual_seed(321)
+    # canonical points close to the zero level set: project random points with a few Newton steps on the SDF
+    P = 256
+    x_norm = (torch.rand(1, 4096, 3, generator=g) * 1.4 - 0.7)
+    for _ in range(6):
+        with torch.enable_grad():
+            xg = x_norm.clone().requires_grad_(True)
+            sdf = sdf_network(xg)
+            grad = diff_operators.gradient(sdf, xg, create_graph=False)
+        x_norm = (xg - sdf * grad / (grad.pow(2).sum(-1, keepdim=True) + 1e-8)).detach()
+    with torch.no_grad():
+        keep = sdf_network(x_norm)[0, :, 0].abs().argsort()[:P]
+        x_norm = x_norm[:, keep]
+        x_hat = RFU.unnormalize_canonical_points(x_norm, cmin, cmax, center)
+        x_bar, T_true = RFU.forward_skinning(x_hat, loc, sc, cmin, cmax, center, skin, vol, bones)
+        x_posed = x_bar + trans
+        cam = torch.zeros(1, P, 3)
+        depth = x_posed.norm(dim=-1)
+        rays = x_posed / depth[..., None]
+        # perturbed starts; a few hopeless ones exercise the divergence / best-iterate paths; some rays masked out
+        x0 = x_hat + torch.randn(1, P, 3, generator=g) * 0.01
+        z0 = depth + torch.randn(1, P, generator=g) * 0.01
+        x0[:, :6] += 0.4
+        valid = torch.ones(1, P, dtype=torch.bool)
+        valid[:, 10:20] = False
+        T0 = T_true + torch.randn(1, P, 4, 4, generator=g) * 1e-3
+        xo, zo, To, conv = RFU.search_iso_surface_depth(cam, rays, valid, x0, z0, T0, sdf_network, loc, sc, skin, vol,
+                                                        bones, trans, cmin, cmax, center, eval_mode=True)
+    save("f1_broyden4.npz", cam=cam[0], rays=rays[0], valid=valid[0], x0=x0[0], z0=z0[0], T0=T0[0], x_opt=xo[0],
+         z_opt=zo[0], T_opt=To[0], converged=conv[0])
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f1d4":
+        return make_f1_d4()
     if len(sys.argv) > 1 and sys.argv[1] == "f8":
         return make_f8()
     torch.set_num_threads(os.cpu_count())

@@ -73,6 +73,28 @@ def test_f1_broyden3(frame377):
     np.testing.assert_allclose(err.numpy()[~valid], g["diff"][~valid], rtol=5e-2, atol=1e-4)
 
 
+def test_f1_broyden4(frame377):
+    """D = 4: the joint root find on (x_hat, depth) -- Jacobian assembly, residual and broyden() -- against the
+    reference's search_iso_surface_depth (RFU:365-484) on 256 rays with perturbed starts, masked-out rays and a
+    few hopeless starts."""
+    g = golden("f1_broyden4.npz")
+    fr = frame377
+    valid = torch.from_numpy(g["valid"])
+    x, z, Tm, conv = O.joint_root_find(fr, T(g["cam"]), T(g["rays"]), valid, T(g["x0"]), T(g["z0"]), T(g["T0"]))
+    ref_conv = g["converged"]
+    assert (conv.numpy() == ref_conv).mean() >= 0.995
+    both = conv.numpy() & ref_conv
+    assert both.sum() > 200
+    np.testing.assert_allclose(x.numpy()[both], g["x_opt"][both], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(z.numpy()[both], g["z_opt"][both], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(Tm.numpy()[both], g["T_opt"][both], rtol=1e-3, atol=1e-4)
+    off = ~g["valid"]                               # rays outside the mask keep their inputs (RFU:472-482)
+    np.testing.assert_array_equal(x.numpy()[off], g["x0"][off])
+    np.testing.assert_array_equal(z.numpy()[off], g["z0"][off])
+    np.testing.assert_array_equal(Tm.numpy()[off], g["T0"][off])
+    assert not conv.numpy()[off].any() and not ref_conv[off].any()
+
+
 @pytest.mark.parametrize("name", ["zju377_mono", "zju313"])
 def test_f4_color(scene, name):
     g = golden("f4_color_%s.npz" % name)
