@@ -457,6 +457,88 @@ def test_render_is_reproducible_under_load(scene):
 
 
 @gpu
+def test_batch_of_views_equals_single_views(scene):
+    """B = 2 views of one frame through MetaAvatarRender.forward (the reference batches views that share a pose,
+    RT:118-132): the same dict entries as two B = 1 calls, bit for bit, including the per-view points_cam."""
+    from arah_release_amd import config
+    dev = torch.device("cuda:0")
+    model, _ = config.build_synthetic_model("zju313", device=dev)
+    a = scene.make_inputs(96, 96, frame_idx=5, device=dev, max_rays=3000)
+    b = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in a.items()}
+    b["pose_cond"] = dict(a["pose_cond"])
+    perm = torch.randperm(a["ray_dirs"].shape[1], generator=torch.Generator().manual_seed(2)).to(dev)
+    for k in ("ray_dirs", "body_bounds_intersections", "body_mask"):
+        b[k] = a[k][:, perm].contiguous()
+    b["cam_loc"] = a["cam_loc"] + torch.tensor([[0.01, -0.02, 0.015]], device=dev)
+    ang = 0.05
+    R = torch.tensor([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]], dtype=torch.float32, device=dev)
+    b["pose"] = a["pose"].clone()
+    b["pose"][0, :3, :3] = R @ a["pose"][0, :3, :3]
+    both = {}
+    for k, v in a.items():
+        if torch.is_tensor(v) and k in ("ray_dirs", "body_bounds_intersections", "body_mask", "cam_loc", "pose", "intrinsics",
+                                         "cam_rot", "cam_trans", "smpl_verts", "skinning_weights", "bone_transforms",
+                                         "trans", "coord_min", "coord_max", "center", "minimal_shape", "Jtrs", "rots"):
+            both[k] = torch.cat([a[k], b[k]], dim=0)
+        else:
+            both[k] = v
+    both["pose_cond"] = dict(a["pose_cond"])
+    with torch.no_grad():
+        oa = model(a, eval=True)
+        ob = model(b, eval=True)
+        o2 = model(both, eval=True)
+    for k in ("rgb_values", "network_body_mask", "points_cam"):
+        assert o2[k].shape[0] == 2
+        if k == "points_cam":   # B > 1 applies the per-view pose in a torch epilogue: same formula, fp32 reassociation
+            np.testing.assert_allclose(o2[k][0].cpu().numpy(), oa[k][0].cpu().numpy(), rtol=0, atol=2e-6)
+            np.testing.assert_allclose(o2[k][1].cpu().numpy(), ob[k][0].cpu().numpy(), rtol=0, atol=2e-6)
+        else:
+            assert torch.equal(o2[k][0], oa[k][0]), k
+            assert torch.equal(o2[k][1], ob[k][0]), k
+
+
+@gpu
+def test_config5_stress_1024_128(scene):
+    """BASELINE config 5: 1024x1024, 128 samples/ray (near 32 / far 32), H36M shapes (idr colour net, canonical view
+    directions): one frame = ~6e5 rays, ~4e7 samples, ~29 GB of workspace.  Size-independent properties only."""
+    from arah_release_amd import hip
+    dev = torch.device("cuda:0")
+    from arah_release_amd import config, renderer
+    model, cfg = config.build_synthetic_model("h36m", 128, 32, 32, device=dev)
+    inputs = scene.make_inputs(1024, 1024, frame_idx=9, device=dev)
+    N = inputs["ray_dirs"].shape[1]
+    assert N > 400000
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder,
+                                     model.deviation_decoder, pose_cond, inputs["smpl_verts"],
+                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    ws = hip.Workspace(dev)
+    samp = hip.Sampling(dev, 128, 32, 32, True, False)
+    pose = torch.eye(4)[:3]
+    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+    ws.ensure(N, 128)
+    ws.reset_counters()
+    rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam, d, nf, pose)
+    torch.cuda.synchronize()
+    c = ws.counters()
+    assert float(rgb.min()) >= 0 and float(acc.max()) <= 1.0
+    assert bool((rgb.max(dim=-1)[0] <= acc + 1e-5).all())
+    assert 0.05 < float(conv.float().mean()) < 0.6 and float(vol.float().mean()) > 0.9
+    n_conv = int(conv.sum())
+    # every converged ray carries near + far + 1 = 65 samples, the others 128: all of them are canonicalised once
+    assert c["n_knn"] >= n_conv * 65 + (N - n_conv) * 128
+    # a subset of the rays rendered alone gives the same pixels
+    sub = torch.arange(0, N, 97, device=dev)
+    rgb_s = hip.render(frame, ws, samp, cam, d[sub].contiguous(), nf[sub].contiguous(), pose)[0]
+    assert torch.equal(rgb_s, rgb[sub])
+
+
+@gpu
 def test_edge_cases(ctx, scene):
     """Empty ray set, rays whose interval is empty (near == far), a single ray."""
     hip = ctx["hip"]
