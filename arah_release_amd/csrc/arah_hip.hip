@@ -856,7 +856,7 @@ __device__ __forceinline__ void store_T(float* dst, const float (&T)[16]) {
 constexpr int kSpillPerWg = 5 * kWaves * (kSdfMT * kNT) * 64;   // f32x4 elements
 
 template <bool GRAD, bool SPLIT>
-__global__ __launch_bounds__(kThreads) void k_sdf_eval(FrameDev fr, const float* x_norm, const int* list,
+__global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(FrameDev fr, const float* x_norm, const int* list,
                                                         const int* count, int n_direct, float* sdf_out,
                                                         float* feat_out, float* grad_out, f32x4* spill_all,
                                                         unsigned long long* ctr_fwd, unsigned long long* ctr_grad) {
@@ -977,7 +977,7 @@ __device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceS
 }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads) void k_sdf_march(FrameDev fr, TraceState st, const int* list, const int* count,
+__global__ __launch_bounds__(kThreads, 4) void k_sdf_march(FrameDev fr, TraceState st, const int* list, const int* count,
                                                          int* next_list, int* next_count,
                                                          unsigned long long* ctr_fwd) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1220,7 +1220,7 @@ __device__ __forceinline__ void canon_mlp_tiles(const FrameDev& fr, const CanonR
 }
 
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, SPLIT ? 2 : 4) void k_canon_mlp(FrameDev fr, const CanonRec* __restrict__ rin,
+__global__ __launch_bounds__(kThreads, 4) void k_canon_mlp(FrameDev fr, const CanonRec* __restrict__ rin,
                                                                        const int* count, float* __restrict__ lg,
                                                                        unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1736,7 +1736,7 @@ __device__ __forceinline__ float volsdf_density(float sdf, float inv_beta) {
 // bit-identical to shading everything (tests/test_hip_parity.py::test_lazy_shading_is_exact).
 // ------------------------------------------------------------------------------------------
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
+__global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
                                                        f32x4* shaded, int* next_list, int* next_count,
                                                        unsigned long long* ctr_fwd) {
     constexpr int TW = kTile;
@@ -2134,17 +2134,22 @@ constexpr size_t lds_color() {
 }
 
 // Launch KS when the frame was prepared for the split engine, KE (exact fp32) otherwise.
-// A split-engine kernel must be ALONE on its CU: with two workgroups of it co-resident (4 waves per SIMD) results
-// became irreproducible on MI355X / ROCm 7.2 -- whole 16-point groups of a tile wrong, run to run, while the same
-// binary is bit-reproducible with one workgroup per CU (tools/ubench/trunk_repro.hip isolates it).  The launch
-// therefore asks for at least kLdsSplitSolo bytes of LDS, more than half of the CU's 160 KB.
+// ARAH_SPLIT_SOLO=1 makes every split-engine workgroup own its CU (asks for more than half of the 160 KB LDS):
+// the workaround that was in place until the irreproducibility of co-resident workgroups was traced to the packed
+// K = 3 input layer (no_pack in mlp.hpp); kept as a diagnostic switch.
+inline size_t split_lds(size_t lds) {
+    static const bool solo = [] {
+        const char* e = getenv("ARAH_SPLIT_SOLO");
+        return e && e[0] == '1';
+    }();
+    constexpr size_t kSolo = 84 * 1024;
+    return solo && lds < kSolo ? kSolo : lds;
+}
 constexpr size_t kLdsSplitSolo = 84 * 1024;
-#define LAUNCH_ENGINE(split, KS, KE, GRID, BLOCK, LDS, ...)                                             \
-    do {                                                                                                \
-        if (split)                                                                                      \
-            hipLaunchKernelGGL(KS, GRID, BLOCK, (LDS) > kLdsSplitSolo ? (LDS) : kLdsSplitSolo, __VA_ARGS__); \
-        else                                                                                            \
-            hipLaunchKernelGGL(KE, GRID, BLOCK, LDS, __VA_ARGS__);                                      \
+#define LAUNCH_ENGINE(split, KS, KE, GRID, BLOCK, LDS, ...)                              \
+    do {                                                                                 \
+        if (split) hipLaunchKernelGGL(KS, GRID, BLOCK, split_lds(LDS), __VA_ARGS__);     \
+        else hipLaunchKernelGGL(KE, GRID, BLOCK, LDS, __VA_ARGS__);                      \
     } while (0)
 
 template <typename K>

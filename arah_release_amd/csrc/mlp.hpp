@@ -29,6 +29,10 @@
 
 #include "pointwise.hpp"
 
+#ifndef ARAH_SYNC
+#define ARAH_SYNC() __syncthreads()
+#endif
+
 namespace arah {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -39,6 +43,16 @@ constexpr int kTile = 64;     // points per tile
 constexpr int kNT = 4;        // N-tiles (16 points each) per wave
 
 __device__ __forceinline__ void zero_acc(f32x4& a) { a = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// Compiler fence for the K = 3 input layers.  hipcc (ROCm 7.2) turns their unrolled dot products into
+// v_pk_fma_f32 with op_sel / op_sel_hi half-broadcasts of the coordinate operand; with that code in a kernel, two
+// co-resident workgroups of the split engine produced irreproducible results on MI355X (whole 16-point groups
+// wrong, run to run) -- tools/ubench/trunk_repro.hip bisects it down to exactly this: the same layer compiled to
+// scalar v_fma_f32 is bit-reproducible.  The empty asm pins each value in its own VGPR, which keeps the SLP
+// vectoriser away from the chain; the arithmetic (an explicit fmaf chain) is unchanged.
+__device__ __forceinline__ void no_pack(f32x4& v) {
+    asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
 
 // acc[m][n] += Wp(rows of M-tiles mt0..mt0+MT-1, KC 16-chunks) * act(64 points)
 template <int KC, int MT, int NT = kNT>
@@ -129,58 +143,102 @@ constexpr float kInvActScale = 1.0f / 1024.0f;
 // acc[m][n] += Wsplit(M-tiles mt0..mt0+MT-1, KC32 32-chunks) * act(16 NT points)
 //   weights : wp[((mt*KC32 + kc)*2 + s)*64 + lane]  (s = 0 hi, 1 lo), lane (j, g) holds W[mt*16 + j][kc*32 + 8g .. +7]
 //   act     : LDS rows of ld floats; hi plane at byte 0, lo plane at byte lo_off; lane reads k = kc*32 + 8g .. +7
-template <int KC32, int MT, int NT>
+// DEEP: fully unrolled, both operands one chunk ahead -- for kernels that run two waves per SIMD (large register
+// budgets, little thread-level parallelism to hide latency).  Otherwise rolled, A one chunk ahead, B loaded at the
+// top of the chunk: fits the 128-VGPR budget of four waves per SIMD, whose other waves hide the LDS latency.
+template <int KC32, int MT, int NT, bool DEEP = false>
 __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int mt0, const float* act, int ld,
                                                int lo_off, f32x4 (&acc)[MT][NT], int lane) {
     const int j = lane & 15, g = lane >> 4;
     const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + g * 16;
     const f16x8* aptr = wp + (size_t)mt0 * KC32 * 2 * 64 + lane;
-    // Fully unrolled and software-pipelined one chunk deep on BOTH operands: a CU-owning workgroup has only two
-    // waves per SIMD, so a wave must keep the matrix pipe fed by itself (measured: with the B fragments loaded
-    // at the top of each chunk one wave's 192 MFMAs took 7k cycles instead of 3.1k).
-    f16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+    if constexpr (DEEP || KC32 <= 4) {
+        f16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        ah[0][m] = aptr[((m * KC32) * 2 + 0) * 64];
-        al[0][m] = aptr[((m * KC32) * 2 + 1) * 64];
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        bh[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4);
-        bl[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off);
-    }
-#pragma unroll
-    for (int kc = 0; kc < KC32; ++kc) {
-        const int c = kc & 1, x = c ^ 1;
-        if (kc + 1 < KC32) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 0) * 64];
-                al[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 1) * 64];
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                bh[x][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + (kc + 1) * 64);
-                bl[x][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + (kc + 1) * 64);
-            }
+        for (int m = 0; m < MT; ++m) {
+            ah[0][m] = aptr[((m * KC32) * 2 + 0) * 64];
+            al[0][m] = aptr[((m * KC32) * 2 + 1) * 64];
         }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)   // small terms first, three passes over the MT*NT independent accumulators
+        for (int n = 0; n < NT; ++n) {
+            bh[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4);
+            bl[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off);
+        }
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+        for (int kc = 0; kc < KC32; ++kc) {
+            const int c = kc & 1, x = c ^ 1;
+            if (kc + 1 < KC32) {
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+                for (int m = 0; m < MT; ++m) {
+                    ah[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 0) * 64];
+                    al[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 1) * 64];
+                }
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bl[c][n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NT; ++n) {
+                    bh[x][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + (kc + 1) * 64);
+                    bl[x][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + (kc + 1) * 64);
+                }
+            }
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)   // small terms first, three passes over the MT*NT independent accumulators
 #pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bh[c][n], acc[m][n], 0, 0, 0);
-        // keep the scheduler from sinking the next chunk's loads below this chunk's MFMAs
-        __builtin_amdgcn_sched_barrier(0);
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bl[c][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+            // keep the scheduler from sinking the next chunk's loads below this chunk's MFMAs
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        f16x8 ah[MT], al[MT], ahn[MT], aln[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[m] = aptr[((m * KC32) * 2 + 0) * 64];
+            al[m] = aptr[((m * KC32) * 2 + 1) * 64];
+        }
+#pragma unroll 1
+        for (int kc = 0; kc < KC32; ++kc) {
+            const int kn = kc + 1 < KC32 ? kc + 1 : kc;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ahn[m] = aptr[((m * KC32 + kn) * 2 + 0) * 64];
+                aln[m] = aptr[((m * KC32 + kn) * 2 + 1) * 64];
+            }
+            f16x8 bh[NT], bl[NT];
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
+                bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + kc * 64);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = ahn[m];
+                al[m] = aln[m];
+            }
+        }
     }
 }
 
@@ -334,6 +392,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
 #pragma unroll
                 for (int r = 0; r < 4; ++r)   // explicit chain: every instantiation must round identically
                     v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
+                no_pack(v);
                 film_sine<GRAD>(v, fw, pw, f, amp, h, d);
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
@@ -341,7 +400,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             }
         }
     }
-    __syncthreads();
+    ARAH_SYNC();
 #pragma unroll 1
     for (int k = 1; k < 6; ++k) {
         f32x4 acc[kSdfMT][NT];
@@ -349,9 +408,9 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
-        if (SPLIT) gemm_acc_split<8, kSdfMT, NT>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+        if (SPLIT) gemm_acc_split<8, kSdfMT, NT, GRAD>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);   // GRAD kernels: 2 waves/SIMD
         else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
-        __syncthreads();   // everyone is done reading the layer input
+        ARAH_SYNC();   // everyone is done reading the layer input
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
@@ -370,7 +429,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
                 }
             }
         }
-        __syncthreads();
+        ARAH_SYNC();
     }
 }
 
@@ -382,7 +441,7 @@ __device__ __forceinline__ void unsplit_rows(float* act, int ld, int tid) {
         const int e = tid + i * kThreads;
         v[i] = load_split(act, ld, 512, e >> 8, e & 255);
     }
-    __syncthreads();
+    ARAH_SYNC();
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
         const int e = tid + i * kThreads;
@@ -423,7 +482,7 @@ __device__ __forceinline__ void sdf_backward(const SdfNet& net, float* bwd, int 
 #pragma unroll
         for (int n = 0; n < kNT; ++n) *reinterpret_cast<f32x4*>(bwd + (n * 16 + j) * ld + ch0) = dlast[m][n] * w;
     }
-    __syncthreads();
+    ARAH_SYNC();
 #pragma unroll 1
     for (int k = 4; k >= 0; --k) {   // g_k+1 (layer index k, 0-based) = W_{k+2}^T u_{k+2}
         f32x4 acc[kSdfMT][kNT];
@@ -432,7 +491,7 @@ __device__ __forceinline__ void sdf_backward(const SdfNet& net, float* bwd, int 
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
         gemm_acc<16, kSdfMT>(net.wpT[k], mt0, bwd, ld, acc, lane);
-        __syncthreads();
+        ARAH_SYNC();
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
@@ -442,7 +501,7 @@ __device__ __forceinline__ void sdf_backward(const SdfNet& net, float* bwd, int 
                 *reinterpret_cast<f32x4*>(bwd + (n * 16 + j) * ld + ch0) = acc[m][n] * d;
             }
         }
-        __syncthreads();
+        ARAH_SYNC();
     }
     // grad_c = sum_ch w0[ch][c] * u1[pt][ch]
     const int pt = tid >> 3, part = tid & 7;
@@ -515,7 +574,10 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
             f32x4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r)   // explicit chain: every instantiation must round identically
-                h[r] = softplus100(fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], fmaf(w[r][0], x[0], b[r]))));
+                h[r] = fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], fmaf(w[r][0], x[0], b[r])));
+            no_pack(h);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = softplus100(h[r]);
             if (SPLIT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) h[r] = fminf(h[r] * S, kSat);
@@ -525,7 +587,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
             }
         }
     }
-    __syncthreads();
+    ARAH_SYNC();
 #pragma unroll 1
     for (int k = 1; k < 4; ++k) {
         f32x4 acc[1][NT];
@@ -533,7 +595,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         for (int n = 0; n < NT; ++n) zero_acc(acc[0][n]);
         if (SPLIT) gemm_acc_split<4, 1, NT>(net.wps[k - 1], wave, act, ld, 256, acc, lane);
         else gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
-        __syncthreads();
+        ARAH_SYNC();
         const int ch0 = wave * 16 + 4 * g;
         const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
         const float inv = SPLIT ? net.scales[4 + k - 1] : 1.0f;
@@ -551,7 +613,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
                 *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
             }
         }
-        __syncthreads();
+        ARAH_SYNC();
     }
     {   // output layer 128 -> 25 (padded 32): wave w computes M-tile (w & 1) of N-tile (w >> 1)
         const int mt = wave & 1, nt = wave >> 1;
@@ -568,7 +630,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
             for (int r = 0; r < 4; ++r) logits[(nt * 16 + j) * kLogitLd + ch0 + r] = acc[r] + b[r];
         }
     }
-    __syncthreads();
+    ARAH_SYNC();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -628,7 +690,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         gemm_acc<D::kKC0, 2>(net.w0p, wave * 2, A, D::kLdA, acc, lane);
         relu_store<2>(acc, net.bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
     }
-    __syncthreads();
+    ARAH_SYNC();
     {
         f32x4 acc[2][kNT];
 #pragma unroll
@@ -636,19 +698,19 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
         gemm_acc<16, 2>(net.w1p, wave * 2, B, ldB, acc, lane);
-        __syncthreads();
+        ARAH_SYNC();
         relu_store<2>(acc, net.bias + 256, B, ldB, wave * 2, lane);
     }
-    __syncthreads();
+    ARAH_SYNC();
     {
         f32x4 acc[1][kNT];
 #pragma unroll
         for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
         gemm_acc<16, 1>(net.w2p, wave, B, ldB, acc, lane);
-        __syncthreads();
+        ARAH_SYNC();
         relu_store<1>(acc, net.bias + 512, B, ldB, wave, lane);   // cols 0..127
     }
-    __syncthreads();
+    ARAH_SYNC();
     {
         f32x4 acc[2][kNT];
 #pragma unroll
@@ -657,10 +719,10 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
         gemm_acc<D::kKC0, 2>(net.w3ap, wave * 2, A, D::kLdA, acc, lane);
         gemm_acc<8, 2>(net.w3bp, wave * 2, B, ldB, acc, lane);
-        __syncthreads();
+        ARAH_SYNC();
         relu_store<2>(acc, net.bias + 640, B, ldB, wave * 2, lane);
     }
-    __syncthreads();
+    ARAH_SYNC();
     {
         f32x4 acc[2][kNT];
 #pragma unroll
@@ -668,10 +730,10 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
         gemm_acc<16, 2>(net.w4p, wave * 2, B, ldB, acc, lane);
-        __syncthreads();
+        ARAH_SYNC();
         relu_store<2>(acc, net.bias + 896, B, ldB, wave * 2, lane);
     }
-    __syncthreads();
+    ARAH_SYNC();
     {
         const int pt = tid >> 3, part = tid & 7;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;

@@ -75,8 +75,28 @@ __device__ __forceinline__ void trunk_dbg(const SdfNet& net, const float* xin, f
             for (int n = 0; n < NT; ++n) {
                 f32x4 v, h, d;
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
+                if (FL & 512) {
+                    for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v[r]));   // K=3 chain unpacked, sine free to pack
+                }
                 if (FL & 1) {
                     for (int r = 0; r < 4; ++r) h[r] = fminf(fmaxf(v[r] * 3.0f, -1.0f), 1.0f) * kActScale;
+                } else if (FL & (32 | 64 | 128 | 256)) {
+                    for (int r = 0; r < 4; ++r) {
+                        float w = fmaf(v[r], fw[r], pw[r]);
+                        if (FL & 64) asm volatile("" : "+v"(w));          // one element at a time: no v_pk_* packing
+                        const float q = rintf(w);
+                        const float rr = w - q;
+                        const float r2 = rr * rr;
+                        float p = fmaf(r2, 0.0772201280771219f * kActScale, -0.5980451736306471f * kActScale);
+                        p = fmaf(p, r2, 2.550031377188653f * kActScale);
+                        p = fmaf(p, r2, -5.167706878920042f * kActScale);
+                        p = fmaf(p, r2, 3.1415925800446054f * kActScale);
+                        float val = p * rr;
+                        if (!(FL & 32)) val = __uint_as_float(__float_as_uint(val) ^ ((unsigned)(int)q << 31));
+                        if (FL & 128) val = fminf(fmaxf(val, -1000.0f), 1000.0f);
+                        if (FL & 64) asm volatile("" : "+v"(val));
+                        h[r] = val;
+                    }
                 }
                 else film_sine<false>(v, fw, pw, zero4, kActScale, h, d);
                 store_split4(act, ld, 512, n * 16 + j, ch0, h);
@@ -623,6 +643,11 @@ int main(int argc, char** argv) {
         }
     }
     run_dbg<4>("one-channel head", net, dX, n, dO, lds);
+    run_dbg<512>("K=3 chain fenced, product sine", net, dX, n, dO, lds);
+    run_dbg<256>("layer-1 sine re-written inline (same math)", net, dX, n, dO, lds);
+    run_dbg<32>("layer-1 sine without the sign flip", net, dX, n, dO, lds);
+    run_dbg<64>("layer-1 sine, packing broken", net, dX, n, dO, lds);
+    run_dbg<128>("layer-1 sine clamped to +-1000", net, dX, n, dO, lds);
     run_dbg<1>("clamp instead of sine in layer 1", net, dX, n, dO, lds);
     run_dbg<2>("clamp instead of sine in MFMA layers", net, dX, n, dO, lds);
     run_dbg<3>("clamp everywhere", net, dX, n, dO, lds);
