@@ -1,4 +1,28 @@
-// Reproducibility of the product SDF trunk (mlp.hpp) under load: same inputs, repeated launches, bitwise compare.
+// Reproducer and bisection of an MI355X (gfx950, ROCm 7.2 hipcc) correctness hazard found while bringing up the
+// split-precision SDF trunk: with TWO workgroups of the kernel resident on a CU, whole 16-point groups of a tile
+// came out wrong, irreproducibly (different tiles every run, errors of order 1), while the same binary was
+// bit-reproducible with one workgroup per CU.
+//
+// What the switches below established (every line is a measured run; `dbg flags N` kernels are local copies of the
+// trunk with one thing changed, all launched 2 workgroups / CU and re-run 4x with a bitwise compare):
+//   * not the GEMM loop: fencing all operand loads ahead of the MFMAs and draining the matrix pipe per chunk
+//     changes nothing; the isolated layer chain (gemm_f16x3.hip) is reproducible at 2 workgroups / CU;
+//   * not barriers (doubled / fenced / s_sleep variants still fail), not the fused ds_write2st64_b64 store, not
+//     s_waitcnt after stores, not the LDS base offset;
+//   * not "four f16-MFMA waves per SIMD": 16 waves of ONE workgroup are bit-exact, even with the two halves skewed by
+//     a phase (k_trunk_16w, k_trunk_16w_skew);
+//   * it is the FIRST layer (K = 3, vector ALU): with its FiLM sine replaced by a clamp the failures vanish (flag 1),
+//     with the sine kept there and removed everywhere else they stay (flag 2);
+//   * and within that layer it is code generation, not data: the identical math with each value pinned in its own
+//     VGPR (flag 64 / 512: `asm volatile("" : "+v"(x))`) or followed by a no-op clamp (flag 128) is reproducible.
+//     The failing builds compile the unrolled 3-term dot products into v_pk_fma_f32 with op_sel / op_sel_hi
+//     half-broadcasts of the coordinate operand (112 v_pk_fma_f32 in the layer); the passing builds into scalar
+//     v_fmac_f32 / v_fmaak_f32.  Fencing ONLY the dot products (flag 512; the sine stays packed) is enough.
+// Product fix: `no_pack()` in csrc/mlp.hpp after the K = 3 chains.  The split engine then runs two workgroups per
+// CU and is bit-reproducible (tests/test_hip_parity.py::test_render_is_reproducible_under_load).
+//
+// Also kept here: s_memtime phase clocks of the trunk on a CU-owning workgroup (k_trunk_clk), and of a two-tile
+// de-phased variant (k_pair_clk) that was tried while the one-workgroup-per-CU workaround was in place.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -559,7 +583,7 @@ int main(int argc, char** argv) {
             printf("grid %3d  %-6s trunk: worst rerun differs in %zu of %d (max |diff| %.3g)  sample out %.6f\n", grid, split ? "split" : "exact", worst, n, md, r0[12345]);
         }
     }
-    run_dbg<0>("copy of product trunk", net, dX, n, dO, lds);
+    run_dbg<0>("K=3 layer as hipcc packs it (v_pk_fma + op_sel)", net, dX, n, dO, lds);
     {
         std::vector<float> ref(n);
         k_trunk<true><<<256, kThreads, lds>>>(net, dX, n, dO);
@@ -652,6 +676,6 @@ int main(int argc, char** argv) {
     run_dbg<2>("clamp instead of sine in MFMA layers", net, dX, n, dO, lds);
     run_dbg<3>("clamp everywhere", net, dX, n, dO, lds);
     run_dbg<7>("clamp everywhere, 1-channel head", net, dX, n, dO, lds);
-    run_dbg<0>("copy of product trunk", net, dX, n, dO, lds);
+    run_dbg<0>("K=3 layer as hipcc packs it (v_pk_fma + op_sel)", net, dX, n, dO, lds);
     return 0;
 }
