@@ -148,10 +148,7 @@ class Workspace:
     def counters(self):
         out = ArahCounters()
         _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream()), "arah_counters_read")
-        d = {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn")}
-        if out.reserved[0] or out.reserved[1]:   # only a -DARAH_PROFILE_CANON build writes these (phase clocks)
-            d["reserved"] = [int(out.reserved[0]), int(out.reserved[1])]
-        return d
+        return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn")}
 
 
 class Frame:
