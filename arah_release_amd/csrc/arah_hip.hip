@@ -760,50 +760,65 @@ __device__ __forceinline__ int nearest_vertex_wave(const KnnData& kd, const Grid
 // SRC_POINTS : id = i, p = pts[i]                 -> x raw canonical
 // SRC_RAYS   : id = list[i] (ray), p = o + t[ray] d -> x NORMALISED (sphere tracing evaluates the SDF there)
 // SRC_SAMPLES: id = list[i] (q = ray*S + s), p = o + z[q] d -> x raw canonical
-// Short lists (the tail of sphere tracing) skip the 119 KB LDS fill and read clusters / spheres / bones from L2.
-constexpr int kKnnDirectBelow = 4096;
+// Two kernels per call, one of them returns at once (the list length lives on the device):
+//   n <  wave_below: k_nearest_wave -- one WAVE per query, clusters / spheres / bones straight from L2, no LDS, so
+//                    many waves per CU; the right shape for the sphere-tracing lists (<= one ray per pixel);
+//   n >= wave_below: k_nearest_invlbs -- one THREAD per query against the vertex table staged in 119 KB of LDS.
+template <int SRC>
+__device__ __forceinline__ V3 knn_point_of(const float* pts, const RaySet& rs, const float* depth, int n_steps,
+                                           const int* list, int i, int& id) {
+    if (SRC == SRC_POINTS) {
+        id = i;
+        return V3{pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
+    }
+    id = list[i];
+    return SRC == SRC_RAYS ? ray_point(rs, id, depth[id]) : ray_point(rs, id / n_steps, depth[id]);
+}
+
+constexpr int kKnnWaveThreads = 256;
+
+template <int SRC>
+__global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, KnnData kd, const float* pts, RaySet rs,
+                                                                   const float* depth, int n_steps, const int* list,
+                                                                   const int* count, int n_direct, int wave_below,
+                                                                   int* idx_out, float* x_out, float* T_out,
+                                                                   CanonRec* rec_out, unsigned long long* ctr) {
+    const int n = (SRC == SRC_POINTS) ? n_direct : *count;
+    if (n >= wave_below) return;
+    const GridInfo g = *kd.grid;
+    if (blockIdx.x == 0 && threadIdx.x == 0) count_add(ctr, n);
+    const int lane = threadIdx.x & 63;
+    const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (int i = wave_global; i < n; i += n_waves) {
+        int id;
+        const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
+        float best = 3.4e38f;
+        int bi = 0x7fffffff;
+        if (SRC == SRC_RAYS && idx_out) {   // sphere tracing: the previous step's nearest vertex bounds the search
+            const int seed = idx_out[id];
+            if (seed >= 0) {
+                const float dx = fr.verts_raw[seed * 3] - p.x, dy = fr.verts_raw[seed * 3 + 1] - p.y,
+                            dz = fr.verts_raw[seed * 3 + 2] - p.z;
+                best = dx * dx + dy * dy + dz * dz;
+                bi = seed;
+            }
+        }
+        bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
+        if (lane == 0) nearest_finish<SRC>(fr, fr.bones, i, id, p, bi, idx_out, x_out, T_out, rec_out);
+    }
+}
 
 template <int SRC>
 __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, KnnData kd, const float* pts, RaySet rs,
                                                                  const float* depth, int n_steps, const int* list,
-                                                                 const int* count, int n_direct, int* idx_out,
-                                                                 float* x_out, float* T_out, CanonRec* rec_out,
-                                                                 unsigned long long* ctr) {
+                                                                 const int* count, int n_direct, int wave_below,
+                                                                 int* idx_out, float* x_out, float* T_out,
+                                                                 CanonRec* rec_out, unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
-    if ((int)(blockIdx.x * blockDim.x) >= (n < kKnnDirectBelow ? n * 64 : n)) return;
+    if (n < wave_below || (int)(blockIdx.x * blockDim.x) >= n) return;
     const GridInfo g = *kd.grid;
     if (blockIdx.x == 0 && threadIdx.x == 0) count_add(ctr, n);
-    auto point_of = [&](int i, int& id) {
-        if (SRC == SRC_POINTS) {
-            id = i;
-            return V3{pts[i * 3], pts[i * 3 + 1], pts[i * 3 + 2]};
-        }
-        id = list[i];
-        return SRC == SRC_RAYS ? ray_point(rs, id, depth[id]) : ray_point(rs, id / n_steps, depth[id]);
-    };
-    if (n < kKnnDirectBelow) {   // one wave per query, everything read through L2 (no LDS fill)
-        const int lane = threadIdx.x & 63;
-        const int wave_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
-        for (int i = wave_global; i < n; i += n_waves) {
-            int id;
-            const V3 p = point_of(i, id);
-            float best = 3.4e38f;
-            int bi = 0x7fffffff;
-            if (SRC == SRC_RAYS && idx_out) {
-                const int seed = idx_out[id];
-                if (seed >= 0) {
-                    const float dx = fr.verts_raw[seed * 3] - p.x, dy = fr.verts_raw[seed * 3 + 1] - p.y,
-                                dz = fr.verts_raw[seed * 3 + 2] - p.z;
-                    best = dx * dx + dy * dy + dz * dz;
-                    bi = seed;
-                }
-            }
-            bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
-            if (lane == 0) nearest_finish<SRC>(fr, fr.bones, i, id, p, bi, idx_out, x_out, T_out, rec_out);
-        }
-        return;
-    }
     float* sv = smem;                              // [kMaxClusters][29][4] clustered vertices, one pad slot per cluster
     float* ssph = sv + (size_t)kMaxClusters * kClusterLds * 4;   // [kMaxClusters][4]
     float* sb = ssph + kMaxClusters * 4;           // [24][16]
@@ -816,7 +831,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
     __syncthreads();
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         int id;
-        const V3 p = point_of(i, id);
+        const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
         nearest_invlbs_point<SRC, kClusterLds>(fr, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
     }
 }
@@ -2117,6 +2132,11 @@ inline int grid_for(long long n_items, int per_block) {
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? ARAH_OK : ARAH_E_LAUNCH; }
 
+inline int env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+
 // dynamic LDS sizes (bytes)
 constexpr size_t kLdsSdfFwd = (64 * 4 * 2 + 64) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsSdfGrad = kLdsSdfFwd + (size_t)64 * kSdfLd * 4;
@@ -2193,6 +2213,29 @@ hipEvent_t g_shade_ev0 = nullptr, g_shade_ev1 = nullptr, g_density_ev0 = nullptr
 
 KnnData knn_of(const FrameDev& fd) {
     return KnnData{fd.knn.sorted4, fd.knn.spheres, reinterpret_cast<const GridInfo*>(fd.knn.grid), fd.knn.cells};
+}
+
+// nearest vertex + inverse LBS of up to n_max queries: the wave kernel and the bulk kernel, one of which returns at once
+template <int SRC>
+void launch_nearest(hipStream_t s, const FrameDev& fd, long long n_max, const float* pts, const RaySet& rs,
+                    const float* depth, int n_steps, const int* list, const int* count, int n_direct, int* idx_out,
+                    float* x_out, float* T_out, CanonRec* rec_out, unsigned long long* ctr) {
+    // list lengths below which one wave per query beats one thread per query (measured)
+    // 512x512 frame: sphere-tracing lists (<= 1.5e5 rays, shrinking) 68.0 -> 65.4 ms per frame with the wave kernel below
+    // 16k..64k entries; the 8.6e6-sample list of loop C wants the LDS table (86 ms when forced onto the wave kernel)
+    static const int below[3] = {env_int("ARAH_KNN_WAVE_POINTS", 4096), env_int("ARAH_KNN_WAVE_RAYS", 32768),
+                                 env_int("ARAH_KNN_WAVE_SAMPLES", 32768)};
+    const int wave_below = below[SRC];
+    long long gw = (n_max * 64 + kKnnWaveThreads - 1) / kKnnWaveThreads;
+    if (gw > 4096) gw = 4096;
+    if (gw < 1) gw = 1;
+    if (n_max >= 0 && (SRC != SRC_POINTS || n_direct < wave_below))
+        hipLaunchKernelGGL(k_nearest_wave<SRC>, dim3((int)gw), dim3(kKnnWaveThreads), 0, s, fd, knn_of(fd), pts, rs, depth,
+                           n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out, rec_out, ctr);
+    if (SRC != SRC_POINTS || n_direct >= wave_below)
+        hipLaunchKernelGGL(k_nearest_invlbs<SRC>, dim3(grid_for(n_max, kKnnThreads)), dim3(kKnnThreads), kLdsKnn, s, fd,
+                           knn_of(fd), pts, rs, depth, n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out,
+                           rec_out, ctr);
 }
 
 RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
@@ -2548,9 +2591,9 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     setup_attributes();
     RaySet rs = make_rays(nullptr, nullptr, 1);
-    hipLaunchKernelGGL(k_nearest_invlbs<SRC_POINTS>, dim3(grid_for(n, kKnnThreads)), dim3(kKnnThreads), kLdsKnn,
-                       reinterpret_cast<hipStream_t>(stream), to_dev(*f), knn_of(to_dev(*f)), pts, rs, (const float*)nullptr, 1,
-                       (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, (CanonRec*)nullptr, &w.ctr->n_knn);
+    launch_nearest<SRC_POINTS>(reinterpret_cast<hipStream_t>(stream), to_dev(*f), n, pts, rs, (const float*)nullptr, 1,
+                               (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, (CanonRec*)nullptr,
+                               &w.ctr->n_knn);
     return check_launch();
 }
 
@@ -2620,13 +2663,12 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     hipLaunchKernelGGL(k_trace_begin, dim3(gb), dim3(256), 0, s, near_far, n, w.t, w.far, w.diverged, w.xcur, w.Tcur,
                        w.listA, &cntA[0]);
     TraceState ts{w.t, w.far, w.xcur, w.diverged};
-    const int gk = grid_for(n, kKnnThreads), gm = grid_for(n, kTile);
+    const int gm = grid_for(n, kTile);
     for (int it = 0; it < kSphereIters; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
-        hipLaunchKernelGGL(k_nearest_invlbs<SRC_RAYS>, dim3(gk), dim3(kKnnThreads), kLdsKnn, s, fd, knn_of(fd),
-                           (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin, (const int*)&cntA[it], 0,
-                           w.nn_idx, w.xcur, w.Tcur, (CanonRec*)nullptr, &w.ctr->n_knn);
+        launch_nearest<SRC_RAYS>(s, fd, n, (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin,
+                                 (const int*)&cntA[it], 0, w.nn_idx, w.xcur, w.Tcur, (CanonRec*)nullptr, &w.ctr->n_knn);
         LAUNCH_ENGINE(fd.split, k_sdf_march<true>, k_sdf_march<false>, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts,
                       (const int*)lin, (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
     }
@@ -2689,9 +2731,8 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     const int gq = (int)((Q + 255) / 256);
     hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 4095) / 4096)), dim3(1024), 0, s, (const uint8_t*)w.q_smask, (int)Q, w.listA, &w.counts[0]);
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
-    hipLaunchKernelGGL(k_nearest_invlbs<SRC_SAMPLES>, dim3(grid_for(Q, kKnnThreads)), dim3(kKnnThreads), kLdsKnn, s, fd,
-                       knn_of(fd), (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA, (const int*)&w.counts[0], 0,
-                       (int*)nullptr, pts, T, w.recA, &w.ctr->n_knn);
+    launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA,
+                                (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, w.recA, &w.ctr->n_knn);
     TargetSrc ts;
     ts.tgt = nullptr;
     ts.rs = rs;

@@ -270,7 +270,7 @@ void run_nt(const char* name, SdfNet net, const float* dX, int n, float* dO, siz
 }
 
 // phase clocks of the split trunk on a CU-owning workgroup (s_memtime ticks, wave 0)
-__global__ __launch_bounds__(kThreads) void k_trunk_clk(SdfNet net, const float* __restrict__ x, int n, float* out, float* clk) {
+__global__ __launch_bounds__(kThreads, 4) void k_trunk_clk(SdfNet net, const float* __restrict__ x, int n, float* out, float* clk) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;
     float* outv = xin + 64 * 4;
@@ -598,18 +598,20 @@ int main(int argc, char** argv) {
     }
     {
         float* dC; hipMalloc(&dC, 512 * 2 * 8 * 4);
-        for (int grid : {256, 512}) {
+        for (int grid : {256, 512, 1024}) {   // 1024: un-padded LDS, two workgroups per CU
             hipMemset(dC, 0, 512 * 2 * 8 * 4);
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_trunk_clk), hipFuncAttributeMaxDynamicSharedMemorySize, 90 * 1024);
-            k_trunk_clk<<<grid, kThreads, 90 * 1024>>>(net, dX, n, dO, dC);
+            const size_t lclk = grid == 1024 ? lds : 90 * 1024;
+            if (grid == 1024) grid = 512;
+            k_trunk_clk<<<grid, kThreads, lclk>>>(net, dX, n, dO, dC);
             hipDeviceSynchronize();
             std::vector<float> c(grid * 16);
             hipMemcpy(c.data(), dC, c.size() * 4, hipMemcpyDeviceToHost);
             for (int wv = 0; wv < 2; ++wv) {
                 double a[7] = {0, 0, 0, 0, 0, 0, 0};
                 for (int b = 0; b < grid; ++b) for (int k = 0; k < 7; ++k) a[k] += c[(b * 2 + wv) * 8 + k] / grid;
-                printf("1 WG/CU, grid %d, wave %d: per layer gemm %.0f  barrier %.0f  epilogue %.0f  barrier %.0f | layer-1 %.0f  head+io %.0f ticks, %.1f tiles/WG\n",
-                       grid, wv ? 5 : 0, a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+                printf("%s, grid %d, wave %d: per layer gemm %.0f  barrier %.0f  epilogue %.0f  barrier %.0f | layer-1 %.0f  head+io %.0f ticks, %.1f tiles/WG\n",
+                       lclk == lds ? "2 WG/CU" : "1 WG/CU", grid, wv ? 5 : 0, a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
             }
         }
     }
