@@ -829,7 +829,14 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         reinterpret_cast<f32x4*>(ssph)[i] = reinterpret_cast<const f32x4*>(kd.spheres)[i];
     for (int i = threadIdx.x; i < 24 * 16; i += blockDim.x) sb[i] = fr.bones[i];
     __syncthreads();
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // Sample lists are ray-major (64 consecutive entries ~ one ray from near to far).  Within a block of 512 entries a
+    // wave takes 8 runs of 8 consecutive entries, 64 apart: 8 neighbouring rays x 8 neighbouring depths instead of one
+    // ray end to end, so that its lanes walk (mostly) the same clusters.
+    const int t = threadIdx.x;
+    const int slot = SRC == SRC_SAMPLES ? ((t >> 3) & 7) * 64 + (t >> 6) * 8 + (t & 7) : t;
+    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + slot;
+        if (i >= n) continue;
         int id;
         const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
         nearest_invlbs_point<SRC, kClusterLds>(fr, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
