@@ -28,7 +28,7 @@ constexpr float kClampDist = 0.1f;     // RT:174
 constexpr int kBroydenSteps = 50;      // broyden.py:4
 constexpr float kDvg = 1.0f;
 constexpr int kMaxVerts = 6912;
-constexpr int kKnnThreads = 512;
+constexpr int kKnnThreads = 1024;      // 16 waves share the 119 KB vertex table: the walk is latency-bound
 constexpr int kMaxGrid = 512;          // persistent grid cap for the MFMA kernels: 256 CUs x (at most) 2 resident workgroups
 
 // ------------------------------------------------------------------------------------------
@@ -670,12 +670,25 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const K
         cnt = cl[0];
     }
     if (cnt != 255) {
-        int c = cl[1];
+        // four candidates at a time: their ids, spheres and lower bounds are independent loads / arithmetic, in flight
+        // together (the walk is latency-bound: ~2 waves per SIMD next to the 119 KB table); each bound is still
+        // compared against the running best at the moment its cluster comes up, so no extra cluster is scanned
 #pragma unroll 1
-        for (int k = 0; k < cnt; ++k) {
-            const int cn = cl[min(k + 2, 63)];   // next id in flight while this cluster is scanned
-            if (sphere_may_hold_nn(reinterpret_cast<const f32x4*>(ssph)[c], p, best)) scan_cluster<STRIDE>(sv, c, p, best, bi);
-            c = cn;
+        for (int k = 0; k < cnt; k += 4) {
+            int c[4];
+            float lb2[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = cl[min(1 + k + u, 63)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c[u]];
+                const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
+                const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - sp[3], 0.f);
+                lb2[u] = lb * lb;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k + u < cnt && lb2[u] <= best * 1.00001f + 1e-12f) scan_cluster<STRIDE>(sv, c[u], p, best, bi);
         }
     } else {   // outside the grid / overflowed cell: every cluster, same pruning
 #pragma unroll 1
@@ -833,7 +846,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
     // wave takes 8 runs of 8 consecutive entries, 64 apart: 8 neighbouring rays x 8 neighbouring depths instead of one
     // ray end to end, so that its lanes walk (mostly) the same clusters.
     const int t = threadIdx.x;
-    const int slot = SRC == SRC_SAMPLES ? ((t >> 3) & 7) * 64 + (t >> 6) * 8 + (t & 7) : t;
+    const int slot = SRC == SRC_SAMPLES ? (t & ~511) + ((t >> 3) & 7) * 64 + ((t >> 6) & 7) * 8 + (t & 7) : t;
     for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
         const int i = i0 + slot;
         if (i >= n) continue;
