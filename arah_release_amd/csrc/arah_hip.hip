@@ -202,7 +202,7 @@ __global__ void k_fold_film(const float* __restrict__ freq, const float* __restr
     fws[i] = (float)(f * c) * inv;
 }
 
-// Largest hidden activation of the skinning MLP (Softplus: h >= 0) per layer over a 17^3 lattice of the normalised
+// Largest hidden activation of the skinning MLP (Softplus: h >= 0) per layer over a 9^3 lattice of the normalised
 // cube [-1.5, 1.5]^3 -- query points are normalised to [-1, 1] over the padded body box (RFU:37-51), root-finding
 // iterates stray a little beyond.  One thread per lattice point, plain fp32 loops over the raw row-major weights.
 struct SkinRaw {
@@ -212,8 +212,8 @@ struct SkinRaw {
 __global__ __launch_bounds__(128) void k_skin_probe(SkinRaw net, unsigned* amax) {
     __shared__ float h[2][128];
     const int pt = blockIdx.x, c = threadIdx.x;
-    const float x = -1.5f + 3.0f * (float)(pt % 17) / 16.0f, y = -1.5f + 3.0f * (float)((pt / 17) % 17) / 16.0f,
-                z = -1.5f + 3.0f * (float)(pt / 289) / 16.0f;
+    const float x = -1.5f + 3.0f * (float)(pt % 9) / 8.0f, y = -1.5f + 3.0f * (float)((pt / 9) % 9) / 8.0f,
+                z = -1.5f + 3.0f * (float)(pt / 81) / 8.0f;
     float v = softplus100(net.w[0][c * 3] * x + net.w[0][c * 3 + 1] * y + net.w[0][c * 3 + 2] * z + net.b[0][c]);
     h[0][c] = v;
     float m = v;
@@ -2421,7 +2421,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
             raw.w[i] = nets->skin_w[i];
             raw.b[i] = nets->skin_b[i];
         }
-        hipLaunchKernelGGL(k_skin_probe, dim3(17 * 17 * 17), dim3(128), 0, s, raw, amax);
+        hipLaunchKernelGGL(k_skin_probe, dim3(9 * 9 * 9), dim3(128), 0, s, raw, amax);
         for (int i = 0; i < 4; ++i) {
             const int M = i < 3 ? 128 : 25, mt = i < 3 ? 8 : 2;
             hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, s, nets->skin_w[i + 1], M * 128, amax + 4 + i);
