@@ -21,8 +21,12 @@
 // Product fix: `no_pack()` in csrc/mlp.hpp after the K = 3 chains.  The split engine then runs two workgroups per
 // CU and is bit-reproducible (tests/test_hip_parity.py::test_render_is_reproducible_under_load).
 //
-// Also kept here: s_memtime phase clocks of the trunk on a CU-owning workgroup (k_trunk_clk), and of a two-tile
-// de-phased variant (k_pair_clk) that was tried while the one-workgroup-per-CU workaround was in place.
+// Also kept here, all bit-exact against the reference and none of them faster than two plain workgroups per CU
+// (0.76 ms for 400 k points): s_memtime phase clocks of the trunk (k_trunk_clk); a two-tile variant whose SIMD-mate
+// waves run GEMM and epilogue in opposite order (k_pair_clk, 0.90-1.0 ms); 16 waves in one workgroup, plain and skewed
+// by a phase (0.78 / 0.84 ms); and a two-tile variant with the epilogue of one tile interleaved INSIDE the GEMM loop
+// of the other in the same wave, with and without a 1 MFMA : 3 VALU sched_group_barrier pattern (k_pair_fused,
+// 0.89 ms, 256 VGPRs + spills).  In every arrangement kernel time ~ matrix-pipe time + vector-ALU time.
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -536,6 +540,143 @@ __global__ __launch_bounds__(1024) void k_trunk_16w_skew(SdfNet net, const float
     }
 }
 
+// ---- two tiles per workgroup, epilogue of one tile INTERLEAVED INSIDE the GEMM loop of the other (same wave) ----
+// Cross-wave overlap of VALU epilogues and MFMA GEMMs does not materialise on this part (kernel time ~ MFMA time +
+// VALU time in every arrangement measured above); within one wave, VALU instructions issued between MFMAs do run in
+// the MFMA's shadow.  Each kc chunk of tile X's GEMM (24 MFMAs) carries the FiLM-sine epilogue of one (m, n) group
+// of tile Y; sched_group_barrier asks for a 1 MFMA : 3 VALU issue pattern.
+template <bool DO_G, bool DO_E, bool HINT>
+__device__ __forceinline__ void fused_phase(const SdfNet& net, int kG, const float* actX, f32x4 (&accX)[2][4], int kE,
+                                            const f32x4 (&accY)[2][4], float* actY, int ld, int mt0, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 fwE[2], pwE[2];
+    if (DO_E) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            fwE[m] = *reinterpret_cast<const f32x4*>(net.fws + kE * 256 + ch0);
+            pwE[m] = *reinterpret_cast<const f32x4*>(net.pw + kE * 256 + ch0);
+        }
+    }
+    const char* bptr = reinterpret_cast<const char*>(actX) + j * ld * 4 + g * 16;
+    const f16x8* aptr = DO_G ? net.wps[kG - 1] + (size_t)mt0 * 8 * 2 * 64 + lane : nullptr;
+    f16x8 ah[2][2], al[2][2];
+    if (DO_G) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) zero_acc(accX[m][n]);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ah[0][m] = aptr[((m * 8) * 2 + 0) * 64];
+            al[0][m] = aptr[((m * 8) * 2 + 1) * 64];
+        }
+    }
+#pragma unroll
+    for (int kc = 0; kc < 8; ++kc) {
+        const int c = kc & 1, x = c ^ 1;
+        f16x8 bh[4], bl[4];
+        if (DO_G) {
+            if (kc + 1 < 8) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    ah[x][m] = aptr[((m * 8 + kc + 1) * 2 + 0) * 64];
+                    al[x][m] = aptr[((m * 8 + kc + 1) * 2 + 1) * 64];
+                }
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
+                bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + 512 + kc * 64);
+            }
+        }
+        f32x4 h, d;
+        if (DO_E) film_sine<false>(accY[kc >> 2][kc & 3], fwE[kc >> 2], pwE[kc >> 2], zero4, kActScale, h, d);
+        if (DO_G) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) accX[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[c][m], bh[n], accX[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) accX[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bl[n], accX[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) accX[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[c][m], bh[n], accX[m][n], 0, 0, 0);
+        }
+        if (DO_E) store_split4(actY, ld, 512, (kc & 3) * 16 + j, (mt0 + (kc >> 2)) * 16 + 4 * g, h);
+        if (DO_G && DO_E && HINT) {
+#pragma unroll
+            for (int q = 0; q < 24; ++q) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <bool HINT>
+__global__ __launch_bounds__(kThreads) void k_pair_fused(SdfNet net, const float* __restrict__ x, int n, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;
+    float* outv = xin + 128 * 4;
+    float* actA = outv + 128 * 4;
+    float* actB = actA + 64 * kSdfLd;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 15, g = lane >> 4, mt0 = wave * 2;
+    const int ld = kSdfLd;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    auto layer0 = [&](const float* xi, float* act) {
+        f32x4 xx[4];
+        for (int nn = 0; nn < 4; ++nn) xx[nn] = *reinterpret_cast<const f32x4*>(xi + (nn * 16 + j) * 4);
+        for (int m = 0; m < 2; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            f32x4 w[4];
+            for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+            for (int nn = 0; nn < 4; ++nn) {
+                f32x4 v, h, d;
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], xx[nn][2], fmaf(w[r][1], xx[nn][1], w[r][0] * xx[nn][0]));
+                no_pack(v);
+                film_sine<false>(v, fw, pw, zero4, kActScale, h, d);
+                store_split4(act, ld, 512, nn * 16 + j, ch0, h);
+            }
+        }
+    };
+    for (int tile = blockIdx.x; tile * 128 < n; tile += gridDim.x) {
+        if (tid < 128) {
+            const int i = tile * 128 + tid;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (i < n) v = f32x4{x[i * 3], x[i * 3 + 1], x[i * 3 + 2], 0.f};
+            reinterpret_cast<f32x4*>(xin)[tid] = v;
+        }
+        __syncthreads();
+        layer0(xin, actA);
+        layer0(xin + 256, actB);
+        __syncthreads();
+        f32x4 accA[2][4], accB[2][4];
+        fused_phase<true, false, HINT>(net, 1, actA, accA, 0, accB, actB, ld, mt0, lane);       // G(A,1)
+        __syncthreads();
+#pragma unroll 1
+        for (int k = 1; k < 6; ++k) {
+            fused_phase<true, true, HINT>(net, k, actB, accB, k, accA, actA, ld, mt0, lane);     // G(B,k) + E(A,k)
+            __syncthreads();
+            if (k < 5) fused_phase<true, true, HINT>(net, k + 1, actA, accA, k, accB, actB, ld, mt0, lane);   // G(A,k+1) + E(B,k)
+            else fused_phase<false, true, HINT>(net, 0, actA, accA, k, accB, actB, ld, mt0, lane);           // E(B,5)
+            __syncthreads();
+        }
+        sdf_head<true>(net, actA, ld, outv, 4, tid);
+        sdf_head<true>(net, actB, ld, outv + 256, 4, tid);
+        __syncthreads();
+        if (tid < 128 && tile * 128 + tid < n) out[tile * 128 + tid] = outv[tid * 4];
+        __syncthreads();
+    }
+}
+
 int main(int argc, char** argv) {
     const int n = 400000;
     unsigned s = 777;
@@ -666,6 +807,30 @@ int main(int argc, char** argv) {
             size_t bad = 0;
             for (int i = 0; i < n; ++i) bad += memcmp(&ref[i], &r1[i], 4) != 0;
             printf("16 waves, halves skewed by one step: %.3f ms, differs from the 1-WG/CU reference in %zu of %d\n", ms, bad, n);
+        }
+    }
+    {
+        const size_t lp = (128 * 4 * 2) * 4 + (size_t)128 * kSdfLd * 4;
+        std::vector<float> ref(n), r1(n);
+        k_trunk<true><<<256, kThreads, lds>>>(net, dX, n, dO);
+        hipDeviceSynchronize();
+        hipMemcpy(ref.data(), dO, n * 4, hipMemcpyDeviceToHost);
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        for (int hint = 0; hint < 2; ++hint) {
+            auto launch = [&](int grid) { if (hint) k_pair_fused<true><<<grid, kThreads, lp>>>(net, dX, n, dO); else k_pair_fused<false><<<grid, kThreads, lp>>>(net, dX, n, dO); };
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_pair_fused<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lp);
+            for (int grid : {256, 512}) {
+                hipMemset(dO, 0, n * 4);
+                launch(grid); hipDeviceSynchronize();
+                hipEventRecord(e0); launch(grid); hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                hipMemcpy(r1.data(), dO, n * 4, hipMemcpyDeviceToHost);
+                size_t bad = 0;
+                for (int i = 0; i < n; ++i) bad += memcmp(&ref[i], &r1[i], 4) != 0;
+                printf("two tiles, epilogue inside the GEMM loop (%s), grid %d: %.3f ms (%.0f TF algorithmic), differs from reference in %zu of %d\n",
+                       hint ? "1 MFMA : 3 VALU hint" : "compiler order", grid, ms, (double)n * 657408 / ms / 1e9, bad, n);
+            }
         }
     }
     run_dbg<4>("one-channel head", net, dX, n, dO, lds);
