@@ -11,6 +11,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC arah_hip.hip -o libarah_hip.so
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/arah_hip.h"
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_clusters(const GridInfo* 
     }
 }
 
-struct CanonRec {   // loop C's travelling per-point state (layout documented at k_canon_iter)
+struct CanonRec {   // loop C's travelling per-point state (layout documented above k_canon_mlp / k_canon_update)
     f32x4 r[10];
 };
 
