@@ -439,12 +439,15 @@ def test_split_engine_matches_exact_fp32_engine(scene):
 
 
 @gpu
-def test_render_is_reproducible_under_load(scene):
-    """Full-size frame, three renders with the same inputs: bit-identical.  (Guards the launch discipline of the
-    split engine -- one workgroup per CU; two co-resident workgroups gave irreproducible 16-point groups.)"""
+@pytest.mark.parametrize("engine", ["split", "fp32"])
+def test_render_is_reproducible_under_load(scene, engine):
+    """Full-size frame, three renders with the same inputs: bit-identical, on both GPU engines.  (The first
+    split-engine build was not: a K = 3 input layer that hipcc had packed into v_pk_fma_f32 + op_sel corrupted whole
+    16-point groups when two workgroups shared a CU -- see no_pack() in csrc/mlp.hpp.)"""
     from arah_release_amd import hip
     dev = torch.device("cuda:0")
-    frame, inputs, cfg = _frame_for(scene, "zju377_mono", 512, 11, None, dev)
+    prec = hip.PRECISION_SPLIT_F16 if engine == "split" else hip.PRECISION_FP32
+    frame, inputs, cfg = _frame_for(scene, "zju377_mono", 512, 11, prec, dev)
     ws = hip.Workspace(dev)
     samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
     pose = torch.eye(4)[:3]
