@@ -57,6 +57,19 @@ def test_struct_sizes_match_header():
     assert C.sizeof(hip.ArahCounters) == 64
 
 
+@pytest.mark.parametrize("name", ["gemm_f16x3", "trunk_repro", "gemm_loop", "mfma_f32_peak"])
+def test_microbenchmarks_compile(name, tmp_path):
+    """tools/ubench/*.hip include the product's mlp.hpp; keep them compiling for gfx950."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    src = os.path.join(REPO, "tools", "ubench", name + ".hip")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-c", src, "-o",
+                    str(tmp_path / (name + ".o"))], check=True, capture_output=True)
+
+
 def test_product_has_no_cpu_fallback():
     from arah_release_amd import hip
     if torch.cuda.is_available():
