@@ -691,10 +691,24 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const K
             for (int u = 0; u < 4; ++u)
                 if (k + u < cnt && lb2[u] <= best * 1.00001f + 1e-12f) scan_cluster<STRIDE>(sv, c[u], p, best, bi);
         }
-    } else {   // outside the grid / overflowed cell: every cluster, same pruning
+    } else {
+        // Outside the grid / overflowed cell: every cluster is a candidate, in k-d order -- not by distance, so the
+        // running best would tighten slowly and most clusters would be scanned (measured: ~150 of 256 per wave for
+        // the first sphere-tracing steps, whose points sit on the body's bounding box).  A first pass over the
+        // spheres gives the bound "some vertex is within d(centre) + r"; the second pass scans only the clusters whose
+        // sphere can beat it.  Still exact: the bound is attained by a vertex of a cluster that passes its own test.
+        float cap = best;
+#pragma unroll 4
+        for (int c = 0; c < g.n_clusters; ++c) {
+            const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c];
+            const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
+            const float ub = sqrtf(dx * dx + dy * dy + dz * dz) + sp[3];
+            cap = fminf(cap, ub * ub * 1.00001f);
+        }
 #pragma unroll 1
         for (int c = 0; c < g.n_clusters; ++c)
-            if (sphere_may_hold_nn(reinterpret_cast<const f32x4*>(ssph)[c], p, best)) scan_cluster<STRIDE>(sv, c, p, best, bi);
+            if (sphere_may_hold_nn(reinterpret_cast<const f32x4*>(ssph)[c], p, fminf(best, cap)))
+                scan_cluster<STRIDE>(sv, c, p, best, bi);
     }
     nearest_finish<SRC>(fr, sb, i, id, p, bi, idx_out, x_out, T_out, rec_out);
 }
