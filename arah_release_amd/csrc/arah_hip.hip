@@ -576,8 +576,8 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_clusters(const GridInfo* 
     }
 }
 
-struct CanonRec {   // loop C's travelling per-point state (layout documented above k_canon_mlp / k_canon_update)
-    f32x4 r[10];
+struct CanonSeed {   // loop C's start state of one sample: {x0(3), id | T0 row-major} (see k_canon_solve)
+    f32x4 r[5];
 };
 
 struct KnnData {
@@ -616,25 +616,18 @@ __device__ __forceinline__ bool sphere_may_hold_nn(const f32x4 s, V3 p, float be
 // blend the nearest vertex's weights, invert, write the outputs of one query
 template <int SRC>
 __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const float* sb, int i, int id, V3 p, int bi,
-                                               int* idx_out, float* x_out, float* T_out, CanonRec* rec_out) {
+                                               int* idx_out, float* x_out, float* T_out, CanonSeed* rec_out) {
     float T[16];
     blend(fr.vert_weights + (size_t)bi * 24, sb, T);
     V3 y = V3{p.x - fr.bc.trans[0], p.y - fr.bc.trans[1], p.z - fr.bc.trans[2]};
     V3 xh = inverse_affine_apply(T, y);
     if (SRC == SRC_RAYS) xh = normalize_pt(fr.bc, xh);
     if (idx_out) idx_out[id] = bi;
-    if (SRC == SRC_SAMPLES && rec_out) {   // loop C starts from here: the record IS the initial state
-        const f32x4 x = {xh.x, xh.y, xh.z, __int_as_float(id)};
-        const f32x4 zz = {0.f, 0.f, 0.f, 0.f};
-        CanonRec* r = rec_out + i;
-        r->r[0] = x;
-        r->r[1] = zz;
-        r->r[2] = zz;
-        r->r[3] = zz;
-        r->r[4] = zz;
-        r->r[5] = x;
+    if (SRC == SRC_SAMPLES && rec_out) {   // loop C starts from here: the seed IS the initial state
+        CanonSeed* r = rec_out + i;
+        r->r[0] = f32x4{xh.x, xh.y, xh.z, __int_as_float(id)};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) r->r[6 + c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
+        for (int c = 0; c < 4; ++c) r->r[1 + c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
         return;
     }
     x_out[(size_t)id * 3 + 0] = xh.x;
@@ -650,7 +643,7 @@ __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const float* 
 template <int SRC, int STRIDE>
 __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const KnnData& kd, const GridInfo& g,
                                                      const float* sv, const float* ssph, const float* sb, int i, int id,
-                                                     V3 p, int* idx_out, float* x_out, float* T_out, CanonRec* rec_out) {
+                                                     V3 p, int* idx_out, float* x_out, float* T_out, CanonSeed* rec_out) {
     float best = 3.4e38f;
     int bi = 0x7fffffff;
     if (SRC == SRC_RAYS && idx_out) {   // sphere tracing: the previous step's nearest vertex bounds the search
@@ -810,7 +803,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
                                                                    const float* depth, int n_steps, const int* list,
                                                                    const int* count, int n_direct, int wave_below,
                                                                    int* idx_out, float* x_out, float* T_out,
-                                                                   CanonRec* rec_out, unsigned long long* ctr) {
+                                                                   CanonSeed* rec_out, unsigned long long* ctr) {
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
     if (n >= wave_below) return;
     const GridInfo g = *kd.grid;
@@ -841,7 +834,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
                                                                  const float* depth, int n_steps, const int* list,
                                                                  const int* count, int n_direct, int wave_below,
                                                                  int* idx_out, float* x_out, float* T_out,
-                                                                 CanonRec* rec_out, unsigned long long* ctr) {
+                                                                 CanonSeed* rec_out, unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
     // ray / point lists are spread evenly over the grid (the table fill is per workgroup: one workgroup per CU,
@@ -1215,14 +1208,21 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
 }
 
 // ------------------------------------------------------------------------------------------
-// loop C: 3-D Broyden on g(x) = LBS(x) - target, one iteration per launch (RFU:267-362,
-// broyden.py:4-78).  The state of a live point is one 160-byte record that travels with it through
-// the ping-pong buffers in LIST ORDER: an iteration streams records in (coalesced), evaluates the
-// skinning MLP on 64 of them per tile, and streams the survivors out (ballot-compacted, coalesced).
-// Dense per-id outputs (best x, best T, |g|_best) are written exactly once, when a point retires.
-//   r0 = {x_eval(3), id}   r1 = {step(3), |g|_best}   r2 = {g(3), J0}   r3 = {J1..J4}   r4 = {J5..J8}
-//   r5 = {x_best(3), -}    r6..r9 = T_best (4x4 row-major)
-// FIRST: evaluates g(x0), derives J^-1_0 from the same weights (RFU:327); nobody retires.
+// loop C: 3-D Broyden on g(x) = LBS(x) - target (RFU:267-362, broyden.py:4-78) as ONE resident kernel.
+//
+// A workgroup keeps 64 SLOTS (= the 64 columns of its MFMA tile).  Every pass of its loop evaluates the skinning
+// MLP on the 64 slots (8 waves, split or exact engine), then the four lanes {j, j+16, j+32, j+48} of wave n < 4
+// finish slot 16 n + j: hierarchical softmax, row g = lane >> 4 of the blended transform, residual, best iterate and
+// the "good Broyden" bookkeeping.  The whole Broyden state of a point (x, step, g, J^-1, best x / T, |g|_best: 44
+// floats) lives in the workgroup's LDS from the moment the point enters a slot until it retires; from HBM nothing
+// but the 80-byte seed is read and nothing but the final best iterate (x, T, |g|) is written, exactly once.
+// A slot whose point retires (converged / diverged / 1 + 50 evaluations) is refilled in the same pass from the
+// launch-wide queue of seeds (one atomic per 64 seeds and wave), so tiles stay full while points need different
+// numbers of iterations (mean 3.7, a fraction of a percent the full 51), and there is no per-iteration launch.
+// Per-point arithmetic does not depend on the slot or on its neighbours: results are deterministic although the
+// schedule is not.
+//   seed = {x0(3), id | T0 (4x4 row-major)}: nearest-vertex start (RT:403-422) written by k_nearest_invlbs<SAMPLES>
+//          or k_canon_seed.  T0 doubles as the initial best T (broyden.py:41).
 // ------------------------------------------------------------------------------------------
 struct TargetSrc {
     const float* tgt;     // explicit [Q][3] or null
@@ -1243,199 +1243,278 @@ struct CanonOut {
     float* err;    // [Q]
 };
 
-__device__ __forceinline__ void canon_flush(const CanonOut& o, int id, const f32x4 xb, const f32x4 (&Tb)[4], float eb) {
-    o.pts[(size_t)id * 3] = xb[0];
-    o.pts[(size_t)id * 3 + 1] = xb[1];
-    o.pts[(size_t)id * 3 + 2] = xb[2];
+constexpr int kSeedChunk = 64;   // seeds a wave takes from the queue per atomic
+
+// 25 raw logits of a slot -> 24 weights in registers; the four lanes of the slot share the 25 sigmoids through the
+// slot's LDS row (in place).  Same arithmetic as hsoftmax<float>(20 * logits).
+__device__ __forceinline__ void hsoftmax_quad(float* row, int g, float (&w)[24]) {
+    float ra, rb, rc, sa, sb, sc;
+    softmax3<float>(row[1] * 20.0f, row[2] * 20.0f, row[3] * 20.0f, ra, rb, rc);
+    softmax3<float>(row[12] * 20.0f, row[13] * 20.0f, row[14] * 20.0f, sa, sb, sc);
+    float sg_own[7];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) reinterpret_cast<f32x4*>(o.T + (size_t)id * 16)[c] = Tb[c];
-    o.err[id] = eb;
-}
-
-constexpr int kLogitOut = 28;   // floats per point in the logit stream (25 valid; 7 x 16 bytes)
-
-// Pass 1 of an iteration -- the matrix-core part: skinning-MLP logits of every live record, in list order.
-template <int NT, bool SPLIT>
-__device__ __forceinline__ void canon_mlp_tiles(const FrameDev& fr, const CanonRec* __restrict__ rin, int n,
-                                                float* __restrict__ lg, unsigned long long* ctr, float* smem) {
-    constexpr int TW = 16 * NT;
-    float* xin = smem;                        // [64][4] normalised
-    float* logits = xin + 64 * 4;             // [64][33]
-    float* act = logits + 64 * kLogitLd;      // 64*33 floats is a multiple of 4: stays 16-byte aligned
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
-        if (tid < TW) {
-            const int i = tile * TW + tid;
-            f32x4 r0 = {0.f, 0.f, 0.f, 0.f};
-            if (i < n) r0 = rin[i].r[0];
-            const V3 q = normalize_pt(fr.bc, V3{r0[0], r0[1], r0[2]});
-            reinterpret_cast<f32x4*>(xin)[tid] = f32x4{q.x, q.y, q.z, 0.f};
+    for (int k = 0; k < 7; ++k) sg_own[k] = sigm(row[min(g + 4 * k, 24)] * 20.0f);
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+        if (g + 4 * k < 25) row[g + 4 * k] = sg_own[k];
+    // the four lanes are in one wave: LDS operations of a wave complete in order, only the compiler must not move
+    // the reads below above the writes
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    float sgm[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) sgm[i] = row[i];
+    const float g0 = sgm[0];
+    w[1] = g0 * ra;
+    w[2] = g0 * rb;
+    w[3] = g0 * rc;
+    w[0] = 1.0f - g0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float q = sgm[4 + k];
+        w[4 + k] = w[1 + k] * q;
+        w[1 + k] = w[1 + k] * (1.0f - q);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float q = sgm[7 + k];
+        w[7 + k] = w[4 + k] * q;
+        w[4 + k] = w[4 + k] * (1.0f - q);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float q = sgm[10 + k];
+        w[10 + k] = w[7 + k] * q;
+        w[7 + k] = w[7 + k] * (1.0f - q);
+    }
+    const float g24 = sgm[24];
+    w[12] = w[9] * g24 * sa;
+    w[13] = w[9] * g24 * sb;
+    w[14] = w[9] * g24 * sc;
+    w[9] = w[9] * (1.0f - g24);
+    {
+        const float q = sgm[15];
+        w[15] = w[12] * q;
+        w[12] = w[12] * (1.0f - q);
+    }
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl) {   // 13,14 -> 16,17 -> 18,19 -> 20,21 -> 22,23
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int p = (lvl == 0 ? 13 : 14 + 2 * lvl) + k, c = 16 + 2 * lvl + k;
+            const float q = sgm[c];
+            w[c] = w[p] * q;
+            w[p] = w[p] * (1.0f - q);
         }
-        __syncthreads();
-        skin_mlp<NT, SPLIT>(fr.skin, xin, act, logits, wave, lane);
-        if (tid == 0) count_add(ctr, min(TW, n - tile * TW));
-        const int cnt = min(TW, n - tile * TW) * kLogitOut;
-        float* dst = lg + (size_t)tile * TW * kLogitOut;
-        for (int e = tid; e < cnt; e += kThreads) dst[e] = logits[(e / kLogitOut) * kLogitLd + e % kLogitOut];
-        __syncthreads();
     }
 }
+
+// per-slot state block in LDS (floats): the Broyden state of the point in the slot between two passes
+enum { ST_X = 0, ST_STEP = 3, ST_G = 6, ST_XB = 9, ST_J = 12, ST_EB = 21, ST_TG = 22, ST_ID = 25, ST_NEV = 26, ST_SIZE = 27 };   // odd stride: slots on distinct banks
+constexpr size_t kLdsCanonSolve =
+    (64 * 4 + 64 * kLogitLd + 24 * 16 + 16 + 64 * ST_SIZE + 64 * 16) * 4 + (size_t)64 * kSkinLd * 4;
 
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, 4) void k_canon_mlp(FrameDev fr, const CanonRec* __restrict__ rin,
-                                                                       const int* count, float* __restrict__ lg,
-                                                                       unsigned long long* ctr) {
+__global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const f32x4* __restrict__ seeds,
+                                                             const int* count, int* queue_head, TargetSrc ts,
+                                                             CanonOut outp, unsigned long long* ctr) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;                        // [64][4] normalised
+    float* logits = xin + 64 * 4;             // [64][33]
+    float* sbones = logits + 64 * kLogitLd;   // [24][16]; 64*33 floats is a multiple of 4: stays 16-byte aligned
+    int* alive = reinterpret_cast<int*>(sbones + 24 * 16);   // [4] owner waves with a live slot (+ pad to 16)
+    float* state = reinterpret_cast<float*>(alive + 16);     // [64][ST_SIZE]
+    float* tbest = state + 64 * ST_SIZE;                     // [64][16] best T so far
+    float* act = tbest + 64 * 16;                            // [64][132]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int j = lane & 15, g = lane >> 4;
+    const bool owner = wave < 4;
+    const int slot = (wave & 3) * 16 + j;
+    float* row = logits + slot * kLogitLd;
+    float* st = state + slot * ST_SIZE;
+    int* sti = reinterpret_cast<int*>(st);
+    f32x4* tb = reinterpret_cast<f32x4*>(tbest + slot * 16) + g;   // this lane's row of the slot's best T
     const int n = *count;
-    if (n < kNarrowBelow) canon_mlp_tiles<1, SPLIT>(fr, rin, n, lg, ctr, smem);
-    else canon_mlp_tiles<kNT, SPLIT>(fr, rin, n, lg, ctr, smem);
-}
-
-// Pass 2 -- one thread per record, at full occupancy: weights, blended transform, residual, Broyden bookkeeping,
-// and the ballot-compacted stream of survivors (broyden.py:41-75).  The per-point code is latency-bound
-// (sequential softmax tree, 24-joint blend, dependent record reads); run by one wave per 64-point MFMA tile it
-// kept the matrix pipe idle for a third of loop C.
-constexpr int kUpdThreads = 256;
-template <bool FIRST>
-__global__ __launch_bounds__(kUpdThreads) void k_canon_update(FrameDev fr, const CanonRec* __restrict__ rin,
-                                                              CanonRec* __restrict__ rout,
-                                                              const float* __restrict__ lg, const int* count,
-                                                              int* next_count, TargetSrc ts, CanonOut outp) {
-    __shared__ float sbones[24 * 16];
-    __shared__ float srow[kUpdThreads * kLogitLd];
-    const int tid = threadIdx.x, lane = tid & 63;
-    for (int i = tid; i < 24 * 16; i += kUpdThreads) sbones[i] = fr.bones[i];
-    __syncthreads();
-    const int n = *count;
-    float* row = srow + tid * kLogitLd;
-    for (int base_i = blockIdx.x * kUpdThreads; base_i < n; base_i += gridDim.x * kUpdThreads) {   // wave-uniform trip count
-        const int i = base_i + tid;
-        const bool live = i < n;
-        f32x4 r0 = {0.f, 0.f, 0.f, __int_as_float(-1)};
-        if (live) {
-            r0 = rin[i].r[0];
-            const f32x4* src = reinterpret_cast<const f32x4*>(lg + (size_t)i * kLogitOut);
-#pragma unroll
-            for (int c = 0; c < kLogitOut / 4; ++c) {
-                const f32x4 v = src[c];
-                row[c * 4] = v[0];
-                row[c * 4 + 1] = v[1];
-                row[c * 4 + 2] = v[2];
-                row[c * 4 + 3] = v[3];
-            }
-        }
-        const int id = live ? __float_as_int(r0[3]) : -1;
-        const V3 x = V3{r0[0], r0[1], r0[2]};
-        bool keep = false, improved = false;
-        float T[16], gx[3], dg[3], dx[3], eb = 0.f;
-        if (id >= 0) {
-            f32x4 r1, r2;
-            if (!FIRST) {
-                r1 = rin[i].r[1];
-                r2 = rin[i].r[2];
-            }
-            V3 xbar;
-            skin_tail(row, sbones, x, T, xbar);
-            const V3 tg = target_of(ts, fr.bc, id);
-            const float gnew[3] = {xbar.x - tg.x, xbar.y - tg.y, xbar.z - tg.z};
-            if (FIRST) {
-#pragma unroll
-                for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
-                eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                keep = true;                                        // every point takes at least one step
-            } else {
-                eb = r1[3];
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    dx[r] = r1[r];
-                    dg[r] = gnew[r] - r2[r];
-                    gx[r] = r2[r] + dg[r];                          // broyden.py:50-51
+    for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
+    if (owner && g == 0) sti[ST_ID] = -1;
+    int q_pos = 0, q_end = 0;        // this wave's private piece of the queue (wave-uniform)
+    bool exhausted = n <= 0;
+    int n_eval = 0;
+    for (;;) {
+        if (owner) {
+            // ---- refill the empty slots of this wave (LDS operations of one wave complete in order)
+            int id = sti[ST_ID];
+            const unsigned long long m = __ballot(id < 0) & 0xffffull;   // lanes 0..15 speak for their slots
+            int need = __popcll(m);
+            const int rank = __popcll(m & ((1ull << j) - 1ull));
+            int src = -1, given = 0;
+            while (need > 0 && !exhausted) {   // wave-uniform
+                if (q_pos == q_end) {
+                    int p = 0;
+                    if (lane == 0) p = atomicAdd(queue_head, kSeedChunk);
+                    p = __builtin_amdgcn_readfirstlane(p);
+                    if (p >= n) {
+                        exhausted = true;
+                        break;
+                    }
+                    q_pos = p;
+                    q_end = min(p + kSeedChunk, n);
                 }
-                const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                improved = err < eb;                                // broyden.py:54-61
-                if (improved) eb = err;
-                keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
+                const int take = min(q_end - q_pos, need);
+                if (id < 0 && rank >= given && rank < given + take) src = q_pos + (rank - given);
+                q_pos += take;
+                given += take;
+                need -= take;
             }
-        }
-        // survivors get their slot in the output stream now, so that the record can be written piece by piece
-        const unsigned long long m = __ballot(keep);
-        int base = 0;
-        if (lane == 0 && m) base = atomicAdd(next_count, __popcll(m));
-        base = __shfl(base, 0);
-        CanonRec* dst = rout + base + __popcll(m & ((1ull << lane) - 1ull));
-        if (id >= 0) {
-            // best iterate: the new one if it improved, else carried over (FIRST: x0 and the nearest-vertex T0,
-            // broyden.py:41); retiring points hand it in
-            f32x4 xb, Tb[4];
-            if (improved) {
-                xb = f32x4{x.x, x.y, x.z, 0.f};
+            if (src >= 0) {
+                const f32x4 s0 = seeds[(size_t)src * 5];
+                *tb = seeds[(size_t)src * 5 + 1 + g];      // T0 doubles as the initial best T (broyden.py:41)
+                id = __float_as_int(s0[3]);
+                if (g == 0) {
+                    const V3 tg = target_of(ts, fr.bc, id);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Tb[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
-            } else {
-                xb = rin[i].r[5];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) Tb[c] = rin[i].r[6 + c];
-            }
-            if (keep) {
-                dst->r[5] = xb;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dst->r[6 + c] = Tb[c];
-            } else {
-                canon_flush(outp, id, xb, Tb, eb);
-            }
-        }
-        if (keep) {
-            float J[9], stp[3];
-            if (FIRST) {
-                inv3_of44(T, J);                                    // RFU:327-328
-#pragma unroll
-                for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
-            } else {
-                const f32x4 r2 = rin[i].r[2], r3 = rin[i].r[3], r4 = rin[i].r[4];
-                J[0] = r2[3];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    J[1 + e] = r3[e];
-                    J[5 + e] = r4[e];
+                    for (int r = 0; r < 3; ++r) {
+                        st[ST_X + r] = s0[r];
+                        st[ST_XB + r] = s0[r];
+                    }
+                    st[ST_TG] = tg.x;
+                    st[ST_TG + 1] = tg.y;
+                    st[ST_TG + 2] = tg.z;
+                    sti[ST_ID] = id;
+                    sti[ST_NEV] = 0;
                 }
-                broyden_update<3>(J, dx, dg, gx, stp);
             }
-            dst->r[0] = f32x4{x.x + stp[0], x.y + stp[1], x.z + stp[2], r0[3]};
-            dst->r[1] = f32x4{stp[0], stp[1], stp[2], eb};
-            dst->r[2] = f32x4{gx[0], gx[1], gx[2], J[0]};
-            dst->r[3] = f32x4{J[1], J[2], J[3], J[4]};
-            dst->r[4] = f32x4{J[5], J[6], J[7], J[8]};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (g == 0) {
+                f32x4 xn = {0.f, 0.f, 0.f, 0.f};
+                if (id >= 0) {
+                    const V3 q = normalize_pt(fr.bc, V3{st[ST_X], st[ST_X + 1], st[ST_X + 2]});
+                    xn = f32x4{q.x, q.y, q.z, 0.f};
+                }
+                reinterpret_cast<f32x4*>(xin)[slot] = xn;
+            }
+            const unsigned long long live = __ballot(id >= 0) & 0xffffull;
+            if (lane == 0) alive[wave] = live != 0ull;
+            n_eval += __popcll(live);
         }
-    }
-}
-
-// records still alive after the last iteration hand in their best iterate
-__global__ void k_canon_drain(const CanonRec* __restrict__ rin, const int* count, CanonOut outp) {
-    const int n = *count;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const f32x4 r0 = rin[i].r[0];
-        f32x4 Tb[4];
+        __syncthreads();
+        if (!(alive[0] | alive[1] | alive[2] | alive[3])) break;
+        skin_mlp<kNT, SPLIT>(fr.skin, xin, act, logits, wave, lane);   // ends with a barrier
+        if (owner) {
+            // ---- weights, row g of T = sum_j w_j A_j, x_bar, residual
+            f32x4 Trow = {0.f, 0.f, 0.f, 0.f};
+            {
+                float w[24];
+                hsoftmax_quad(row, g, w);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Tb[c] = rin[i].r[6 + c];
-        canon_flush(outp, __float_as_int(r0[3]), rin[i].r[5], Tb, rin[i].r[1][3]);
+                for (int jn = 0; jn < 24; ++jn) {
+                    if ((jn & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // four bone rows in flight, not all 24 (VGPRs)
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sbones + jn * 16 + g * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Trow[c] = fmaf(w[jn], b[c], Trow[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int id = sti[ST_ID];
+            const int nev = sti[ST_NEV];
+            const float x0 = st[ST_X], x1 = st[ST_X + 1], x2 = st[ST_X + 2];
+            const float xbar_g = fmaf(Trow[0], x0, fmaf(Trow[1], x1, fmaf(Trow[2], x2, Trow[3])));
+            const float gn_g = xbar_g - st[ST_TG + min(g, 2)];
+            float gnew[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) gnew[r] = __shfl(gn_g, j + 16 * r);
+            const bool first = nev == 0;
+            float J[9];
+            if (__any(id >= 0 && first)) {   // wave-uniform: J^-1_0 = (T[:3,:3])^-1 from the same weights (RFU:327-328)
+                float T9[16];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) T9[r * 4 + c] = __shfl(Trow[c], j + 16 * r);
+                inv3_of44(T9, J);
+            }
+            int flags = 0;   // bit 0: keep, bit 1: improved
+            if (g == 0 && id >= 0) {
+                float gx[3], stp[3], eb;
+                bool keep, improved = false;
+                if (first) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
+                    eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                    keep = true;                                        // every point takes at least one step
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
+                } else {
+                    float dg[3], dxv[3];
+                    eb = st[ST_EB];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float gp = st[ST_G + r];
+                        dxv[r] = st[ST_STEP + r];
+                        dg[r] = gnew[r] - gp;
+                        gx[r] = gp + dg[r];                             // broyden.py:50-51
+                    }
+                    const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                    improved = err < eb;                                // broyden.py:54-61
+                    if (improved) {
+                        eb = err;
+                        st[ST_XB] = x0;
+                        st[ST_XB + 1] = x1;
+                        st[ST_XB + 2] = x2;
+                    }
+                    keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
+                    if (keep) {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) J[e] = st[ST_J + e];
+                        broyden_update<3>(J, dxv, dg, gx, stp);          // broyden.py:69-75
+                    }
+                }
+                if (nev + 1 > kBroydenSteps) keep = false;              // 1 + 50 evaluations (broyden.py:44)
+                sti[ST_NEV] = nev + 1;
+                st[ST_EB] = eb;
+                if (keep) {
+                    st[ST_X] = x0 + stp[0];
+                    st[ST_X + 1] = x1 + stp[1];
+                    st[ST_X + 2] = x2 + stp[2];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        st[ST_STEP + r] = stp[r];
+                        st[ST_G + r] = gx[r];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) st[ST_J + e] = J[e];
+                }
+                flags = (keep ? 1 : 0) | (improved ? 2 : 0);
+            }
+            flags = __shfl(flags, j);
+            if (flags & 2) *tb = Trow;
+            if (id >= 0 && !(flags & 1)) {   // retire: the best iterate is the result (broyden.py:78)
+                reinterpret_cast<f32x4*>(outp.T + (size_t)id * 16)[g] = *tb;
+                if (g == 0) {
+                    outp.pts[(size_t)id * 3] = st[ST_XB];
+                    outp.pts[(size_t)id * 3 + 1] = st[ST_XB + 1];
+                    outp.pts[(size_t)id * 3 + 2] = st[ST_XB + 2];
+                    outp.err[id] = st[ST_EB];
+                    sti[ST_ID] = -1;
+                }
+            }
+        }
+        __syncthreads();   // logits rows / alive flags are rewritten by the next pass
     }
+    if (owner && lane == 0) count_add(ctr, n_eval);
 }
 
-// initial records from (x0, T0) stored densely by id: rec[i] = {x0, id, ..., best = (x0, T0)}
-__global__ void k_canon_seed(const int* list, const int* count, const float* x0, const float* T0, CanonRec* rout) {
+// seeds from (x0, T0) stored densely by id: seed[i] = {x0, id | T0}
+__global__ void k_canon_seed(const int* list, const int* count, const float* x0, const float* T0, f32x4* seeds) {
     const int n = *count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int id = list[i];
-        const f32x4 x = {x0[(size_t)id * 3], x0[(size_t)id * 3 + 1], x0[(size_t)id * 3 + 2], __int_as_float(id)};
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rout[i].r[0] = x;
-        rout[i].r[1] = z;
-        rout[i].r[2] = z;
-        rout[i].r[3] = z;
-        rout[i].r[4] = z;
-        rout[i].r[5] = x;
+        seeds[(size_t)i * 5] = f32x4{x0[(size_t)id * 3], x0[(size_t)id * 3 + 1], x0[(size_t)id * 3 + 2], __int_as_float(id)};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) rout[i].r[6 + c] = reinterpret_cast<const f32x4*>(T0 + (size_t)id * 16)[c];
+        for (int c = 0; c < 4; ++c) seeds[(size_t)i * 5 + 1 + c] = reinterpret_cast<const f32x4*>(T0 + (size_t)id * 16)[c];
     }
 }
 
@@ -1800,7 +1879,7 @@ __device__ __forceinline__ float volsdf_density(float sdf, float inv_beta) {
 template <bool SPLIT>
 __global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
                                                        f32x4* shaded, int* next_list, int* next_count,
-                                                       unsigned long long* ctr_fwd) {
+                                                       unsigned long long* ctr_fwd, unsigned long long* ctr_dens) {
     constexpr int TW = kTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                                   // [TW][4]
@@ -1825,7 +1904,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const floa
         sdf_trunk<false, kNT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
         sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid);
         __syncthreads();
-        if (tid == 0) count_add(ctr_fwd, min(TW, n - tile * TW));
+        if (tid == 0) {
+            count_add(ctr_fwd, min(TW, n - tile * TW));
+            count_add(ctr_dens, min(TW, n - tile * TW));
+        }
         if (tid < TW) {   // whole waves: TW is a multiple of 64
             const int id = ids[tid];
             bool keep = false;
@@ -2055,11 +2137,8 @@ __global__ void k_composite(int n, int S, int render_last_pt, const float* z, co
 }
 
 // IDR:114-115, 142-143, 251: camera-space surface points, zeroed off-surface
-struct Pose34 {
-    float m[12];
-};
 __global__ void k_points_cam(FrameDev fr, int n, RaySet rs, const float* dists, const uint8_t* conv,
-                             const float* points_hat_norm, Pose34 pose, float* points_cam) {
+                             const float* points_hat_norm, const float* __restrict__ pose, float* points_cam) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const V3 pw = ray_point(rs, i, dists[i]);
@@ -2069,7 +2148,7 @@ __global__ void k_points_cam(FrameDev fr, int n, RaySet rs, const float* dists, 
                 az = fabsf(points_hat_norm[(size_t)i * 3 + 2]);
     const bool surf = conv[i] && ax <= 1.0f && ay <= 1.0f && az <= 1.0f;
     for (int r = 0; r < 3; ++r) {
-        const float v = pose.m[r * 4] * wx + pose.m[r * 4 + 1] * wy + pose.m[r * 4 + 2] * wz + pose.m[r * 4 + 3];
+        const float v = pose[r * 4] * wx + pose[r * 4 + 1] * wy + pose[r * 4 + 2] * wz + pose[r * 4 + 3];
         points_cam[(size_t)i * 3 + r] = surf ? v : 0.f;
     }
 }
@@ -2109,8 +2188,7 @@ struct Workspace {
     uint8_t* o_conv;
     // per sample
     float* q_err;
-    CanonRec *recA, *recB;
-    float* logit;         // [Q][kLogitOut] logit stream between the two passes of a loop-C iteration
+    CanonSeed* seeds;     // [Q] start states of loop C, in list order
     float *o_z, *o_pts, *o_T;
     uint8_t* o_mask;
     uint8_t* q_smask;
@@ -2152,9 +2230,7 @@ Workspace carve(void* base, int n_rays, int n_steps) {
     w.listA = c.take<int>(Q);
     w.listB = c.take<int>(Q);
     w.q_err = c.take<float>(Q);
-    w.recA = c.take<CanonRec>(Q);
-    w.recB = c.take<CanonRec>(Q);
-    w.logit = c.take<float>(Q * kLogitOut);
+    w.seeds = c.take<CanonSeed>(Q);
     w.o_z = c.take<float>(Q);
     w.o_pts = c.take<float>(Q * 3);
     w.o_T = c.take<float>(Q * 16);
@@ -2187,7 +2263,6 @@ inline int env_int(const char* name, int dflt) {
 // dynamic LDS sizes (bytes)
 constexpr size_t kLdsSdfFwd = (64 * 4 * 2 + 64) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsSdfGrad = kLdsSdfFwd + (size_t)64 * kSdfLd * 4;
-constexpr size_t kLdsCanonMlp = (64 * 4 + 64 * kLogitLd) * 4 + (size_t)64 * kSkinLd * 4;
 constexpr size_t kLdsSkin = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSkinLd * 4;
 constexpr size_t kLdsJoint = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsKnn = ((size_t)kMaxClusters * kClusterLds * 4 + kMaxClusters * 4 + 24 * 16) * 4;
@@ -2219,15 +2294,23 @@ constexpr size_t kLdsSplitSolo = 84 * 1024;
         else hipLaunchKernelGGL(KE, GRID, BLOCK, LDS, __VA_ARGS__);                      \
     } while (0)
 
+// hipFuncSetAttribute is per DEVICE: the raised dynamic-LDS limits are set once for every device ordinal a call
+// arrives on (the current device at the time of the call -- the host binding makes the buffers' device current).
+bool g_attr_failed = false;
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)bytes) != hipSuccess)
+        g_attr_failed = true;
 }
 
-void setup_attributes() {
-    static bool done = false;
-    if (done) return;
-    done = true;
+int setup_attributes() {
+    constexpr int kMaxDevices = 64;
+    static bool done[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return ARAH_E_LAUNCH;
+    if (done[dev]) return ARAH_OK;
+    g_attr_failed = false;
     allow_lds(k_nearest_invlbs<SRC_POINTS>, kLdsKnn);
     allow_lds(k_nearest_invlbs<SRC_RAYS>, kLdsKnn);
     allow_lds(k_nearest_invlbs<SRC_SAMPLES>, kLdsKnn);
@@ -2241,8 +2324,8 @@ void setup_attributes() {
     allow_lds(k_density<true>, kLdsSplitSolo);
     allow_lds(k_skin_eval, kLdsSkin);
     allow_lds(k_skin_jac, kLdsSkin);
-    allow_lds(k_canon_mlp<false>, kLdsCanonMlp);
-    allow_lds(k_canon_mlp<true>, kLdsSplitSolo);
+    allow_lds(k_canon_solve<false>, kLdsCanonSolve);
+    allow_lds(k_canon_solve<true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<true, false>, kLdsJoint);
     allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<false, false>, kLdsJoint);
@@ -2253,6 +2336,9 @@ void setup_attributes() {
     allow_lds(k_shade<true, true>, lds_shade<true>());
     allow_lds(k_color_eval<false>, lds_color<false>());
     allow_lds(k_color_eval<true>, lds_color<true>());
+    if (g_attr_failed) return ARAH_E_LAUNCH;
+    done[dev] = true;
+    return ARAH_OK;
 }
 
 // optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
@@ -2266,7 +2352,7 @@ KnnData knn_of(const FrameDev& fd) {
 template <int SRC>
 void launch_nearest(hipStream_t s, const FrameDev& fd, long long n_max, const float* pts, const RaySet& rs,
                     const float* depth, int n_steps, const int* list, const int* count, int n_direct, int* idx_out,
-                    float* x_out, float* T_out, CanonRec* rec_out, unsigned long long* ctr) {
+                    float* x_out, float* T_out, CanonSeed* rec_out, unsigned long long* ctr) {
     // list lengths below which one wave per query beats one thread per query (measured)
     // 512x512 frame: sphere-tracing lists (<= 1.5e5 rays, shrinking) 68.0 -> 65.4 ms per frame with the wave kernel below
     // 16k..64k entries; the 8.6e6-sample list of loop C wants the LDS table (86 ms when forced onto the wave kernel)
@@ -2401,7 +2487,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     if (nets->precision != ARAH_PRECISION_SPLIT_F16 && nets->precision != ARAH_PRECISION_FP32) return ARAH_E_BADARG;
     const FrameLayout L = frame_layout(nets->col_mode);
     if (frame_bytes < L.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* base = reinterpret_cast<char*>(frame_buf);
     auto P = [&](size_t off) { return reinterpret_cast<float*>(base + off); };
@@ -2572,7 +2658,7 @@ int arah_sdf_eval(const ArahFrame* f, const float* x_norm, int32_t n, float* sdf
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev fd = to_dev(*f);
     const int g = grid_for(n, kTile);
@@ -2593,7 +2679,7 @@ int arah_skin_lbs(const ArahFrame* f, const float* x_hat, int32_t n, float* wout
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipLaunchKernelGGL(k_skin_eval, dim3(grid_for(n, kTile)), dim3(kThreads), kLdsSkin,
                        reinterpret_cast<hipStream_t>(stream), to_dev(*f), x_hat, n, wout, x_bar, T, &w.ctr->n_skin_fwd);
     return check_launch();
@@ -2605,7 +2691,7 @@ int arah_skin_jacobian(const ArahFrame* f, const float* x_hat, int32_t n, float*
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipLaunchKernelGGL(k_skin_jac, dim3(grid_for(n, 16)), dim3(kThreads), kLdsSkin,
                        reinterpret_cast<hipStream_t>(stream), to_dev(*f), x_hat, (const int*)nullptr,
                        (const int*)nullptr, n, jac, &w.ctr->n_skin_jac);
@@ -2619,7 +2705,7 @@ int arah_color_eval(const ArahFrame* f, const float* x_norm, const float* normal
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev fd = to_dev(*f);
     if (f->col_mode == ARAH_COLOR_IDR)
@@ -2637,39 +2723,27 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     RaySet rs = make_rays(nullptr, nullptr, 1);
     launch_nearest<SRC_POINTS>(reinterpret_cast<hipStream_t>(stream), to_dev(*f), n, pts, rs, (const float*)nullptr, 1,
-                               (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, (CanonRec*)nullptr,
+                               (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, (CanonSeed*)nullptr,
                                &w.ctr->n_knn);
     return check_launch();
 }
 
-// shared driver of loop C: (x0, T0) are stored densely by id in out.pts / out.T for every id in listA
+// shared driver of loop C.  seeded: w.seeds[0 .. cnt[0]) are already written (k_nearest_invlbs<SAMPLES>); otherwise
+// (x0, T0) are stored densely by id in out.pts / out.T for every id in listA.  w.counts: [0] = number of seeds,
+// [1] = head of the seed queue (zeroed by the caller's memset of w.counts).
 static int run_broyden3(const FrameDev& fd, Workspace& w, TargetSrc ts, CanonOut outp, long long max_pts,
                         bool seeded, hipStream_t s) {
-    int* cnt = w.counts;   // cnt[it] = number of records consumed by iteration it
-    const int g = grid_for(max_pts, kTile);
-    long long gu_ll = (max_pts + kUpdThreads - 1) / kUpdThreads;
-    const int gu = (int)(gu_ll < 1 ? 1 : (gu_ll > 4096 ? 4096 : gu_ll));
+    int* cnt = w.counts;
     if (!seeded)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
-                           (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, w.recA);
-    for (int it = 0; it <= kBroydenSteps; ++it) {
-        const CanonRec* rin = (it & 1) ? w.recB : w.recA;
-        CanonRec* rout = (it & 1) ? w.recA : w.recB;
-        LAUNCH_ENGINE(fd.split, k_canon_mlp<true>, k_canon_mlp<false>, dim3(g), dim3(kThreads), kLdsCanonMlp, s, fd, rin,
-                      (const int*)&cnt[it], w.logit, &w.ctr->n_skin_fwd);
-        if (it == 0)
-            hipLaunchKernelGGL(k_canon_update<true>, dim3(gu), dim3(kUpdThreads), 0, s, fd, rin, rout,
-                               (const float*)w.logit, (const int*)&cnt[it], &cnt[it + 1], ts, outp);
-        else
-            hipLaunchKernelGGL(k_canon_update<false>, dim3(gu), dim3(kUpdThreads), 0, s, fd, rin, rout,
-                               (const float*)w.logit, (const int*)&cnt[it], &cnt[it + 1], ts, outp);
-    }
-    const int last = kBroydenSteps + 1;
-    hipLaunchKernelGGL(k_canon_drain, dim3(grid_for(max_pts, 256)), dim3(256), 0, s,
-                       (const CanonRec*)((last & 1) ? w.recB : w.recA), (const int*)&cnt[last], outp);
+                           (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T,
+                           reinterpret_cast<f32x4*>(w.seeds));
+    LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
+                  kLdsCanonSolve, s, fd, reinterpret_cast<const f32x4*>(w.seeds), (const int*)&cnt[0], &cnt[1], ts, outp,
+                  &w.ctr->n_skin_fwd);
     return check_launch();
 }
 
@@ -2679,7 +2753,7 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, n, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev fd = to_dev(*f);
     hipMemcpyAsync(x, x0, (size_t)n * 3 * 4, hipMemcpyDeviceToDevice, s);
@@ -2716,7 +2790,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
         launch_nearest<SRC_RAYS>(s, fd, n, (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin,
-                                 (const int*)&cntA[it], 0, w.nn_idx, w.xcur, w.Tcur, (CanonRec*)nullptr, &w.ctr->n_knn);
+                                 (const int*)&cntA[it], 0, w.nn_idx, w.xcur, w.Tcur, (CanonSeed*)nullptr, &w.ctr->n_knn);
         LAUNCH_ENGINE(fd.split, k_sdf_march<true>, k_sdf_march<false>, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts,
                       (const int*)lin, (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
     }
@@ -2759,7 +2833,7 @@ int arah_trace(const ArahFrame* f, const float* cam_loc, int32_t rays_per_cam, c
     if (!cam_loc || !dirs || !near_far || !points_hat_norm || !T || !conv || !start || !end) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     return trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, root_find_all, points_hat_norm, T, conv, start,
                       end, reinterpret_cast<hipStream_t>(stream));
 }
@@ -2780,7 +2854,7 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 4095) / 4096)), dim3(1024), 0, s, (const uint8_t*)w.q_smask, (int)Q, w.listA, &w.counts[0]);
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
     launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA,
-                                (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, w.recA, &w.ctr->n_knn);
+                                (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, w.seeds, &w.ctr->n_knn);
     TargetSrc ts;
     ts.tgt = nullptr;
     ts.rs = rs;
@@ -2813,7 +2887,7 @@ int arah_sample_canonicalize(const ArahFrame* f, const ArahSampling* cfg, const 
     if (!cam_loc || !dirs || !near_far || !conv || !start || !end || !z || !pts || !T || !mask) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     if ((rand_steps || rand_near || rand_far) && (!rand_steps || !rand_near || (cfg->n_far > 0 && !rand_far)))
         return ARAH_E_BADARG;   // jitter is all or nothing
     return sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, conv, start, end, n, rand_steps, rand_near,
@@ -2835,7 +2909,8 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
         if (g_density_ev0) hipEventRecord(g_density_ev0, s);
         LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
-                      (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd);
+                      (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd,
+                      &w.ctr->r0);
         if (g_density_ev1) hipEventRecord(g_density_ev1, s);
         slist = w.listB;
         scount = &w.counts[1];
@@ -2864,13 +2939,13 @@ int arah_shade_composite(const ArahFrame* f, const ArahSampling* cfg, const floa
     if (!dirs || !z || !pts || !T || !mask || !rgb || !vol_mask) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     return shade_impl(f, cfg, w, dirs, z, pts, T, mask, n, rgb, acc, vol_mask, reinterpret_cast<hipStream_t>(stream));
 }
 
 // ---- whole eval forward -------------------------------------------------------------------------
 int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_loc, int32_t rays_per_cam,
-                const float* dirs, const float* near_far, const float* h_pose34, int32_t n, float* rgb,
+                const float* dirs, const float* near_far, const float* d_pose34, int32_t n, float* rgb,
                 float* points_cam, uint8_t* vol_mask, float* acc, float* dists, uint8_t* surface_conv,
                 void* workspace, size_t wbytes, void* stream) {
     if (!f || !cfg || n < 0 || !workspace) return ARAH_E_BADARG;
@@ -2878,10 +2953,10 @@ int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_lo
     if (rc) return rc;
     if (n == 0) return ARAH_OK;   // empty ray set: nothing to do, data pointers may be NULL
     if (!cam_loc || !dirs || !near_far || !rgb || !vol_mask) return ARAH_E_BADARG;
-    if (points_cam && !h_pose34) return ARAH_E_BADARG;
+    if (points_cam && !d_pose34) return ARAH_E_BADARG;
     Workspace w = carve(workspace, n, cfg->n_steps);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
-    setup_attributes();
+    if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* o_start = dists ? dists : w.o_start;
     uint8_t* o_conv = surface_conv ? surface_conv : w.o_conv;
@@ -2892,13 +2967,10 @@ int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_lo
     if (rc) return rc;
     rc = shade_impl(f, cfg, w, dirs, w.o_z, w.o_pts, w.o_T, w.o_mask, n, rgb, acc ? acc : w.o_acc, vol_mask, s);
     if (rc) return rc;
-    if (points_cam) {
-        Pose34 p;
-        for (int i = 0; i < 12; ++i) p.m[i] = h_pose34[i];
+    if (points_cam)
         hipLaunchKernelGGL(k_points_cam, dim3((n + 255) / 256), dim3(256), 0, s, to_dev(*f), n,
                            make_rays(cam_loc, dirs, rays_per_cam), (const float*)o_start, (const uint8_t*)o_conv,
-                           (const float*)w.o_xnorm, p, points_cam);
-    }
+                           (const float*)w.o_xnorm, d_pose34, points_cam);
     return check_launch();
 }
 

@@ -544,12 +544,19 @@ struct SkinNet {
 constexpr int kSkinLd = 132;
 constexpr int kLogitLd = 33;
 
-// Softplus(beta=100): log1p(exp(100 x))/100 == max(x,0) + log(1 + exp(-|100 x|))/100.  The correction is
-// <= 0.00693 and needs only ABSOLUTE accuracy (~1e-9 here), so hardware exp2/log2 are enough; for
-// 100 x > 20 it vanishes in fp32 and the result is x, like torch's threshold branch.
+// Softplus(beta=100): log1p(exp(100 x))/100 == max(x,0) + log1p(exp(-|100 x|))/100.  The correction is
+// <= 0.00693 and needs only ABSOLUTE accuracy (~1e-9 here), so the hardware exp2/log2 are fed directly: the
+// argument -|x| 100 log2(e) is at most a few tens in magnitude where the correction is not yet negligible, its
+// rounding error (|a| 2^-24) moves the correction by < 2e-10; for 100 x > 20 the correction vanishes in fp32 and
+// the result is x, like torch's threshold branch.  Six VALU operations, two of them transcendental.
+// Scaled form for the split engine: xs = S x  ->  S softplus100(x), with c1 = 100 log2(e) / S, c2 = S ln(2) / 100
+// (S a power of two: the scaling commutes with every rounding).
+__device__ __forceinline__ float softplus100_scaled(float xs, float c1, float c2) {
+    const float e = __builtin_amdgcn_exp2f(-fabsf(xs) * c1);
+    return fmaf(__builtin_amdgcn_logf(1.0f + e), c2, fmaxf(xs, 0.f));
+}
 __device__ __forceinline__ float softplus100(float x) {
-    const float e = exp_fast(-fabsf(100.0f * x));
-    return fmaxf(x, 0.f) + __builtin_amdgcn_logf(1.0f + e) * 6.93147180559945e-3f;
+    return softplus100_scaled(x, 144.269504088896341f, 6.93147180559945e-3f);
 }
 
 // xin LDS [16*NT][4] normalised coords -> logits LDS [16*NT][kLogitLd] (25 valid, un-scaled).
@@ -568,6 +575,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
         const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + ch0);
         const float S = SPLIT ? net.scales[0] : 1.0f;
+        const float c1 = 144.269504088896341f / S, c2 = 6.93147180559945e-3f * S;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const f32x4 x = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
@@ -576,13 +584,13 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
             for (int r = 0; r < 4; ++r)   // explicit chain: every instantiation must round identically
                 h[r] = fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], fmaf(w[r][0], x[0], b[r])));
             no_pack(h);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = softplus100(h[r]);
             if (SPLIT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = fminf(h[r] * S, kSat);
+                for (int r = 0; r < 4; ++r) h[r] = fminf(softplus100_scaled(h[r] * S, c1, c2), kSat);
                 store_split4(act, ld, 256, n * 16 + j, ch0, h);
             } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = softplus100(h[r]);
                 *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
             }
         }
@@ -597,15 +605,18 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         else gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
         ARAH_SYNC();
         const int ch0 = wave * 16 + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
-        const float inv = SPLIT ? net.scales[4 + k - 1] : 1.0f;
+        f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
         const float S = SPLIT ? net.scales[k] : 1.0f;
+        const float inv = SPLIT ? net.scales[4 + k - 1] * S : 1.0f;   // accumulator -> S (W h): S is a power of two
+        const float c1 = 144.269504088896341f / S, c2 = 6.93147180559945e-3f * S;
+        if (SPLIT) b = b * S;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             f32x4 h;
             if (SPLIT) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) h[r] = fminf(softplus100(fmaf(acc[0][n][r], inv, b[r])) * S, kSat);
+                for (int r = 0; r < 4; ++r)
+                    h[r] = fminf(softplus100_scaled(fmaf(acc[0][n][r], inv, b[r]), c1, c2), kSat);
                 store_split4(act, ld, 256, n * 16 + j, ch0, h);
             } else {
 #pragma unroll

@@ -71,8 +71,10 @@ class ArahFrame(C.Structure):
 class ArahCounters(C.Structure):
     _fields_ = [("n_sdf_fwd", C.c_uint64), ("n_sdf_grad", C.c_uint64), ("n_skin_fwd", C.c_uint64),
                 ("n_skin_jac", C.c_uint64), ("n_col", C.c_uint64), ("n_knn", C.c_uint64),
-                ("reserved", C.c_uint64 * 2)]
+                ("n_density", C.c_uint64), ("reserved", C.c_uint64)]
 
+
+COUNTER_BYTES = C.sizeof(ArahCounters)
 
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
@@ -118,8 +120,71 @@ def _f32(t):
     return t.detach().to(dtype=torch.float32).contiguous()
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+_call_device = [None]   # device of the C-ABI call in flight (set by _guarded / Frame.__init__)
+
+
+def _stream(device=None):
+    """Current HIP stream OF the call's device (not of whatever device happens to be current)."""
+    device = device if device is not None else _call_device[0]
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class _on_device:
+    """Make `device` current for the duration of a C-ABI call: the kernels, memsets and copies behind the ABI are
+    issued on the current device, torch's own guard does not reach through ctypes."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self.guard = torch.cuda.device(self.device)
+
+    def __enter__(self):
+        self.guard.__enter__()
+        self.prev = _call_device[0]
+        _call_device[0] = self.device
+
+    def __exit__(self, *exc):
+        _call_device[0] = self.prev
+        return self.guard.__exit__(*exc)
+
+
+def _guarded(fn):
+    """Wrapper for fn(frame, ws, ...): frame, workspace and every tensor argument must share one GPU, which
+    becomes the current device (and supplies the stream) for the call."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(frame, ws, *args, **kwargs):
+        dev = frame.device
+        if ws.device != dev:
+            raise ValueError("workspace lives on %s, frame on %s" % (ws.device, dev))
+
+        def check(v):
+            if isinstance(v, torch.Tensor):
+                if v.device != dev:
+                    raise ValueError("argument on %s, frame on %s" % (v.device, dev))
+            elif isinstance(v, (tuple, list)):
+                for u in v:
+                    check(u)
+        for v in list(args) + list(kwargs.values()):
+            check(v)
+        with _on_device(dev):
+            return fn(frame, ws, *args, **kwargs)
+    return wrapper
+
+
+def _same_device(*tensors):
+    """All device buffers of one C-ABI call must live on one GPU; returns it."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise ValueError("device-resident tensor required")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise ValueError("buffers of one call live on different devices: %s vs %s" % (dev, t.device))
+    return dev
 
 
 def require_gpu():
@@ -132,23 +197,36 @@ class Workspace:
     """Caller-owned scratch of the C ABI (grows on demand, never shrinks)."""
 
     def __init__(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.buf = None
 
     def ensure(self, n_rays, n_steps):
         need = load_library().arah_workspace_bytes(int(n_rays), int(n_steps))
         if self.buf is None or self.buf.numel() < need:
-            self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
-            load_library().arah_counters_reset(_ptr(self.buf), _stream())
+            old = self.buf
+            with torch.cuda.device(self.device):
+                self.buf = torch.empty(need, dtype=torch.uint8, device=self.device)
+                if old is None:
+                    _check(load_library().arah_counters_reset(_ptr(self.buf), _stream(self.device)),
+                           "arah_counters_reset")
+                else:   # the work counters sit at the head of the workspace: a grown buffer inherits them
+                    self.buf[:COUNTER_BYTES].copy_(old[:COUNTER_BYTES])
         return self.buf
 
     def reset_counters(self):
-        _check(load_library().arah_counters_reset(_ptr(self.buf), _stream()), "arah_counters_reset")
+        with torch.cuda.device(self.device):
+            _check(load_library().arah_counters_reset(_ptr(self.buf), _stream(self.device)), "arah_counters_reset")
 
     def counters(self):
         out = ArahCounters()
-        _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream()), "arah_counters_read")
-        return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn")}
+        with torch.cuda.device(self.device):
+            _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream(self.device)),
+                   "arah_counters_read")
+        return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn",
+                                                   "n_density")}
 
 
 class Frame:
@@ -209,11 +287,13 @@ class Frame:
             body.center[i] = float(center[i])
         body.coord_min, body.coord_max = float(coord_min), float(coord_max)
         body.n_verts = int(verts.shape[0])
+        _same_device(*keep)
         nbytes = lib.arah_frame_bytes(C.byref(nets), C.byref(body))
-        self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self.handle = ArahFrame()
-        _check(lib.arah_prepare_frame(C.byref(nets), C.byref(body), _ptr(self.buf), C.c_size_t(nbytes),
-                                      C.byref(self.handle), _stream()), "arah_prepare_frame")
+        with _on_device(dev):
+            self.buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _check(lib.arah_prepare_frame(C.byref(nets), C.byref(body), _ptr(self.buf), C.c_size_t(nbytes),
+                                          C.byref(self.handle), _stream()), "arah_prepare_frame")
         # the pack kernels read `keep` asynchronously on the current stream; hold the raw tensors
         # until the frame is dropped (cheap: a few MB)
         self._keep = keep
@@ -243,6 +323,7 @@ class Sampling:
 # ------------------------------------------------------------------------------------------------
 # thin functional wrappers (allocate outputs with torch, call the C ABI on the current stream)
 # ------------------------------------------------------------------------------------------------
+@_guarded
 def sdf_eval(frame, ws, x_norm, want_feat=False, want_grad=False):
     lib = load_library()
     x = _f32(x_norm)
@@ -256,6 +337,7 @@ def sdf_eval(frame, ws, x_norm, want_feat=False, want_grad=False):
     return sdf, feat, grad
 
 
+@_guarded
 def skin_lbs(frame, ws, x_hat):
     lib = load_library()
     x = _f32(x_hat)
@@ -269,6 +351,7 @@ def skin_lbs(frame, ws, x_hat):
     return w, xb, T
 
 
+@_guarded
 def skin_jacobian(frame, ws, x_hat):
     lib = load_library()
     x = _f32(x_hat)
@@ -280,6 +363,7 @@ def skin_jacobian(frame, ws, x_hat):
     return jac
 
 
+@_guarded
 def color_eval(frame, ws, x_norm, normal, view, feat):
     lib = load_library()
     x, nr, ft = _f32(x_norm), _f32(normal), _f32(feat)
@@ -292,6 +376,7 @@ def color_eval(frame, ws, x_norm, normal, view, feat):
     return rgb
 
 
+@_guarded
 def nearest_inverse_lbs(frame, ws, pts):
     lib = load_library()
     p = _f32(pts)
@@ -305,6 +390,7 @@ def nearest_inverse_lbs(frame, ws, pts):
     return idx, x0, T0
 
 
+@_guarded
 def broyden3_lbs(frame, ws, tgt, x0, T0):
     lib = load_library()
     tgt, x0, T0 = _f32(tgt), _f32(x0), _f32(T0)
@@ -320,6 +406,7 @@ def broyden3_lbs(frame, ws, tgt, x0, T0):
     return x, T, err, conv.bool()
 
 
+@_guarded
 def trace(frame, ws, cam_loc, dirs, near_far, root_find_all=False):
     """cam_loc (B,3), dirs (B*N,3) flat, near_far (B*N,2) -> x_norm, T, conv, start, end."""
     lib = load_library()
@@ -338,6 +425,7 @@ def trace(frame, ws, cam_loc, dirs, near_far, root_find_all=False):
     return xn, T, conv, start, end
 
 
+@_guarded
 def sample_canonicalize(frame, ws, sampling, cam_loc, dirs, near_far, conv, start, end, rand=None):
     """rand: None (eval) or (rand_steps (N,S), rand_near (N,near+1), rand_far (N,far)) uniform draws."""
     lib = load_library()
@@ -361,6 +449,7 @@ def sample_canonicalize(frame, ws, sampling, cam_loc, dirs, near_far, conv, star
     return z, pts, T, mask
 
 
+@_guarded
 def shade_composite(frame, ws, sampling, dirs, z, pts, T, mask):
     lib = load_library()
     d = _f32(dirs)
@@ -398,8 +487,10 @@ def set_density_events(start=None, stop=None):
     _check(lib.arah_set_density_events(a, b), "arah_set_density_events")
 
 
+@_guarded
 def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):
-    """Whole eval forward. pose34: host (3,4) world->camera. Returns rgb, points_cam, vol_mask, acc, dists, conv."""
+    """Whole eval forward. pose34: DEVICE (3,4) world->camera (no host copy, no stream drain).
+    Returns rgb, points_cam, vol_mask, acc, dists, conv."""
     lib = load_library()
     cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
     n, S = d.shape[0], sampling.n_steps
@@ -411,8 +502,8 @@ def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):
     acc = torch.empty(n, device=dev)
     dists = torch.empty(n, device=dev)
     conv = torch.empty(n, dtype=torch.uint8, device=dev)
-    h_pose = (C.c_float * 12)(*[float(v) for v in pose34.reshape(-1)[:12]])
+    d_pose = _f32(pose34).reshape(-1)[:12].contiguous()
     _check(lib.arah_render(C.byref(frame.handle), C.byref(sampling.handle), _ptr(cam), C.c_int32(n // cam.shape[0]),
-                           _ptr(d), _ptr(nf), h_pose, C.c_int32(n), _ptr(rgb), _ptr(pcam), _ptr(vol), _ptr(acc),
+                           _ptr(d), _ptr(nf), _ptr(d_pose), C.c_int32(n), _ptr(rgb), _ptr(pcam), _ptr(vol), _ptr(acc),
                            _ptr(dists), _ptr(conv), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_render")
     return rgb, pcam, vol, acc, dists, conv

@@ -237,7 +237,7 @@ class IDHRNetwork(nn.Module):
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                       ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2),
-                                                      pose[0, :3, :4].detach().float().cpu())
+                                                      pose[0, :3, :4].detach().float().contiguous())
         pcam = pcam.reshape(B, N, 3)
         if B > 1:   # per-view camera pose for the remaining batch elements (IDR:114-115)
             pw = cam_loc.reshape(B, 1, 3) + dists.reshape(B, N, 1) * ray_dirs

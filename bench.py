@@ -80,19 +80,34 @@ def pmc_traffic(kernel):
         return None, None
 
 
-def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays):
-    """Oracle on `sample_rays` rays spread evenly over frame 0 of the benchmark workload."""
+def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu=None, dev=None):
+    """Oracle on `sample_rays` rays spread evenly over frame 0 of the benchmark workload, timed on the host cores;
+    the same rays are rendered by the HIP path and compared (BASELINE.json's "+ PSNR vs ref": the oracle is the
+    pinned CPU restatement of the reference, the reference itself does not travel to this box)."""
+    import numpy as np
     from arah_release_amd import config
     from oracle import arah_oracle as O
     model, cfg = config.build_synthetic_model(cfg_name, n_steps, near, far, device="cpu")
     inputs = scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays)
     n = inputs["ray_dirs"].shape[1]
     t0 = time.perf_counter()
-    O.render_inputs(model, inputs, cfg["model"]["cano_view_dirs"], n_steps, near, far)
+    ref = O.render_inputs(model, inputs, cfg["model"]["cano_view_dirs"], n_steps, near, far)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d rays evenly subsampled from frame 0 of the %dx%dx%d workload, oracle/arah_oracle.py "
-                      "(torch CPU fp32, cKDTree 1-NN), %.1f s" % (n, size, size, n_steps, dt)}
+    out = {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+           "sample": "%d rays evenly subsampled from frame 0 of the %dx%dx%d workload, oracle/arah_oracle.py "
+                     "(torch CPU fp32, cKDTree 1-NN), %.1f s" % (n, size, size, n_steps, dt)}
+    if model_gpu is not None:
+        with torch.no_grad():
+            got = model_gpu(scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays, device=dev), eval=True)
+        rgb = got["rgb_values"][0].double().cpu().numpy()
+        mask = got["network_body_mask"][0].cpu().numpy()
+        rgb_ref = ref["rgb_values"].double().numpy()
+        mask_ref = ref["network_body_mask"].numpy()
+        mse = float(np.mean((rgb - rgb_ref) ** 2))
+        out["psnr_vs_oracle_db"] = None if mse == 0 else -10.0 * float(np.log10(mse))   # im2mesh/utils/eval.py:6-9
+        out["mask_agreement"] = float((mask == mask_ref).mean())
+        out["parity_sample"] = "HIP render of the same %d rays vs the oracle's image" % n
+    return out
 
 
 def main():
@@ -105,6 +120,9 @@ def main():
     ap.add_argument("--config", default="zju377_mono")
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--passes", default="all", choices=["all", "default"],
+                    help="'default': only the product's default path (profiling runs); 'all' adds the full-shading, "
+                         "exact-engine and strict passes over the same frames")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -144,15 +162,18 @@ def main():
     ev1 = torch.cuda.Event(enable_timing=True)
     tracer = model.idhr_network.ray_tracer
 
-    def timed_pass(full_shading):
+    n_rays_max = max(int(i["ray_dirs"].shape[1]) for i in warm_inputs + timed_inputs)
+
+    def timed_pass(full_shading, precision="split"):
         """K timed steps (barrier + sync on both sides), then the same K steps again with HIP events
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
         tracer.full_shading = full_shading
+        os.environ["ARAH_PRECISION"] = precision
+        ws = tracer.workspace(dev)
+        ws.ensure(n_rays_max, args.n_steps)   # sized for the largest frame before anything is timed or counted
         for inp in warm_inputs:
             model(inp, eval=True)
         sync()
-        ws = tracer.workspace(dev)
-        ws.ensure(1, 1)
         ws.reset_counters()
         t0 = time.perf_counter()
         for inp in timed_inputs:
@@ -168,39 +189,38 @@ def main():
             torch.cuda.synchronize()
             ms.append(ev0.elapsed_time(ev1))
         setter(None, None)
+        os.environ["ARAH_PRECISION"] = default_engine
         return dt, ctr, ms
 
+    default_engine = os.environ.get("ARAH_PRECISION", "split")
     split = hip.default_precision() == hip.PRECISION_SPLIT_F16
     with torch.no_grad():
-        elapsed, counters, dens_ms = timed_pass(False)          # the product's default path
-        elapsed_full, counters_full, shade_ms = timed_pass(True)  # shade every valid sample, like the reference
-        elapsed_exact = None
-        if split:                                               # same frames on the exact fp32 MFMA engine
-            os.environ["ARAH_PRECISION"] = "fp32"
-            elapsed_exact, _, _ = timed_pass(False)
-            os.environ["ARAH_PRECISION"] = "split"
+        elapsed, counters, dens_ms = timed_pass(False, default_engine)          # the product's default path
+        elapsed_full = elapsed_exact = elapsed_strict = None
+        if args.passes == "all":
+            elapsed_full, counters_full, shade_ms = timed_pass(True, default_engine)  # shade every valid sample, like the reference
+        if split and args.passes == "all":                      # same frames on the exact fp32 MFMA engine
+            elapsed_exact, _, _ = timed_pass(False, "fp32")
+            elapsed_strict, counters_strict, strict_ms = timed_pass(True, "fp32")   # all of the reference's work, fp32 MFMA only
         tracer.full_shading = False
 
     total_rays, t_max = aggregate(n_rays_local, elapsed, dist if world > 1 else None)
-    _, t_max_full = aggregate(n_rays_local, elapsed_full, dist if world > 1 else None)
+    t_max_full = aggregate(n_rays_local, elapsed_full, dist if world > 1 else None)[1] if elapsed_full else None
     t_max_exact = aggregate(n_rays_local, elapsed_exact, dist if world > 1 else None)[1] if elapsed_exact else None
+    t_max_strict = aggregate(n_rays_local, elapsed_strict, dist if world > 1 else None)[1] if elapsed_strict else None
     if rank == 0:
         mode = cfg["model"]["renderer_kwargs"]["mode"]
-        n_launch = max(len(shade_ms), 1)
 
         def path_flops(c):
             return (F_SDF * c["n_sdf_fwd"] + F_SDF_GRAD * c["n_sdf_grad"] + 105472 * (c["n_skin_fwd"] + 3 * c["n_skin_jac"]) +
                     F_COL[mode] * c["n_col"] + 55120 * c["n_knn"])
 
         # dominant kernel of the default path: k_density = the SDF MLP forward on every valid sample
-        dens_samples = counters_full["n_col"] / n_launch          # == number of valid (converged) samples
+        n_launch = max(len(dens_ms), 1)
+        dens_samples = counters["n_density"] / n_launch           # == number of valid (converged) samples
         dens_avg_ms = sum(dens_ms) / n_launch
         achieved = dens_samples * F_SDF / (dens_avg_ms * 1e-3) / 1e12
-        # dominant kernel of the shade-everything path: k_shade
         flops_per_sample = F_SDF + F_SDF_GRAD + F_COL[mode]
-        samples_per_launch = counters_full["n_col"] / n_launch
-        avg_ms = sum(shade_ms) / n_launch
-        achieved_full = samples_per_launch * flops_per_sample / (avg_ms * 1e-3) / 1e12
         total_flops = path_flops(counters)
         tf = {True: "true", False: "false"}
         dens_traffic, traffic_src = pmc_traffic("k_density<%s>" % tf[split])
@@ -214,7 +234,9 @@ def main():
         line = {
             "metric": "rendered rays/sec", "value": total_rays / t_max, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (operands as hi+lo f16 pairs on the f16 MFMA pipe, fp32 accumulate)" if split else "f32",
+            "data": "synthetic",
             "precision": engine,
             "config": {"workload": "ZJUMOCAP-377-mono test.py inference, %dx%d, %d samples/ray (near %d / far %d), "
                                    "synthetic capsule body + fitted SIREN, one frame per step" %
@@ -223,34 +245,54 @@ def main():
                        "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world},
             "roofline": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
                          "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
-                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
+                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_live": False,
                          "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples, "flops_per_sample": F_SDF,
                          "peak_note": ("algorithmic fp32 flops against dense f16 MFMA peak / 3 (three f16 MFMAs per "
                                        "fp32 product); executed f16 MFMA rate = 3 x achieved" if split else
                                        "dense fp32 MFMA peak")},
-            "full_shading": {"note": "same frames with lazy shading off (normal + colour for EVERY valid sample, as "
-                                     "the reference does); bit-identical images",
-                             "value": total_rays / t_max_full, "unit": "rays/s",
-                             "ms_per_step": 1e3 * t_max_full / max(args.steps, 1),
-                             "algorithmic_mflop_per_ray": path_flops(counters_full) / max(n_rays_local, 1) / 1e6,
-                             "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": achieved_full,
-                                          "peak": peak_shade, "unit": "TFLOP/s",
-                                          "frac": achieved_full / peak_shade, "traffic": shade_traffic,
-                                          "peak_note": "time-weighted over the kernel's GEMM classes and their engines",
-                                          "avg_launch_ms": avg_ms, "samples_per_launch": samples_per_launch,
-                                          "flops_per_sample": flops_per_sample}},
             "work": {"per_ray": {k: v / max(n_rays_local, 1) for k, v in counters.items()},
                      "algorithmic_mflop_per_ray": total_flops / max(n_rays_local, 1) / 1e6,
                      "whole_path_tflops_rank0": total_flops / elapsed / 1e12},
         }
+        if t_max_full:
+            # dominant kernel of the shade-everything path: k_shade (forward trunk on the default engine, reverse sweep
+            # and colour MLP on the exact engine)
+            n_l = max(len(shade_ms), 1)
+            samples_per_launch = counters_full["n_col"] / n_l
+            avg_ms = sum(shade_ms) / n_l
+            achieved_full = samples_per_launch * flops_per_sample / (avg_ms * 1e-3) / 1e12
+            line["full_shading"] = {"note": "same frames with lazy shading off (normal + colour for EVERY valid sample, as "
+                                            "the reference does); bit-identical images",
+                                    "value": total_rays / t_max_full, "unit": "rays/s",
+                                    "ms_per_step": 1e3 * t_max_full / max(args.steps, 1),
+                                    "algorithmic_mflop_per_ray": path_flops(counters_full) / max(n_rays_local, 1) / 1e6,
+                                    "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": achieved_full,
+                                                 "peak": peak_shade, "unit": "TFLOP/s",
+                                                 "frac": achieved_full / peak_shade, "traffic": shade_traffic,
+                                                 "peak_note": "time-weighted over the kernel's GEMM classes and their engines",
+                                                 "avg_launch_ms": avg_ms, "samples_per_launch": samples_per_launch,
+                                                 "flops_per_sample": flops_per_sample}}
         if t_max_exact:
             line["exact_fp32_engine"] = {"note": "same frames with ARAH_PRECISION=fp32 (v_mfma_f32_16x16x4_f32 for every "
                                                  "GEMM, two workgroups per CU)",
                                          "value": total_rays / t_max_exact, "unit": "rays/s",
                                          "ms_per_step": 1e3 * t_max_exact / max(args.steps, 1)}
+        if t_max_strict:
+            n_l = max(len(strict_ms), 1)
+            ach = counters_strict["n_col"] / n_l * flops_per_sample / (sum(strict_ms) / n_l * 1e-3) / 1e12
+            line["strict"] = {"note": "reference-equivalent work: exact fp32 MFMA engine (v_mfma_f32_16x16x4_f32 for every "
+                                      "GEMM) AND normal + colour for every valid sample",
+                              "value": total_rays / t_max_strict, "unit": "rays/s",
+                              "ms_per_step": 1e3 * t_max_strict / max(args.steps, 1),
+                              "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": ach,
+                                           "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                                           "avg_launch_ms": sum(strict_ms) / n_l}}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(scene, args.config, args.size, args.n_steps, near, far,
-                                                args.cpu_sample_rays)
+                                                args.cpu_sample_rays, model_gpu=model, dev=dev)
+            line["psnr_vs_oracle_db"] = line["cpu_baseline"].get("psnr_vs_oracle_db")
+            line["mask_agreement"] = line["cpu_baseline"].get("mask_agreement")
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -158,7 +158,8 @@ typedef struct ArahFrame {
 /* Work counters (points evaluated), SURVEY 8(d). */
 typedef struct ArahCounters {
     uint64_t n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn;
-    uint64_t reserved[2];
+    uint64_t n_density;   /* samples seen by the density pre-pass of lazy shading (a subset of n_sdf_fwd) */
+    uint64_t reserved;
 } ArahCounters;
 
 /* ---- frame preparation ------------------------------------------------------------------ */
@@ -216,10 +217,11 @@ int arah_shade_composite(const ArahFrame* h_frame, const ArahSampling* h_cfg, co
                          const float* z, const float* pts, const float* T, const uint8_t* mask,
                          int32_t n_rays, float* rgb, float* acc, uint8_t* vol_mask, void* workspace,
                          size_t workspace_bytes, void* stream);
-/* whole eval forward.  pose34 = host [3][4] world->camera (R|t).  Any of the optional outputs may
- * be NULL, then they live in the workspace.  -> rgb [N,3], points_cam [N,3], vol_mask [N] */
+/* whole eval forward.  pose34 = DEVICE [3][4] world->camera (R|t), read by the last kernel only (no host copy of
+ * the pose, no stream drain).  Any of the optional outputs may be NULL, then they live in the workspace.
+ * -> rgb [N,3], points_cam [N,3], vol_mask [N] */
 int arah_render(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float* cam_loc,
-                int32_t rays_per_cam, const float* dirs, const float* near_far, const float* h_pose34,
+                int32_t rays_per_cam, const float* dirs, const float* near_far, const float* pose34,
                 int32_t n_rays, float* rgb, float* points_cam, uint8_t* vol_mask, float* acc,
                 float* dists, uint8_t* surface_conv, void* workspace, size_t workspace_bytes,
                 void* stream);
