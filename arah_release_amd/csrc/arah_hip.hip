@@ -109,7 +109,13 @@ FrameDev to_dev(const ArahFrame& f) {
 
 struct Counters {
     unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, r0, r1;
+    unsigned long long clk[8 * 16];   // instrumented builds (-DARAH_CLOCKS): s_memtime ticks per wave slot and phase
 };
+#ifdef ARAH_CLOCKS
+typedef PhaseClk KernelClk;
+#else
+typedef NoClk KernelClk;
+#endif
 
 __device__ __forceinline__ void count_add(unsigned long long* c, int n) {
     if (c && n > 0) atomicAdd(c, (unsigned long long)n);
@@ -627,7 +633,8 @@ __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const float* 
         CanonSeed* r = rec_out + i;
         r->r[0] = f32x4{xh.x, xh.y, xh.z, __int_as_float(id)};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) r->r[1 + c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
+        for (int c = 0; c < 3; ++c) r->r[1 + c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
+        r->r[4] = f32x4{y.x, y.y, y.z, T[15]};   // the target p - trans rides in the (exactly zero) T[3][0..2]
         return;
     }
     x_out[(size_t)id * 3 + 0] = xh.x;
@@ -921,7 +928,7 @@ __global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(
     int* ids = reinterpret_cast<int*>(outv + 64 * 4);   // [64]
     float* actA = reinterpret_cast<float*>(ids + 64);   // [64][260]
     float* actB = actA + 64 * kSdfLd;        // [64][260] (GRAD only)
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = list ? *count : n_direct;
     f32x4* spill = spill_all ? spill_all + (size_t)blockIdx.x * kSpillPerWg : nullptr;
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
@@ -993,7 +1000,7 @@ __device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceS
     float* outv = xin + 64 * 4;
     int* ids = reinterpret_cast<int*>(outv + 64 * 4);
     float* actA = reinterpret_cast<float*>(ids + 64);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const float scale = sdf_scale(fr.bc);
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
         if (tid < TW) {
@@ -1052,7 +1059,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_skin_eval(FrameDev fr, const fl
     float* sbones = xraw + 64 * 4;            // [24][16]
     float* logits = sbones + 24 * 16;         // [64][33]
     float* act = logits + 64 * kLogitLd;      // [64][132]; 64*33 floats keeps the 16-byte alignment
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
         if (tid < kTile) {
@@ -1101,7 +1108,7 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
     float* sbones = xraw + 16 * 4;            // [24][16]
     float* logits = sbones + 24 * 16;         // [64][33]  (col = n*16 + j)
     float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer   // [64][132]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
     const int n = list ? *count : n_direct;
     const int ld = kSkinLd;
@@ -1221,22 +1228,10 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
 // numbers of iterations (mean 3.7, a fraction of a percent the full 51), and there is no per-iteration launch.
 // Per-point arithmetic does not depend on the slot or on its neighbours: results are deterministic although the
 // schedule is not.
-//   seed = {x0(3), id | T0 (4x4 row-major)}: nearest-vertex start (RT:403-422) written by k_nearest_invlbs<SAMPLES>
-//          or k_canon_seed.  T0 doubles as the initial best T (broyden.py:41).
+//   seed = {x0(3), id | T0 rows 0..2 | target(3), T0[3][3]}: nearest-vertex start (RT:403-422) written by
+//          k_nearest_invlbs<SAMPLES> or k_canon_seed.  T0 doubles as the initial best T (broyden.py:41); its last row
+//          is (0, 0, 0, sum of the vertex weights) exactly, so the three zeros carry the target of g.
 // ------------------------------------------------------------------------------------------
-struct TargetSrc {
-    const float* tgt;     // explicit [Q][3] or null
-    RaySet rs;
-    const float* depth;   // z [Q]
-    int n_steps;
-};
-
-__device__ __forceinline__ V3 target_of(const TargetSrc& ts, const BodyConst& bc, int id) {
-    if (ts.tgt) return V3{ts.tgt[(size_t)id * 3], ts.tgt[(size_t)id * 3 + 1], ts.tgt[(size_t)id * 3 + 2]};
-    const V3 p = ray_point(ts.rs, id / ts.n_steps, ts.depth[id]);
-    return V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
-}
-
 struct CanonOut {
     float* pts;    // [Q][3] raw canonical best x
     float* T;      // [Q][16]
@@ -1317,9 +1312,13 @@ constexpr size_t kLdsCanonSolve =
 
 template <bool SPLIT>
 __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const f32x4* __restrict__ seeds,
-                                                             const int* count, int* queue_head, TargetSrc ts,
-                                                             CanonOut outp, unsigned long long* ctr) {
+                                                             const int* count, int* queue_head, CanonOut outp,
+                                                             unsigned long long* ctr, unsigned long long* clk_out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    KernelClk clk;
+#ifdef ARAH_CLOCKS
+    clk.start();
+#endif
     float* xin = smem;                        // [64][4] normalised
     float* logits = xin + 64 * 4;             // [64][33]
     float* sbones = logits + 64 * kLogitLd;   // [24][16]; 64*33 floats is a multiple of 4: stays 16-byte aligned
@@ -1327,7 +1326,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
     float* state = reinterpret_cast<float*>(alive + 16);     // [64][ST_SIZE]
     float* tbest = state + 64 * ST_SIZE;                     // [64][16] best T so far
     float* act = tbest + 64 * 16;                            // [64][132]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
     const bool owner = wave < 4;
     const int slot = (wave & 3) * 16 + j;
@@ -1369,10 +1368,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
             }
             if (src >= 0) {
                 const f32x4 s0 = seeds[(size_t)src * 5];
-                *tb = seeds[(size_t)src * 5 + 1 + g];      // T0 doubles as the initial best T (broyden.py:41)
+                const f32x4 s4 = seeds[(size_t)src * 5 + 4];   // {target, T0[3][3]}
+                f32x4 t0 = seeds[(size_t)src * 5 + 1 + g];
+                if (g == 3) t0 = f32x4{0.f, 0.f, 0.f, s4[3]};
+                *tb = t0;                                      // T0 doubles as the initial best T (broyden.py:41)
                 id = __float_as_int(s0[3]);
                 if (g == 0) {
-                    const V3 tg = target_of(ts, fr.bc, id);
+                    const V3 tg = V3{s4[0], s4[1], s4[2]};
 #pragma unroll
                     for (int r = 0; r < 3; ++r) {
                         st[ST_X + r] = s0[r];
@@ -1400,9 +1402,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
             if (lane == 0) alive[wave] = live != 0ull;
             n_eval += __popcll(live);
         }
+        clk.mark(0);
         __syncthreads();
+        clk.mark(1);
         if (!(alive[0] | alive[1] | alive[2] | alive[3])) break;
-        skin_mlp<kNT, SPLIT>(fr.skin, xin, act, logits, wave, lane);   // ends with a barrier
+        skin_mlp<kNT, SPLIT>(fr.skin, xin, act, logits, wave, lane, clk);   // ends with a barrier
         if (owner) {
             // ---- weights, row g of T = sum_j w_j A_j, x_bar, residual
             f32x4 Trow = {0.f, 0.f, 0.f, 0.f};
@@ -1502,19 +1506,27 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
                 }
             }
         }
+        clk.mark(10);
         __syncthreads();   // logits rows / alive flags are rewritten by the next pass
+        clk.mark(11);
     }
     if (owner && lane == 0) count_add(ctr, n_eval);
+#ifdef ARAH_CLOCKS
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&clk_out[wave * 16 + i], (unsigned long long)clk.acc[i]);
+#endif
 }
 
-// seeds from (x0, T0) stored densely by id: seed[i] = {x0, id | T0}
-__global__ void k_canon_seed(const int* list, const int* count, const float* x0, const float* T0, f32x4* seeds) {
+// seeds from (x0, T0) stored densely by id and explicit targets
+__global__ void k_canon_seed(const int* list, const int* count, const float* x0, const float* T0, const float* tgt,
+                             f32x4* seeds) {
     const int n = *count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int id = list[i];
         seeds[(size_t)i * 5] = f32x4{x0[(size_t)id * 3], x0[(size_t)id * 3 + 1], x0[(size_t)id * 3 + 2], __int_as_float(id)};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) seeds[(size_t)i * 5 + 1 + c] = reinterpret_cast<const f32x4*>(T0 + (size_t)id * 16)[c];
+        for (int c = 0; c < 3; ++c) seeds[(size_t)i * 5 + 1 + c] = reinterpret_cast<const f32x4*>(T0 + (size_t)id * 16)[c];
+        seeds[(size_t)i * 5 + 4] = f32x4{tgt[(size_t)id * 3], tgt[(size_t)id * 3 + 1], tgt[(size_t)id * 3 + 2], T0[(size_t)id * 16 + 15]};
     }
 }
 
@@ -1572,7 +1584,7 @@ __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4St
     int* ids = reinterpret_cast<int*>(sbones + 24 * 16);
     float* logits = reinterpret_cast<float*>(ids + 64);    // [64][33]
     float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer   // [64][260]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const float scale = sdf_scale(fr.bc);
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
@@ -1886,7 +1898,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const floa
     float* outv = xin + TW * 4;                          // [TW][4]
     int* ids = reinterpret_cast<int*>(outv + TW * 4);    // [TW]
     float* actA = reinterpret_cast<float*>(ids + TW);    // [64][260]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = *count;
     const float scale = sdf_scale(fr.bc);
     const float inv_beta = 1.0f / fminf(fmaxf(fabsf(fr.beta), 1e-6f), 1e6f);
@@ -1940,7 +1952,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
     int* ids = reinterpret_cast<int*>(rgbv + 64 * 4);
     float* actA = reinterpret_cast<float*>(ids + 64);   // [64][kLdA]
     float* actB = actA + 64 * D::kLdA;                  // [64][260]
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = list ? *count : n_direct;
     f32x4* spill = spill_all + (size_t)blockIdx.x * kSpillPerWg;
     const float scale = sdf_scale(fr.bc);
@@ -2044,7 +2056,7 @@ __global__ __launch_bounds__(kThreads) void k_color_eval(FrameDev fr, const floa
     float* rgbv = smem;                        // [64][4]
     float* actA = rgbv + 64 * 4;
     float* actB = actA + 64 * D::kLdA;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
         for (int e = tid; e < kTile * 64; e += kThreads) {
             const int pt = e >> 6, c4 = e & 63;
@@ -2643,6 +2655,17 @@ int arah_counters_reset(void* workspace, void* stream) {
                                                                                                            : ARAH_E_LAUNCH;
 }
 
+#ifdef ARAH_CLOCKS
+// instrumented builds only (tools/phase_clocks.py): the 8 x 16 phase clocks behind the counters; syncs the stream
+int arah_debug_clocks(const void* workspace, unsigned long long* h_out, void* stream) {
+    if (!workspace || !h_out) return ARAH_E_BADARG;
+    Workspace w = carve(const_cast<void*>(workspace), 1, 1);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(h_out, w.ctr->clk, sizeof(w.ctr->clk), hipMemcpyDeviceToHost, s) != hipSuccess) return ARAH_E_LAUNCH;
+    return hipStreamSynchronize(s) == hipSuccess ? ARAH_OK : ARAH_E_LAUNCH;
+}
+#endif
+
 int arah_counters_read(const void* workspace, ArahCounters* h_out, void* stream) {
     if (!workspace || !h_out) return ARAH_E_BADARG;
     Workspace w = carve(const_cast<void*>(workspace), 1, 1);
@@ -2731,19 +2754,19 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
     return check_launch();
 }
 
-// shared driver of loop C.  seeded: w.seeds[0 .. cnt[0]) are already written (k_nearest_invlbs<SAMPLES>); otherwise
-// (x0, T0) are stored densely by id in out.pts / out.T for every id in listA.  w.counts: [0] = number of seeds,
+// shared driver of loop C.  tgt == NULL: w.seeds[0 .. cnt[0]) are already written (k_nearest_invlbs<SAMPLES>); otherwise
+// (x0, T0) are stored densely by id in out.pts / out.T and the targets in tgt for every id in listA.  w.counts: [0] = number of seeds,
 // [1] = head of the seed queue (zeroed by the caller's memset of w.counts).
-static int run_broyden3(const FrameDev& fd, Workspace& w, TargetSrc ts, CanonOut outp, long long max_pts,
-                        bool seeded, hipStream_t s) {
+static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, CanonOut outp, long long max_pts,
+                        hipStream_t s) {
     int* cnt = w.counts;
-    if (!seeded)
+    if (tgt)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
-                           (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T,
+                           (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, tgt,
                            reinterpret_cast<f32x4*>(w.seeds));
     LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
-                  kLdsCanonSolve, s, fd, reinterpret_cast<const f32x4*>(w.seeds), (const int*)&cnt[0], &cnt[1], ts, outp,
-                  &w.ctr->n_skin_fwd);
+                  kLdsCanonSolve, s, fd, reinterpret_cast<const f32x4*>(w.seeds), (const int*)&cnt[0], &cnt[1], outp,
+                  &w.ctr->n_skin_fwd, w.ctr->clk);
     return check_launch();
 }
 
@@ -2760,12 +2783,7 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
     hipMemcpyAsync(T, T0, (size_t)n * 16 * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, n, w.listA, &w.counts[0]);
-    TargetSrc ts;
-    ts.tgt = tgt;
-    ts.rs = make_rays(nullptr, nullptr, 1);
-    ts.depth = nullptr;
-    ts.n_steps = 1;
-    int rc = run_broyden3(fd, w, ts, CanonOut{x, T, w.q_err}, n, false, s);
+    int rc = run_broyden3(fd, w, tgt, CanonOut{x, T, w.q_err}, n, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_broyden3_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, (const float*)w.q_err, err, conv);
     return check_launch();
@@ -2855,12 +2873,7 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
     launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA,
                                 (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, w.seeds, &w.ctr->n_knn);
-    TargetSrc ts;
-    ts.tgt = nullptr;
-    ts.rs = rs;
-    ts.depth = z;
-    ts.n_steps = S;
-    int rc = run_broyden3(fd, w, ts, CanonOut{pts, T, w.q_err}, Q, true, s);
+    int rc = run_broyden3(fd, w, nullptr, CanonOut{pts, T, w.q_err}, Q, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_canon_finalize, dim3(gq), dim3(256), 0, s, fd, (int)Q, (const uint8_t*)w.q_smask,
                        (const float*)w.q_err, pts, T, mask);

@@ -54,20 +54,52 @@ __device__ __forceinline__ void no_pack(f32x4& v) {
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
 }
 
+// Weight fragments are addressed as (wave-uniform 64-bit base) + (per-lane 32-bit byte offset): the base stays in
+// SGPRs and one offset VGPR serves every layer, instead of one 64-bit VGPR pointer per layer and 4 KB window
+// (global_load_dwordx4 v, v_off, s[base:base+1] offset:imm).
+template <typename Tp>
+__device__ __forceinline__ Tp ld_frag(const void* __restrict__ base, unsigned lane_off, int const_off) {
+    return *reinterpret_cast<const Tp*>(reinterpret_cast<const char*>(base) + const_off + (size_t)lane_off);
+}
+
+constexpr float kActScale = 1024.0f;       // activations are stored as f16 pairs of 1024 h
+constexpr float kInvActScale = 1.0f / 1024.0f;
+
+// Phase clocks for the instrumented build (tools/phase_clocks.py, -DARAH_CLOCKS): a wave accumulates the s_memtime
+// ticks it spends between consecutive marks.  NoClk compiles to nothing.
+struct NoClk {
+    __device__ __forceinline__ void mark(int) {}
+};
+struct PhaseClk {
+    unsigned prev;
+    unsigned acc[16];
+    __device__ __forceinline__ void start() {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0;
+        prev = (unsigned)__builtin_amdgcn_s_memtime();
+    }
+    __device__ __forceinline__ void mark(int i) {
+        const unsigned t = (unsigned)__builtin_amdgcn_s_memtime();
+        acc[i] += t - prev;
+        prev = t;
+    }
+};
+
 // acc[m][n] += Wp(rows of M-tiles mt0..mt0+MT-1, KC 16-chunks) * act(64 points)
 template <int KC, int MT, int NT = kNT>
 __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, const float* act, int ld,
                                          f32x4 (&acc)[MT][NT], int lane) {
     const int j = lane & 15, g = lane >> 4;
     const float* bptr = act + j * ld + 4 * g;
-    const f32x4* aptr = reinterpret_cast<const f32x4*>(wp) + (size_t)mt0 * KC * 64 + lane;
+    const unsigned aoff = (unsigned)(mt0 * KC * 64 + lane) * 16u;
+    auto lda = [&](int idx) { return ld_frag<f32x4>(wp, aoff, idx * 1024); };
     if constexpr (KC * MT <= 8) {
         // narrow layer: the whole A slice of this wave is 8 VGPR-quads -- load it once, no dependent waits
         f32x4 a_all[MT][KC];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int kc = 0; kc < KC; ++kc) a_all[m][kc] = aptr[(m * KC + kc) * 64];
+            for (int kc = 0; kc < KC; ++kc) a_all[m][kc] = lda(m * KC + kc);
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             __builtin_amdgcn_sched_barrier(0);   // keep the B fragments of later chunks from being hoisted (VGPRs)
@@ -89,14 +121,14 @@ __device__ __forceinline__ void gemm_acc(const float* __restrict__ wp, int mt0, 
     // SIMD keeps the matrix pipe busy (the ping-pong kernels rely on that)
     f32x4 a_cur[MT], a_nxt[MT], b_cur[NT], b_nxt[NT];
 #pragma unroll
-    for (int m = 0; m < MT; ++m) a_cur[m] = aptr[(m * KC) * 64];
+    for (int m = 0; m < MT; ++m) a_cur[m] = lda(m * KC);
 #pragma unroll
     for (int n = 0; n < NT; ++n) b_cur[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld);
 #pragma unroll 1
     for (int kc = 0; kc < KC; ++kc) {
         const int kn = (kc + 1 < KC) ? kc + 1 : kc;
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a_nxt[m] = aptr[(m * KC + kn) * 64];
+        for (int m = 0; m < MT; ++m) a_nxt[m] = lda(m * KC + kn);
 #pragma unroll
         for (int n = 0; n < NT; ++n) b_nxt[n] = *reinterpret_cast<const f32x4*>(bptr + n * 16 * ld + kn * 16);
 #pragma unroll
@@ -119,11 +151,11 @@ __device__ __forceinline__ f32x4 gemm_one(const float* __restrict__ wp, int mt, 
                                           int lane) {
     const int j = lane & 15, g = lane >> 4;
     const float* bptr = act + (nt * 16 + j) * ld + 4 * g;
-    const f32x4* aptr = reinterpret_cast<const f32x4*>(wp) + (size_t)mt * KC * 64 + lane;
+    const unsigned aoff = (unsigned)(mt * KC * 64 + lane) * 16u;
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
     for (int kc = 0; kc < KC; ++kc) {
-        const f32x4 a = aptr[kc * 64];
+        const f32x4 a = ld_frag<f32x4>(wp, aoff, kc * 1024);
         const f32x4 b = *reinterpret_cast<const f32x4*>(bptr + kc * 16);
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], b[0], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], b[1], acc1, 0, 0, 0);
@@ -137,9 +169,6 @@ __device__ __forceinline__ f32x4 gemm_one(const float* __restrict__ wp, int mt, 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-constexpr float kActScale = 1024.0f;       // activations are stored as f16 pairs of 1024 h
-constexpr float kInvActScale = 1.0f / 1024.0f;
-
 // acc[m][n] += Wsplit(M-tiles mt0..mt0+MT-1, KC32 32-chunks) * act(16 NT points)
 //   weights : wp[((mt*KC32 + kc)*2 + s)*64 + lane]  (s = 0 hi, 1 lo), lane (j, g) holds W[mt*16 + j][kc*32 + 8g .. +7]
 //   act     : LDS rows of ld floats; hi plane at byte 0, lo plane at byte lo_off; lane reads k = kc*32 + 8g .. +7
@@ -151,13 +180,14 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
                                                int lo_off, f32x4 (&acc)[MT][NT], int lane) {
     const int j = lane & 15, g = lane >> 4;
     const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + g * 16;
-    const f16x8* aptr = wp + (size_t)mt0 * KC32 * 2 * 64 + lane;
+    const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
+    auto lda = [&](int idx) { return ld_frag<f16x8>(wp, aoff, idx * 1024); };
     if constexpr (DEEP || KC32 <= 4) {
         f16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            ah[0][m] = aptr[((m * KC32) * 2 + 0) * 64];
-            al[0][m] = aptr[((m * KC32) * 2 + 1) * 64];
+            ah[0][m] = lda(((m * KC32) * 2 + 0));
+            al[0][m] = lda(((m * KC32) * 2 + 1));
         }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -170,8 +200,8 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
             if (kc + 1 < KC32) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) {
-                    ah[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 0) * 64];
-                    al[x][m] = aptr[((m * KC32 + kc + 1) * 2 + 1) * 64];
+                    ah[x][m] = lda(((m * KC32 + kc + 1) * 2 + 0));
+                    al[x][m] = lda(((m * KC32 + kc + 1) * 2 + 1));
                 }
 #pragma unroll
                 for (int n = 0; n < NT; ++n) {
@@ -201,16 +231,16 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
         f16x8 ah[MT], al[MT], ahn[MT], aln[MT];
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-            ah[m] = aptr[((m * KC32) * 2 + 0) * 64];
-            al[m] = aptr[((m * KC32) * 2 + 1) * 64];
+            ah[m] = lda(((m * KC32) * 2 + 0));
+            al[m] = lda(((m * KC32) * 2 + 1));
         }
 #pragma unroll 1
         for (int kc = 0; kc < KC32; ++kc) {
             const int kn = kc + 1 < KC32 ? kc + 1 : kc;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
-                ahn[m] = aptr[((m * KC32 + kn) * 2 + 0) * 64];
-                aln[m] = aptr[((m * KC32 + kn) * 2 + 1) * 64];
+                ahn[m] = lda(((m * KC32 + kn) * 2 + 0));
+                aln[m] = lda(((m * KC32 + kn) * 2 + 1));
             }
             f16x8 bh[NT], bl[NT];
 #pragma unroll
@@ -262,28 +292,43 @@ __device__ __forceinline__ float load_split(const float* act, int ld, int lo_off
 }
 
 // One 16x16 output tile (M-tile mt, N-tile nt) on the split engine: narrow output layers split over waves.
+// The A fragments are a separate step so that the caller can issue their loads (L2 latency) ahead of the barrier and
+// the epilogue that precede the layer; three independent accumulators (one per product class) instead of one chain
+// of 3 KC32 dependent MFMAs.
 template <int KC32>
-__device__ __forceinline__ f32x4 gemm_one_split(const f16x8* __restrict__ wp, int mt, int nt, const float* act, int ld,
-                                                int lo_off, int lane) {
-    const int j = lane & 15, g = lane >> 4;
-    const char* bptr = reinterpret_cast<const char*>(act) + (nt * 16 + j) * ld * 4 + g * 16;
-    const f16x8* aptr = wp + (size_t)mt * KC32 * 2 * 64 + lane;
-    f16x8 ah[KC32], al[KC32], bh[KC32], bl[KC32];
+struct SplitA {
+    f16x8 hi[KC32], lo[KC32];
+};
+template <int KC32>
+__device__ __forceinline__ SplitA<KC32> load_split_a(const f16x8* __restrict__ wp, int mt, int lane) {
+    const unsigned aoff = (unsigned)(mt * KC32 * 2 * 64 + lane) * 16u;
+    SplitA<KC32> a;
 #pragma unroll
     for (int kc = 0; kc < KC32; ++kc) {
-        ah[kc] = aptr[(kc * 2 + 0) * 64];
-        al[kc] = aptr[(kc * 2 + 1) * 64];
+        a.hi[kc] = ld_frag<f16x8>(wp, aoff, (kc * 2 + 0) * 1024);
+        a.lo[kc] = ld_frag<f16x8>(wp, aoff, (kc * 2 + 1) * 1024);
+    }
+    return a;
+}
+template <int KC32>
+__device__ __forceinline__ f32x4 gemm_one_split(const SplitA<KC32>& a, int nt, const float* act, int ld, int lo_off,
+                                                int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const char* bptr = reinterpret_cast<const char*>(act) + (nt * 16 + j) * ld * 4 + g * 16;
+    f16x8 bh[KC32], bl[KC32];
+#pragma unroll
+    for (int kc = 0; kc < KC32; ++kc) {
         bh[kc] = *reinterpret_cast<const f16x8*>(bptr + kc * 64);
         bl[kc] = *reinterpret_cast<const f16x8*>(bptr + lo_off + kc * 64);
     }
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kc = 0; kc < KC32; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[kc], bh[kc], acc, 0, 0, 0);
-#pragma unroll
-    for (int kc = 0; kc < KC32; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bl[kc], acc, 0, 0, 0);
-#pragma unroll
-    for (int kc = 0; kc < KC32; ++kc) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[kc], bh[kc], acc, 0, 0, 0);
-    return acc;
+    for (int kc = 0; kc < KC32; ++kc) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo[kc], bh[kc], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi[kc], bl[kc], acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi[kc], bh[kc], acc2, 0, 0, 0);
+    }
+    return (acc0 + acc1) + acc2;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -562,9 +607,10 @@ __device__ __forceinline__ float softplus100(float x) {
 // xin LDS [16*NT][4] normalised coords -> logits LDS [16*NT][kLogitLd] (25 valid, un-scaled).
 // SPLIT: hidden activations h >= 0 live in LDS as hi/lo f16 planes of S_k h (row = 256 B hi | 256 B lo); S_k comes
 // from a per-frame probe of the network (arah_prepare_frame) with 32x headroom, conversions saturate.
-template <int NT = kNT, bool SPLIT = false>
+// clk marks: 2 = input layer, 3/5/7 = GEMM of hidden layer k, 4/6/8 = its barrier + epilogue, 9 = output layer
+template <int NT = kNT, bool SPLIT = false, typename CLK = NoClk>
 __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, float* act, float* logits, int wave,
-                                         int lane) {
+                                         int lane, CLK&& clk = NoClk()) {
     const int j = lane & 15, g = lane >> 4;
     const int ld = kSkinLd;
     constexpr float kSat = 65504.0f;
@@ -596,6 +642,8 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         }
     }
     ARAH_SYNC();
+    clk.mark(2);
+    SplitA<4> a_out;
 #pragma unroll 1
     for (int k = 1; k < 4; ++k) {
         f32x4 acc[1][NT];
@@ -603,6 +651,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         for (int n = 0; n < NT; ++n) zero_acc(acc[0][n]);
         if (SPLIT) gemm_acc_split<4, 1, NT>(net.wps[k - 1], wave, act, ld, 256, acc, lane);
         else gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
+        clk.mark(1 + 2 * k);
         ARAH_SYNC();
         const int ch0 = wave * 16 + 4 * g;
         f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
@@ -624,14 +673,21 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
                 *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
             }
         }
-        ARAH_SYNC();
+        if (k < 3) {
+            ARAH_SYNC();
+            clk.mark(2 + 2 * k);
+        }
     }
+    // the output layer's A fragments travel (L2 latency) while the workgroup gathers at the barrier
+    if (SPLIT && (wave >> 1) < NT) a_out = load_split_a<4>(net.wps[3], wave & 1, lane);
+    ARAH_SYNC();
+    clk.mark(8);
     {   // output layer 128 -> 25 (padded 32): wave w computes M-tile (w & 1) of N-tile (w >> 1)
         const int mt = wave & 1, nt = wave >> 1;
         if (nt < NT) {
             f32x4 acc;
             if (SPLIT) {
-                acc = gemm_one_split<4>(net.wps[3], mt, nt, act, ld, 256, lane) * net.scales[7];
+                acc = gemm_one_split<4>(a_out, nt, act, ld, 256, lane) * net.scales[7];
             } else {
                 acc = gemm_one<8>(net.w4p, mt, nt, act, ld, lane);
             }
@@ -642,6 +698,7 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         }
     }
     ARAH_SYNC();
+    clk.mark(9);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -59,14 +59,13 @@ __device__ __forceinline__ Dual3 operator/(Dual3 a, Dual3 b) {
     const float q = a.v / b.v, ib = 1.0f / b.v;
     return Dual3{q, {(a.d[0] - q * b.d[0]) * ib, (a.d[1] - q * b.d[1]) * ib, (a.d[2] - q * b.d[2]) * ib}};
 }
-// exp(y) for y <= ~88: explicit ln2 split so that the hardware exp2 only sees |r*log2e| <= 0.5
-// (v_exp_f32 is ~1 ulp there; feeding it y*log2e directly loses |y| ulps of the argument).
+// exp(y), y <= 0 in every use (sigmoid of -|x|, softmax after the max shift): the hardware exp2 fed with y log2(e).
+// The product's rounding perturbs the argument by |y| 2^-24, i.e. the result by that RELATIVE amount: < 1.2e-6 at
+// y = -20, where exp(y) itself is 2e-9 -- far below fp32 resolution of every quantity these exponentials are added
+// to or normalised by (1 + e, sums of softmax terms).  One multiply + one transcendental instead of the ten
+// operations of a Cody-Waite reduction: transcendentals cost ~16 cycles per wave on gfx950, plain VALU ~2.
 __device__ __forceinline__ float exp_fast(float y) {
-    y = fmaxf(y, -87.0f);
-    const float n = rintf(y * 1.44269504088896341f);
-    float r = fmaf(n, -0.693145751953125f, y);
-    r = fmaf(n, -1.42860682030941723212e-6f, r);
-    return ldexpf(__builtin_amdgcn_exp2f(r * 1.44269504088896341f), (int)n);
+    return __builtin_amdgcn_exp2f(fmaxf(y, -126.0f) * 1.44269504088896341f);
 }
 __device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
 
@@ -103,6 +102,18 @@ __device__ __forceinline__ void softmax3(S a, S b, S c, S& oa, S& ob, S& oc) {
     oa = ea / sum;
     ob = eb / sum;
     oc = ec / sum;
+}
+// float version: one reciprocal (1 ulp, refined by one Newton step) shared by the three quotients
+template <>
+__device__ __forceinline__ void softmax3<float>(float a, float b, float c, float& oa, float& ob, float& oc) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    const float ea = exp_fast(a - m), eb = exp_fast(b - m), ec = exp_fast(c - m);
+    const float sum = ea + eb + ec;   // in [1, 3]
+    float r = rcp_fast(sum);
+    r = fmaf(fmaf(-sum, r, 1.0f), r, r);
+    oa = ea * r;
+    ob = eb * r;
+    oc = ec * r;
 }
 
 // 25 logits (already x20) -> 24 weights along the SMPL tree (utils/utils.py:138-181)

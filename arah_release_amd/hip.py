@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libarah_hip.so")
+# ARAH_LIB_PATH: load another build of the same ABI (the instrumented one of tools/phase_clocks.py)
+LIB_PATH = os.environ.get("ARAH_LIB_PATH") or os.path.join(_HERE, "libarah_hip.so")
 
 ARAH_MAX_STEPS = 128
 COLOR_NO_VIEW_DIR = 0

@@ -312,7 +312,7 @@ def test_full_size_properties(scene):
                                      inputs["coord_min"], inputs["coord_max"], inputs["center"])
     ws = hip.Workspace(dev)
     samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
-    pose = torch.eye(4)[:3]
+    pose = torch.eye(4, device=dev)[:3].contiguous()
     cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
     rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam, d, nf, pose)
     torch.cuda.synchronize()
@@ -350,7 +350,7 @@ def test_lazy_shading_is_exact(scene, name):
                                      inputs["coord_min"], inputs["coord_max"], inputs["center"])
     ws = hip.Workspace(dev)
     cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
-    pose = torch.eye(4)[:3]
+    pose = torch.eye(4, device=dev)[:3].contiguous()
     res, ncol = {}, {}
     for full in (False, True):
         for last in (False, True):
@@ -441,7 +441,7 @@ def test_split_engine_matches_exact_fp32_engine(scene):
     np.testing.assert_allclose(feat_s.cpu().numpy(), feat_e.cpu().numpy(), rtol=2e-4, atol=1e-4)
     np.testing.assert_allclose(gs.cpu().numpy(), ge.cpu().numpy(), rtol=2e-3, atol=5e-4)
     samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
-    pose = torch.eye(4)[:3]
+    pose = torch.eye(4, device=dev)[:3].contiguous()
     cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
     rs = hip.render(fs, ws, samp, cam, d, nf, pose)
     re_ = hip.render(fe, ws, samp, cam, d, nf, pose)
@@ -463,7 +463,7 @@ def test_render_is_reproducible_under_load(scene, engine):
     frame, inputs, cfg = _frame_for(scene, "zju377_mono", 512, 11, prec, dev)
     ws = hip.Workspace(dev)
     samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
-    pose = torch.eye(4)[:3]
+    pose = torch.eye(4, device=dev)[:3].contiguous()
     cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
     ref = hip.render(frame, ws, samp, cam, d, nf, pose)
     for _ in range(2):
@@ -535,7 +535,7 @@ def test_config5_stress_1024_128(scene):
                                      inputs["coord_min"], inputs["coord_max"], inputs["center"])
     ws = hip.Workspace(dev)
     samp = hip.Sampling(dev, 128, 32, 32, True, False)
-    pose = torch.eye(4)[:3]
+    pose = torch.eye(4, device=dev)[:3].contiguous()
     cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
     ws.ensure(N, 128)
     ws.reset_counters()
@@ -562,7 +562,7 @@ def test_edge_cases(ctx, scene):
     samp = hip.Sampling(dev, 64, 16, 16, False, False)
     inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
     cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
-    pose = torch.eye(4)[:3]
+    pose = torch.eye(4, device=dev)[:3].contiguous()
     out = hip.render(ctx["frame"], ctx["ws"], samp, cam, d[:0].contiguous(), nf[:0].contiguous(), pose)
     assert out[0].shape == (0, 3)
     nf0 = nf[:128].clone()
