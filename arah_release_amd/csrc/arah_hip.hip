@@ -51,11 +51,28 @@ struct FrameDev {
     const float* verts_raw;   // caller's [n_verts][3]
     const float* vert_weights;
     const float* bones;
-    BodyConst bc;
-    float beta;
+    const float* scal;   // [9] device: trans(3), center(3), coord_min, coord_max, |variance| -- the host never sees them
     int n_verts;
     int split;   // 1: forward SDF trunks run on the f16-split engine (ARAH_PRECISION_SPLIT_F16)
 };
+
+// The per-frame scalars of a kernel: eight scalar loads from a wave-uniform address.  (Kept OUT of the by-value
+// FrameDev argument on purpose: writing into a kernel argument makes the compiler copy the whole struct to scratch,
+// and the dynamically indexed weight pointers then come from there instead of the kernarg segment.)
+__device__ __forceinline__ BodyConst load_bc(const FrameDev& fr) {
+    const float* s = fr.scal;
+    BodyConst bc;
+    bc.trans[0] = s[0];
+    bc.trans[1] = s[1];
+    bc.trans[2] = s[2];
+    bc.center[0] = s[3];
+    bc.center[1] = s[4];
+    bc.center[2] = s[5];
+    bc.cmin = s[6];
+    bc.cmax = s[7];
+    return bc;
+}
+__device__ __forceinline__ float load_beta(const FrameDev& fr) { return fr.scal[8]; }
 
 FrameDev to_dev(const ArahFrame& f) {
     FrameDev d;
@@ -96,13 +113,7 @@ FrameDev to_dev(const ArahFrame& f) {
     d.knn.cells = reinterpret_cast<const unsigned char*>(f.knn_cells);
     d.vert_weights = f.vert_weights;
     d.bones = f.bones;
-    for (int i = 0; i < 3; ++i) {
-        d.bc.trans[i] = f.trans[i];
-        d.bc.center[i] = f.center[i];
-    }
-    d.bc.cmin = f.coord_min;
-    d.bc.cmax = f.coord_max;
-    d.beta = f.beta;
+    d.scal = f.scalars;
     d.n_verts = f.n_verts;
     return d;
 }
@@ -256,6 +267,17 @@ __global__ void k_skin_scales(const unsigned* amax, float* scales) {
     }
     scales[k] = S;
     scales[4 + k] = 1.0f / (split_weight_scale(amax[4 + k]) * S);
+}
+
+// the per-frame scalars stay on the device: trans(3), center(3), coord_min, coord_max, |variance| -> scal[9]
+__global__ void k_gather_scalars(float* __restrict__ dst, const float* trans, const float* center, const float* cmin,
+                                 const float* cmax, const float* beta) {
+    const int i = threadIdx.x;
+    if (i < 3) dst[i] = trans[i];
+    else if (i < 6) dst[i] = center[i - 3];
+    else if (i == 6) dst[i] = cmin[0];
+    else if (i == 7) dst[i] = cmax[0];
+    else if (i == 8) dst[i] = beta ? beta[0] : 1e-3f;
 }
 
 // dst[r][0..3] = {src[r][0..ncol-1], 0...}
@@ -621,13 +643,13 @@ __device__ __forceinline__ bool sphere_may_hold_nn(const f32x4 s, V3 p, float be
 // SRC_SAMPLES: id = list[i] (q = ray*S + s), p = o + z[q] d -> x raw canonical
 // blend the nearest vertex's weights, invert, write the outputs of one query
 template <int SRC>
-__device__ __forceinline__ void nearest_finish(const FrameDev& fr, const float* sb, int i, int id, V3 p, int bi,
+__device__ __forceinline__ void nearest_finish(const FrameDev& fr, const BodyConst& bc, const float* sb, int i, int id, V3 p, int bi,
                                                int* idx_out, float* x_out, float* T_out, CanonSeed* rec_out) {
     float T[16];
     blend(fr.vert_weights + (size_t)bi * 24, sb, T);
-    V3 y = V3{p.x - fr.bc.trans[0], p.y - fr.bc.trans[1], p.z - fr.bc.trans[2]};
+    V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
     V3 xh = inverse_affine_apply(T, y);
-    if (SRC == SRC_RAYS) xh = normalize_pt(fr.bc, xh);
+    if (SRC == SRC_RAYS) xh = normalize_pt(bc, xh);
     if (idx_out) idx_out[id] = bi;
     if (SRC == SRC_SAMPLES && rec_out) {   // loop C starts from here: the seed IS the initial state
         CanonSeed* r = rec_out + i;
@@ -648,7 +670,7 @@ __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const float* 
 // one query; sv / ssph / sb point either into LDS (STRIDE = kClusterLds) or straight at the frame buffer in
 // global memory (STRIDE = kClusterSize), see k_nearest_invlbs
 template <int SRC, int STRIDE>
-__device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const KnnData& kd, const GridInfo& g,
+__device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const BodyConst& bc, const KnnData& kd, const GridInfo& g,
                                                      const float* sv, const float* ssph, const float* sb, int i, int id,
                                                      V3 p, int* idx_out, float* x_out, float* T_out, CanonSeed* rec_out) {
     float best = 3.4e38f;
@@ -710,7 +732,7 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const K
             if (sphere_may_hold_nn(reinterpret_cast<const f32x4*>(ssph)[c], p, fminf(best, cap)))
                 scan_cluster<STRIDE>(sv, c, p, best, bi);
     }
-    nearest_finish<SRC>(fr, sb, i, id, p, bi, idx_out, x_out, T_out, rec_out);
+    nearest_finish<SRC>(fr, bc, sb, i, id, p, bi, idx_out, x_out, T_out, rec_out);
 }
 
 // (d2, index) minimum over the wave, lowest index on ties
@@ -811,6 +833,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
                                                                    const int* count, int n_direct, int wave_below,
                                                                    int* idx_out, float* x_out, float* T_out,
                                                                    CanonSeed* rec_out, unsigned long long* ctr) {
+    const BodyConst bc = load_bc(fr);
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
     if (n >= wave_below) return;
     const GridInfo g = *kd.grid;
@@ -832,7 +855,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
             }
         }
         bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
-        if (lane == 0) nearest_finish<SRC>(fr, fr.bones, i, id, p, bi, idx_out, x_out, T_out, rec_out);
+        if (lane == 0) nearest_finish<SRC>(fr, bc, fr.bones, i, id, p, bi, idx_out, x_out, T_out, rec_out);
     }
 }
 
@@ -842,6 +865,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
                                                                  const int* count, int n_direct, int wave_below,
                                                                  int* idx_out, float* x_out, float* T_out,
                                                                  CanonSeed* rec_out, unsigned long long* ctr) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
     // ray / point lists are spread evenly over the grid (the table fill is per workgroup: one workgroup per CU,
@@ -869,7 +893,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         for (int i = blockIdx.x * per + t; i < end; i += blockDim.x) {
             int id;
             const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
-            nearest_invlbs_point<SRC, kClusterLds>(fr, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
+            nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
         }
         return;
     }
@@ -879,7 +903,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         if (i >= n) continue;
         int id;
         const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
-        nearest_invlbs_point<SRC, kClusterLds>(fr, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
+        nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
     }
 }
 
@@ -922,6 +946,7 @@ __global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(
                                                         const int* count, int n_direct, float* sdf_out,
                                                         float* feat_out, float* grad_out, f32x4* spill_all,
                                                         unsigned long long* ctr_fwd, unsigned long long* ctr_grad) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                       // [64][4]
     float* outv = xin + 64 * 4;              // [64][4]
@@ -992,7 +1017,7 @@ struct TraceState {
 constexpr int kNarrowBelow = 16 * 512;
 
 template <int NT, bool SPLIT>
-__device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceState& st, const int* list, int n,
+__device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const BodyConst& bc, const TraceState& st, const int* list, int n,
                                                 int* next_list, int* next_count, unsigned long long* ctr_fwd,
                                                 float* smem) {
     constexpr int TW = 16 * NT;
@@ -1001,7 +1026,7 @@ __device__ __forceinline__ void sdf_march_tiles(const FrameDev& fr, const TraceS
     int* ids = reinterpret_cast<int*>(outv + 64 * 4);
     float* actA = reinterpret_cast<float*>(ids + 64);
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const float scale = sdf_scale(fr.bc);
+    const float scale = sdf_scale(bc);
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
         if (tid < TW) {
             const int i = tile * TW + tid;
@@ -1042,10 +1067,11 @@ template <bool SPLIT>
 __global__ __launch_bounds__(kThreads, 4) void k_sdf_march(FrameDev fr, TraceState st, const int* list, const int* count,
                                                          int* next_list, int* next_count,
                                                          unsigned long long* ctr_fwd) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *count;
-    if (n < kNarrowBelow) sdf_march_tiles<1, SPLIT>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
-    else sdf_march_tiles<kNT, SPLIT>(fr, st, list, n, next_list, next_count, ctr_fwd, smem);
+    if (n < kNarrowBelow) sdf_march_tiles<1, SPLIT>(fr, bc, st, list, n, next_list, next_count, ctr_fwd, smem);
+    else sdf_march_tiles<kNT, SPLIT>(fr, bc, st, list, n, next_list, next_count, ctr_fwd, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1053,6 +1079,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_sdf_march(FrameDev fr, TraceSta
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads, 4) void k_skin_eval(FrameDev fr, const float* x_hat, int n, float* w_out,
                                                          float* xbar_out, float* T_out, unsigned long long* ctr) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [64][4] normalised
     float* xraw = xin + 64 * 4;               // [64][4] raw
@@ -1066,7 +1093,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_skin_eval(FrameDev fr, const fl
             const int i = tile * kTile + tid;
             V3 p = V3{0.f, 0.f, 0.f};
             if (i < n) p = V3{x_hat[(size_t)i * 3], x_hat[(size_t)i * 3 + 1], x_hat[(size_t)i * 3 + 2]};
-            const V3 q = normalize_pt(fr.bc, p);
+            const V3 q = normalize_pt(bc, p);
             reinterpret_cast<f32x4*>(xin)[tid] = f32x4{q.x, q.y, q.z, 0.f};
             reinterpret_cast<f32x4*>(xraw)[tid] = f32x4{p.x, p.y, p.z, 0.f};
         }
@@ -1102,6 +1129,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_skin_eval(FrameDev fr, const fl
 __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float* x_hat, const int* list,
                                                         const int* count, int n_direct, float* jac_out,
                                                         unsigned long long* ctr) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [16][4] normalised
     float* xraw = xin + 16 * 4;               // [16][4]
@@ -1112,7 +1140,7 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
     const int j = lane & 15, g = lane >> 4;
     const int n = list ? *count : n_direct;
     const int ld = kSkinLd;
-    const float sN = 2.0f / (1.1f * (fr.bc.cmax - fr.bc.cmin));   // d x_norm / d x_hat
+    const float sN = 2.0f / (1.1f * (bc.cmax - bc.cmin));   // d x_norm / d x_hat
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * 16 < n; tile += gridDim.x) {
         if (tid < 16) {
@@ -1122,7 +1150,7 @@ __global__ __launch_bounds__(kThreads) void k_skin_jac(FrameDev fr, const float*
                 const int id = list ? list[i] : i;
                 p = V3{x_hat[(size_t)id * 3], x_hat[(size_t)id * 3 + 1], x_hat[(size_t)id * 3 + 2]};
             }
-            const V3 q = normalize_pt(fr.bc, p);
+            const V3 q = normalize_pt(bc, p);
             reinterpret_cast<f32x4*>(xin)[tid] = f32x4{q.x, q.y, q.z, 0.f};
             reinterpret_cast<f32x4*>(xraw)[tid] = f32x4{p.x, p.y, p.z, 0.f};
         }
@@ -1314,6 +1342,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const f32x4* __restrict__ seeds,
                                                              const int* count, int* queue_head, CanonOut outp,
                                                              unsigned long long* ctr, unsigned long long* clk_out) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     KernelClk clk;
 #ifdef ARAH_CLOCKS
@@ -1393,7 +1422,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
             if (g == 0) {
                 f32x4 xn = {0.f, 0.f, 0.f, 0.f};
                 if (id >= 0) {
-                    const V3 q = normalize_pt(fr.bc, V3{st[ST_X], st[ST_X + 1], st[ST_X + 2]});
+                    const V3 q = normalize_pt(bc, V3{st[ST_X], st[ST_X + 1], st[ST_X + 2]});
                     xn = f32x4{q.x, q.y, q.z, 0.f};
                 }
                 reinterpret_cast<f32x4*>(xin)[slot] = xn;
@@ -1548,6 +1577,7 @@ struct Broyden4State {
 __global__ void k_joint_init(FrameDev fr, Broyden4State st, RaySet rs, const int* list, const int* count,
                              const float* grad_sdf, const float* jac_lbs, const float* xcur_norm, const float* t,
                              float* x0_raw) {
+    const BodyConst bc = load_bc(fr);
     const int n = *count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int id = list[i];
@@ -1573,7 +1603,7 @@ __global__ void k_joint_init(FrameDev fr, Broyden4State st, RaySet rs, const int
 }
 
 template <bool FIRST, int NT, bool SPLIT>
-__device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4State& st, const RaySet& rs, const int* list,
+__device__ __forceinline__ void joint_tiles(const FrameDev& fr, const BodyConst& bc, const Broyden4State& st, const RaySet& rs, const int* list,
                                             int n, int* next_list, int* next_count, unsigned long long* ctr_skin,
                                             unsigned long long* ctr_sdf, float* smem) {
     constexpr int TW = 16 * NT;
@@ -1585,7 +1615,7 @@ __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4St
     float* logits = reinterpret_cast<float*>(ids + 64);    // [64][33]
     float* act = logits + 64 * kLogitLd;   // 64*33 floats is a multiple of 4: stays 16-byte aligned, stays an LDS pointer   // [64][260]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const float scale = sdf_scale(fr.bc);
+    const float scale = sdf_scale(bc);
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
         if (tid < TW) {
@@ -1594,7 +1624,7 @@ __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4St
             ids[tid] = id;
             f32x4 u = {0.f, 0.f, 0.f, 0.f};
             if (id >= 0) u = reinterpret_cast<const f32x4*>(st.ueval)[id];
-            const V3 q = normalize_pt(fr.bc, V3{u[0], u[1], u[2]});
+            const V3 q = normalize_pt(bc, V3{u[0], u[1], u[2]});
             reinterpret_cast<f32x4*>(xin)[tid] = f32x4{q.x, q.y, q.z, 0.f};
             reinterpret_cast<f32x4*>(xraw)[tid] = u;
         }
@@ -1618,8 +1648,8 @@ __device__ __forceinline__ void joint_tiles(const FrameDev& fr, const Broyden4St
                 const f32x4 u = reinterpret_cast<const f32x4*>(xraw)[tid];
                 skin_tail(logits + tid * kLogitLd, sbones, V3{u[0], u[1], u[2]}, T, xb);
                 const V3 p = ray_point(rs, id, u[3]);                    // RFU:435-436
-                float gnew[4] = {outv[tid * 4] * scale, xb.x - (p.x - fr.bc.trans[0]), xb.y - (p.y - fr.bc.trans[1]),
-                                 xb.z - (p.z - fr.bc.trans[2])};
+                float gnew[4] = {outv[tid * 4] * scale, xb.x - (p.x - bc.trans[0]), xb.y - (p.y - bc.trans[1]),
+                                 xb.z - (p.z - bc.trans[2])};
                 float J[16], stp[4];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) J[e] = st.Jinv[(size_t)id * 16 + e];
@@ -1679,10 +1709,11 @@ __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4St
                                                           const int* count, int* next_list, int* next_count,
                                                           unsigned long long* ctr_skin,
                                                           unsigned long long* ctr_sdf) {
+    const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = *count;
-    if (n < kNarrowBelow) joint_tiles<FIRST, 1, SPLIT>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
-    else joint_tiles<FIRST, kNT, SPLIT>(fr, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
+    if (n < kNarrowBelow) joint_tiles<FIRST, 1, SPLIT>(fr, bc, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
+    else joint_tiles<FIRST, kNT, SPLIT>(fr, bc, st, rs, list, n, next_list, next_count, ctr_skin, ctr_sdf, smem);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1710,10 +1741,11 @@ __global__ void k_trace_begin(const float* near_far, int n, float* t, float* far
 __global__ void k_joint_select(FrameDev fr, int n, const float* xcur_norm, const float* Tcur, const float* t,
                                const uint8_t* diverged, int root_find_all, float* x0_raw, float* xbest, float* zbest,
                                float* Tbest, float* err_best, int* list, int* count) {
+    const BodyConst bc = load_bc(fr);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     if (i < n) {
-        const V3 xr = unnormalize_pt(fr.bc, V3{xcur_norm[(size_t)i * 3], xcur_norm[(size_t)i * 3 + 1], xcur_norm[(size_t)i * 3 + 2]});   // RT:245
+        const V3 xr = unnormalize_pt(bc, V3{xcur_norm[(size_t)i * 3], xcur_norm[(size_t)i * 3 + 1], xcur_norm[(size_t)i * 3 + 2]});   // RT:245
         x0_raw[(size_t)i * 3] = xbest[(size_t)i * 3] = xr.x;
         x0_raw[(size_t)i * 3 + 1] = xbest[(size_t)i * 3 + 1] = xr.y;
         x0_raw[(size_t)i * 3 + 2] = xbest[(size_t)i * 3 + 2] = xr.z;
@@ -1729,12 +1761,13 @@ __global__ void k_joint_select(FrameDev fr, int n, const float* xcur_norm, const
 __global__ void k_trace_finalize(FrameDev fr, int n, const float* near_far, const float* xbest, const float* zbest,
                                  const float* err_best, float* points_hat_norm, uint8_t* conv, float* start,
                                  float* end) {
+    const BodyConst bc = load_bc(fr);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float nr = near_far[i * 2], fa = near_far[i * 2 + 1];
     const float z = zbest[i];
     const bool c = (err_best[i] < kRootThresh) && (z >= nr) && (z <= fa);
-    const V3 xn = normalize_pt(fr.bc, V3{xbest[(size_t)i * 3], xbest[(size_t)i * 3 + 1], xbest[(size_t)i * 3 + 2]});
+    const V3 xn = normalize_pt(bc, V3{xbest[(size_t)i * 3], xbest[(size_t)i * 3 + 1], xbest[(size_t)i * 3 + 2]});
     points_hat_norm[(size_t)i * 3] = xn.x;
     points_hat_norm[(size_t)i * 3 + 1] = xn.y;
     points_hat_norm[(size_t)i * 3 + 2] = xn.z;
@@ -1852,6 +1885,7 @@ __global__ void k_iota(int n, int* list, int* count) {
 // RT:447-461, 549-555: normalise the solution, converged = |g|_best < thr; masked-off samples are zeros
 __global__ void k_canon_finalize(FrameDev fr, int nq, const uint8_t* sample_mask, const float* err_best, float* pts,
                                  float* T, uint8_t* conv) {
+    const BodyConst bc = load_bc(fr);
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= nq) return;
     if (!sample_mask[q]) {
@@ -1860,7 +1894,7 @@ __global__ void k_canon_finalize(FrameDev fr, int nq, const uint8_t* sample_mask
         conv[q] = 0;
         return;
     }
-    const V3 xn = normalize_pt(fr.bc, V3{pts[(size_t)q * 3], pts[(size_t)q * 3 + 1], pts[(size_t)q * 3 + 2]});
+    const V3 xn = normalize_pt(bc, V3{pts[(size_t)q * 3], pts[(size_t)q * 3 + 1], pts[(size_t)q * 3 + 2]});
     pts[(size_t)q * 3] = xn.x;
     pts[(size_t)q * 3 + 1] = xn.y;
     pts[(size_t)q * 3 + 2] = xn.z;
@@ -1892,6 +1926,7 @@ template <bool SPLIT>
 __global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
                                                        f32x4* shaded, int* next_list, int* next_count,
                                                        unsigned long long* ctr_fwd, unsigned long long* ctr_dens) {
+    const BodyConst bc = load_bc(fr);
     constexpr int TW = kTile;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                                   // [TW][4]
@@ -1900,8 +1935,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const floa
     float* actA = reinterpret_cast<float*>(ids + TW);    // [64][260]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = *count;
-    const float scale = sdf_scale(fr.bc);
-    const float inv_beta = 1.0f / fminf(fmaxf(fabsf(fr.beta), 1e-6f), 1e6f);
+    const float scale = sdf_scale(bc);
+    const float inv_beta = 1.0f / fminf(fmaxf(fabsf(load_beta(fr)), 1e-6f), 1e6f);
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
         if (tid < TW) {
             const int i = tile * TW + tid;
@@ -1944,6 +1979,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
                                                      const int* count, int n_direct, f32x4* shaded,
                                                      f32x4* spill_all, unsigned long long* ctr_fwd,
                                                      unsigned long long* ctr_grad, unsigned long long* ctr_col) {
+    const BodyConst bc = load_bc(fr);
     typedef ColDims<IDR> D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [64][4]
@@ -1955,8 +1991,8 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = list ? *count : n_direct;
     f32x4* spill = spill_all + (size_t)blockIdx.x * kSpillPerWg;
-    const float scale = sdf_scale(fr.bc);
-    const float beta = fminf(fmaxf(fabsf(fr.beta), 1e-6f), 1e6f);   // IDR:366
+    const float scale = sdf_scale(bc);
+    const float beta = fminf(fmaxf(fabsf(load_beta(fr)), 1e-6f), 1e6f);   // IDR:366
     const float inv_beta = 1.0f / beta;
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
         if (tid < kTile) {
@@ -2051,6 +2087,7 @@ template <bool IDR>
 __global__ __launch_bounds__(kThreads) void k_color_eval(FrameDev fr, const float* x_norm, const float* normal,
                                                           const float* view, const float* feat, int n, float* rgb,
                                                           unsigned long long* ctr) {
+    const BodyConst bc = load_bc(fr);
     typedef ColDims<IDR> D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* rgbv = smem;                        // [64][4]
@@ -2151,11 +2188,12 @@ __global__ void k_composite(int n, int S, int render_last_pt, const float* z, co
 // IDR:114-115, 142-143, 251: camera-space surface points, zeroed off-surface
 __global__ void k_points_cam(FrameDev fr, int n, RaySet rs, const float* dists, const uint8_t* conv,
                              const float* points_hat_norm, const float* __restrict__ pose, float* points_cam) {
+    const BodyConst bc = load_bc(fr);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const V3 pw = ray_point(rs, i, dists[i]);
-    const float wx = (pw.x - fr.bc.trans[0]) + fr.bc.trans[0], wy = (pw.y - fr.bc.trans[1]) + fr.bc.trans[1],
-                wz = (pw.z - fr.bc.trans[2]) + fr.bc.trans[2];
+    const float wx = (pw.x - bc.trans[0]) + bc.trans[0], wy = (pw.y - bc.trans[1]) + bc.trans[1],
+                wz = (pw.z - bc.trans[2]) + bc.trans[2];
     const float ax = fabsf(points_hat_norm[(size_t)i * 3]), ay = fabsf(points_hat_norm[(size_t)i * 3 + 1]),
                 az = fabsf(points_hat_norm[(size_t)i * 3 + 2]);
     const bool surf = conv[i] && ax <= 1.0f && ay <= 1.0f && az <= 1.0f;
@@ -2398,7 +2436,7 @@ struct FrameLayout {
     size_t sdf_wps[5], sdf_fw, sdf_pw, sdf_fws, sdf_amax;
     size_t skin_w0, skin_wp[3], skin_w4p, skin_bias, skin_wps[4], skin_scales, skin_amax;
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
-    size_t verts4, knn_spheres, knn_grid, knn_cells;
+    size_t verts4, knn_spheres, knn_grid, knn_cells, scalars;
     size_t bytes;
 };
 
@@ -2445,6 +2483,7 @@ FrameLayout frame_layout(int col_mode) {
     L.knn_spheres = take((size_t)kMaxClusters * 4);
     L.knn_grid = take(sizeof(GridInfo) / 4);
     L.knn_cells = take((size_t)kMaxCells * kCellBytes / 4);
+    L.scalars = take(64);
     L.bytes = align_up(off, 256);
     return L;
 }
@@ -2587,6 +2626,9 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         hipLaunchKernelGGL(k_copy, dim3(1), dim3(4), 0, s, cb + 1152, nets->col_b[5], 3, 4);
     }
     // ---- body
+    if (!body->trans || !body->center || !body->coord_min || !body->coord_max) return ARAH_E_BADARG;
+    hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, s, P(L.scalars), body->trans, body->center, body->coord_min,
+                       body->coord_max, nets->beta);
     // ---- body: Morton-sorted vertices, cluster spheres, per-cell candidate clusters (exact 1-NN acceleration)
     hipLaunchKernelGGL(k_sort_verts, dim3(1), dim3(1024), 0, s, body->verts, body->n_verts, P(L.verts4),
                        reinterpret_cast<GridInfo*>(base + L.knn_grid));
@@ -2631,13 +2673,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->vert_weights = body->vert_weights;
     out->bones = body->bones;
     out->sdf_b6 = P(L.sdf_b6);
-    out->beta = nets->beta;
-    for (int i = 0; i < 3; ++i) {
-        out->trans[i] = body->trans[i];
-        out->center[i] = body->center[i];
-    }
-    out->coord_min = body->coord_min;
-    out->coord_max = body->coord_max;
+    out->scalars = P(L.scalars);
     out->n_verts = body->n_verts;
     out->col_mode = nets->col_mode;
     return check_launch();

@@ -38,14 +38,13 @@ _fp = C.c_void_p  # device float*
 class ArahNets(C.Structure):
     _fields_ = [("sdf_w", _fp * 7), ("sdf_b", _fp * 7), ("film_freq", _fp), ("film_phase", _fp),
                 ("skin_w", _fp * 5), ("skin_b", _fp * 5), ("col_w", _fp * 6), ("col_b", _fp * 6),
-                ("pose_vec", _fp), ("col_mode", C.c_int32), ("n_pose", C.c_int32), ("beta", C.c_float),
+                ("pose_vec", _fp), ("col_mode", C.c_int32), ("n_pose", C.c_int32), ("beta", _fp),
                 ("precision", C.c_int32)]
 
 
 class ArahBody(C.Structure):
-    _fields_ = [("verts", _fp), ("vert_weights", _fp), ("bones", _fp), ("trans", C.c_float * 3),
-                ("center", C.c_float * 3), ("coord_min", C.c_float), ("coord_max", C.c_float),
-                ("n_verts", C.c_int32)]
+    _fields_ = [("verts", _fp), ("vert_weights", _fp), ("bones", _fp), ("trans", _fp), ("center", _fp),
+                ("coord_min", _fp), ("coord_max", _fp), ("n_verts", C.c_int32)]
 
 
 class ArahSampling(C.Structure):
@@ -64,8 +63,7 @@ class ArahFrame(C.Structure):
                 ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
                 ("verts4", _fp), ("knn_spheres", _fp), ("knn_grid", _fp), ("knn_cells", _fp),
                 ("verts", _fp), ("vert_weights", _fp), ("bones", _fp),
-                ("beta", C.c_float), ("trans", C.c_float * 3), ("center", C.c_float * 3),
-                ("coord_min", C.c_float), ("coord_max", C.c_float), ("n_verts", C.c_int32),
+                ("scalars", _fp), ("n_verts", C.c_int32),
                 ("col_mode", C.c_int32), ("precision", C.c_int32)]
 
 
@@ -245,6 +243,13 @@ class Frame:
             keep.append(t)
             return t
 
+        def scalar_tensor(v, n):
+            """Per-frame scalars (trans, center, coord_min/max, |variance|) stay on the device: tensors are used as
+            they are (no .item() / .tolist(): those drain the stream); python numbers are uploaded."""
+            if isinstance(v, torch.Tensor):
+                return v.to(device=dev, dtype=torch.float32).reshape(-1)[:n]
+            return torch.tensor(v, dtype=torch.float32, device=dev).reshape(-1)[:n]
+
         nets = ArahNets()
         if color_layers is None:   # tracer-only use: the colour MLP is never evaluated
             color_mode, pose_vec = COLOR_NO_VIEW_DIR, None
@@ -277,16 +282,14 @@ class Frame:
         nets.pose_vec = _ptr(own(pose_vec.reshape(-1))) if n_pose else None
         nets.col_mode = int(color_mode)
         nets.n_pose = n_pose
-        nets.beta = float(beta)
+        nets.beta = _ptr(own(scalar_tensor(beta, 1)))
         nets.precision = default_precision() if precision is None else int(precision)
         self.precision = nets.precision
         body = ArahBody()
         self.verts, self.vert_weights, self.bones = own(verts), own(vert_weights), own(bones.reshape(24, 16))
         body.verts, body.vert_weights, body.bones = _ptr(self.verts), _ptr(self.vert_weights), _ptr(self.bones)
-        for i in range(3):
-            body.trans[i] = float(trans[i])
-            body.center[i] = float(center[i])
-        body.coord_min, body.coord_max = float(coord_min), float(coord_max)
+        body.trans, body.center = _ptr(own(scalar_tensor(trans, 3))), _ptr(own(scalar_tensor(center, 3)))
+        body.coord_min, body.coord_max = _ptr(own(scalar_tensor(coord_min, 1))), _ptr(own(scalar_tensor(coord_max, 1)))
         body.n_verts = int(verts.shape[0])
         _same_device(*keep)
         nbytes = lib.arah_frame_bytes(C.byref(nets), C.byref(body))

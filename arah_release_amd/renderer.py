@@ -74,11 +74,12 @@ def build_frame(sdf_network, skinning_model, rendering_network, deviation_networ
                 raise ValueError("kernels are built for the 5-hidden-layer colour MLP with a skip at 3")
             color_layers = _mlp_layers(rn)
             pose_vec = rn.pose_vector(pose_cond)
-            beta = float(torch.linalg.norm(deviation_network.variance))
+            beta = torch.linalg.norm(deviation_network.variance).reshape(1)   # decoder.py:132-133; stays on the device
+        # trans / center / coord_min / coord_max go down as device tensors: no host copy, no stream drain per frame
         return hip.Frame(sdf_layers, freq, phase, skin_layers, color_layers, mode, pose_vec, beta,
-                         smpl_verts[0], skinning_weights[0], bone_transforms[0], trans.reshape(-1)[:3].tolist(),
-                         center.reshape(-1)[:3].tolist(), float(coord_min.reshape(-1)[0]),
-                         float(coord_max.reshape(-1)[0]), precision=precision)
+                         smpl_verts[0], skinning_weights[0], bone_transforms[0], trans.reshape(-1)[:3],
+                         center.reshape(-1)[:3], coord_min.reshape(-1)[:1], coord_max.reshape(-1)[:1],
+                         precision=precision)
 
 
 class BodyRayTracing(nn.Module):

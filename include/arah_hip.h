@@ -80,7 +80,7 @@ typedef struct ArahNets {
     const float* pose_vec;      /* [n_pose] per-frame constant tail of the colour input (may be NULL if n_pose==0) */
     int32_t col_mode;           /* ARAH_COLOR_* */
     int32_t n_pose;             /* 128 for color_pose_encoder 'latent' */
-    float beta;                 /* |variance|, un-clipped */
+    const float* beta;          /* [1] DEVICE: |variance|, un-clipped (NULL: 1e-3, the reference's initial value) */
     int32_t precision;          /* ARAH_PRECISION_* */
 } ArahNets;
 
@@ -90,9 +90,12 @@ typedef struct ArahBody {
     const float* verts;         /* [n_verts,3] posed + trans */
     const float* vert_weights;  /* [n_verts,24] */
     const float* bones;         /* [24,4,4] */
-    float trans[3];
-    float center[3];
-    float coord_min, coord_max;
+    /* the four per-frame scalars are DEVICE pointers too: they are inputs of the forward (dataset tensors) and are
+     * consumed by the kernels only, so that building a frame needs no device->host copy and no stream drain */
+    const float* trans;         /* [3] */
+    const float* center;        /* [3] */
+    const float* coord_min;     /* [1] */
+    const float* coord_max;     /* [1] */
     int32_t n_verts;            /* <= 6912 */
 } ArahBody;
 
@@ -146,10 +149,7 @@ typedef struct ArahFrame {
     const float* verts;         /* caller's [n_verts][3] */
     const float* vert_weights;  /* caller's */
     const float* bones;         /* caller's [24][16] */
-    float beta;
-    float trans[3];
-    float center[3];
-    float coord_min, coord_max;
+    const float* scalars;       /* [9] device: trans(3), center(3), coord_min, coord_max, |variance| */
     int32_t n_verts;
     int32_t col_mode;
     int32_t precision;          /* ARAH_PRECISION_* the frame was prepared for */

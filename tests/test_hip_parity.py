@@ -50,14 +50,16 @@ def test_struct_sizes_match_header():
     """ctypes mirrors of the POD structs must have the C layout (pointer + int32/float fields)."""
     import ctypes as C
     from arah_release_amd import hip
-    assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 4 * 4   # col_mode, n_pose, beta, precision
-    n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 8 + 4 + 3   # sdf, skin, colour, knn, body pointers
-    assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * (1 + 3 + 3 + 2 + 3)   # beta, trans, center, min/max, 3 ints
+    # pointers ..., col_mode, n_pose (8 bytes), beta (device pointer), precision (+ 4 bytes of tail padding)
+    assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 8 + 8 + 8
+    assert C.sizeof(hip.ArahBody) == 8 * 7 + 8   # seven device pointers, n_verts (+ padding)
+    n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 8 + 4 + 3 + 1   # sdf, skin, colour, knn, body, scalars
+    assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * 3 + 4   # three ints (+ padding)
     assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
     assert C.sizeof(hip.ArahCounters) == 64
 
 
-@pytest.mark.parametrize("name", ["gemm_f16x3", "trunk_repro", "gemm_loop", "mfma_f32_peak"])
+@pytest.mark.parametrize("name", ["gemm_f16x3", "trunk_repro", "gemm_loop", "mfma_f32_peak", "mfma_valu_overlap"])
 def test_microbenchmarks_compile(name, tmp_path):
     """tools/ubench/*.hip include the product's mlp.hpp; keep them compiling for gfx950."""
     import shutil
