@@ -172,22 +172,76 @@ def get_model(cfg, dataset=None, val_size=None, mode="train", low_vram=False, ch
 # ---------------------------------------------------------------------------------------------
 # synthetic weights (no reference checkpoint is redistributable)
 # ---------------------------------------------------------------------------------------------
-def synthetic_state_dict(cfg, asset_path=None):
-    """State-dict entries (reference names) that turn a freshly built model into the synthetic subject:
-    fitted SIREN in the ``hypo_params_init`` buffers, fixed FiLM vectors in the mapping network's last
-    bias, fitted skinning MLP, seeded colour MLP / latent codes / beta."""
-    path = asset_path or os.path.join(_ASSETS, "synthetic_weights.npz")
-    a = np.load(path)
+_REF_POSE_FRAME = 10007   # pose at which the synthetic hypernetwork reproduces the fitted SIREN exactly
+_HYPER_CACHE = {}
+
+
+def _synthetic_hyper_state(a, seed=0):
+    """COMPLETE state of the SDF hypernetwork (every parameter and buffer of ``sdf_decoder``, reference names), built
+    once per process.
+
+    Pose / latent dependence (SURVEY 8a2): a fresh model's residual heads end in an all-zero layer
+    (hyperlayers.py:418-423), so that the pose encoder -> FCBlock / LayerNorm -> weight-reshape path would contribute
+    exactly nothing and every gradient upstream of the heads would vanish.  Here the heads' last layers and the last
+    layer of the FiLM mapping network are seeded and NON-ZERO; ``hypo_params_init`` and the mapping network's last
+    bias are shifted so that the emitted network equals the fitted SIREN at ONE reference pose / latent code that no
+    test uses (frame %d, a latent code of all 0.5): every other pose emits the fitted weights plus a pose-dependent
+    residual (a few 1e-3 of the SDF's range -- millimetres of geometry, three orders above the parity tolerances).
+    All remaining hypernetwork parameters (pose encoder, hidden layers of the heads, LayerNorms, mapping network)
+    are part of the returned state too, so that the reference's own module, whose initialisers draw random numbers in
+    another order, becomes the SAME function.""" % _REF_POSE_FRAME
+    key = (id(a), seed)
+    if key in _HYPER_CACHE:
+        return _HYPER_CACHE[key]
+    from . import synthetic
     t = lambda k: torch.from_numpy(np.asarray(a[k], dtype=np.float32))
-    sd = {}
-    for i in range(7):
-        flat = torch.cat([t("sdf_w%d" % i).reshape(-1), t("sdf_b%d" % i).reshape(-1)]).reshape(1, -1)
-        key = ("sdf_decoder.net.layers.%d.hyper_linear.hypo_params_init" % i) if i < 6 else \
-            "sdf_decoder.net.layers.6.hypo_params_init"
-        sd[key] = flat
-    sd["sdf_decoder.net.mapping_network.network.6.bias"] = torch.cat([t("film_freq").reshape(-1),
-                                                                       t("film_phase").reshape(-1)])
-    sd["sdf_decoder.net.mapping_network.network.6.weight"] = torch.zeros(6 * 256 * 2, 256)
+    rng = torch.random.get_rng_state()
+    torch.manual_seed(seed)
+    dec = nets.decoder_dict["hyper_bvp"](**_SDF_KW)
+    torch.random.set_rng_state(rng)
+
+    def seeded(shape, std, s_):
+        g = torch.Generator().manual_seed(s_)
+        return torch.randn(shape, generator=g) * std
+
+    with torch.no_grad():
+        heads = [l.hyper_linear.hypo_params for l in dec.net.layers[:-1]] + [dec.net.layers[-1].hypo_params]
+        for i, h in enumerate(heads):
+            std = 6.0e-4 if i == 0 else 9.0e-6   # residual ~ a few 1e-3 of the layer's weight scale between two poses
+            h.net[2].weight.copy_(seeded(tuple(h.net[2].weight.shape), std, 7000 + i))
+            h.net[2].bias.copy_(seeded(tuple(h.net[2].bias.shape), std, 7100 + i))
+        last = dec.net.mapping_network.network[6]
+        last.weight.copy_(seeded(tuple(last.weight.shape), 5.0e-5, 7200))
+        # reference condition: pose of a frame no test renders, latent code 0.5 * ones
+        scene = synthetic.SyntheticScene(0)
+        fr = scene.frame(_REF_POSE_FRAME)
+        rots = torch.from_numpy(fr["rots_local"].reshape(1, 24, 9).copy())
+        rots[0, 0] = torch.eye(3).reshape(9)
+        Jn = torch.from_numpy(synthetic.normalize_points_np(scene.joints, scene.coord_min, scene.coord_max,
+                                                            scene.center).astype(np.float32))[None]
+        cond = dec.pose_encoder(rots, Jn)
+        for i, h in enumerate(heads):
+            fitted = torch.cat([t("sdf_w%d" % i).reshape(-1), t("sdf_b%d" % i).reshape(-1)]).reshape(1, -1)
+            holder = dec.net.layers[i].hyper_linear if i < 6 else dec.net.layers[6]
+            holder.hypo_params_init.copy_(fitted - h(cond))
+        film = torch.cat([t("film_freq").reshape(-1), t("film_phase").reshape(-1)])
+        last.bias.zero_()
+        last.bias.copy_(film - dec.net.mapping_network.network(torch.full((1, 128), 0.5))[0])
+    sd = {"sdf_decoder." + k: v.detach().clone() for k, v in dec.state_dict().items()}
+    _HYPER_CACHE[key] = sd
+    return sd
+
+
+def synthetic_state_dict(cfg, asset_path=None):
+    """State-dict entries (reference names) that turn a freshly built model into the synthetic subject: the complete
+    SDF hypernetwork (fitted SIREN + seeded pose / latent dependence, see _synthetic_hyper_state), fitted skinning
+    MLP, seeded colour MLP / latent codes / beta."""
+    path = asset_path or os.path.join(_ASSETS, "synthetic_weights.npz")
+    if path not in _HYPER_CACHE:
+        _HYPER_CACHE[path] = np.load(path)
+    a = _HYPER_CACHE[path]
+    t = lambda k: torch.from_numpy(np.asarray(a[k], dtype=np.float32))
+    sd = dict(_synthetic_hyper_state(a))
     tag = cfg["model"]["renderer_kwargs"]["mode"]
     for k in a.files:
         if k.startswith("skin."):
@@ -200,8 +254,8 @@ def synthetic_state_dict(cfg, asset_path=None):
 
 
 def build_synthetic_model(name="zju377_mono", n_steps=64, near=16, far=16, device="cpu", seed=0, training=None):
-    """Builtin config + synthetic weights; deterministic (the hyper heads are seeded but irrelevant:
-    their last layer is zero, so the emitted SDF MLP equals the fitted one for every pose)."""
+    """Builtin config + synthetic weights; deterministic.  The emitted SDF MLP is the fitted SIREN plus a seeded,
+    pose- and latent-dependent residual of about a percent per weight (synthetic_state_dict)."""
     cfg = builtin_config(name, n_steps, near, far)
     if training:
         cfg["training"].update(training)

@@ -1757,6 +1757,42 @@ __global__ void k_joint_select(FrameDev fr, int n, const float* xcur_norm, const
     append_ids(keep, i, list, count);
 }
 
+// unit seam of loop B (search_iso_surface_depth on caller-supplied starts, RFU:365-484): seed the per-ray arrays from
+// (x0, z0, T0, valid); rays outside `valid` keep their start and never count as converged (RFU:473-484)
+__global__ void k_joint_seed(FrameDev fr, int n, const float* x0, const float* z0, const float* T0, const uint8_t* valid,
+                             float* x0_raw, float* xcur_norm, float* t, float* xbest, float* zbest, float* Tbest,
+                             float* err_best, int* list, int* count) {
+    const BodyConst bc = load_bc(fr);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    if (i < n) {
+        const V3 xr = V3{x0[(size_t)i * 3], x0[(size_t)i * 3 + 1], x0[(size_t)i * 3 + 2]};
+        const V3 xn = normalize_pt(bc, xr);
+        x0_raw[(size_t)i * 3] = xbest[(size_t)i * 3] = xr.x;
+        x0_raw[(size_t)i * 3 + 1] = xbest[(size_t)i * 3 + 1] = xr.y;
+        x0_raw[(size_t)i * 3 + 2] = xbest[(size_t)i * 3 + 2] = xr.z;
+        xcur_norm[(size_t)i * 3] = xn.x;
+        xcur_norm[(size_t)i * 3 + 1] = xn.y;
+        xcur_norm[(size_t)i * 3 + 2] = xn.z;
+        t[i] = zbest[i] = z0[i];
+        for (int e = 0; e < 16; ++e) Tbest[(size_t)i * 16 + e] = T0[(size_t)i * 16 + e];
+        err_best[i] = 3.4e38f;
+        keep = valid[i] != 0;
+    }
+    append_ids(keep, i, list, count);
+}
+
+__global__ void k_joint_seam_out(int n, const float* xbest, const float* zbest, const float* err_best, const uint8_t* valid,
+                                 float* x, float* z, uint8_t* conv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    x[(size_t)i * 3] = xbest[(size_t)i * 3];
+    x[(size_t)i * 3 + 1] = xbest[(size_t)i * 3 + 1];
+    x[(size_t)i * 3 + 2] = xbest[(size_t)i * 3 + 2];
+    z[i] = zbest[i];
+    conv[i] = (valid[i] != 0 && err_best[i] < kRootThresh) ? 1 : 0;
+}
+
 // RT:266-296
 __global__ void k_trace_finalize(FrameDev fr, int n, const float* near_far, const float* xbest, const float* zbest,
                                  const float* err_best, float* points_hat_norm, uint8_t* conv, float* start,
@@ -2825,6 +2861,37 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
     return check_launch();
 }
 
+// ---- loop B on prepared starts ------------------------------------------------------------------
+// Expects, for every ray id in w.listA[0 .. cntB[0]): x0raw (raw canonical start), xcur (the same point normalised),
+// t (start depth); and for EVERY ray the best-iterate arrays seeded with the start (xbest_ray, zbest_ray, T, err_best
+// = huge).  Leaves the best iterates there (RFU:365-484, broyden.py:4-78).
+static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n, float* T, hipStream_t s) {
+    int* cntB = w.counts + kNumCounts;
+    const int gm = grid_for(n, kTile);
+    hipLaunchKernelGGL(k_skin_jac, dim3(grid_for(n, 16)), dim3(kThreads), kLdsSkin, s, fd, (const float*)w.x0raw,
+                       (const int*)w.listA, (const int*)&cntB[0], 0, w.jac_lbs, &w.ctr->n_skin_jac);
+    // d sdf / d x at the normalised start point == d(metric sdf)/d(metric x)  (RFU:408-413)
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<true, true>), (k_sdf_eval<true, false>), dim3(gm), dim3(kThreads), kLdsSdfGrad, s,
+                  fd, (const float*)w.xcur, (const int*)w.listA, (const int*)&cntB[0], 0, w.u_gx /*scratch: sdf*/,
+                  (float*)nullptr, w.grad_sdf, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
+    Broyden4State st{w.u_eval, w.u_step, w.u_gx, w.u_Jinv, w.err_best_ray, w.xbest_ray, w.zbest_ray, T};
+    hipLaunchKernelGGL(k_joint_init, dim3(grid_for(n, 256)), dim3(256), 0, s, fd, st, rs, (const int*)w.listA,
+                       (const int*)&cntB[0], (const float*)w.grad_sdf, (const float*)w.jac_lbs, (const float*)w.xcur,
+                       (const float*)w.t, w.x0raw);
+    for (int it = 0; it <= kBroydenSteps; ++it) {
+        int* lin = (it & 1) ? w.listB : w.listA;
+        int* lout = (it & 1) ? w.listA : w.listB;
+        if (it == 0)
+            LAUNCH_ENGINE(fd.split, (k_joint_iter<true, true>), (k_joint_iter<true, false>), dim3(gm), dim3(kThreads),
+                          kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
+                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+        else
+            LAUNCH_ENGINE(fd.split, (k_joint_iter<false, true>), (k_joint_iter<false, false>), dim3(gm), dim3(kThreads),
+                          kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
+                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+    }
+}
+
 // ---- loops A + B -----------------------------------------------------------------------------
 static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, int32_t rays_per_cam,
                       const float* dirs, const float* near_far, int32_t n, int root_find_all, float* points_hat_norm,
@@ -2852,28 +2919,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     hipLaunchKernelGGL(k_joint_select, dim3(gb), dim3(256), 0, s, fd, n, (const float*)w.xcur, (const float*)w.Tcur,
                        (const float*)w.t, (const uint8_t*)w.diverged, root_find_all, w.x0raw, w.xbest_ray, w.zbest_ray, T,
                        w.err_best_ray, w.listA, &cntB[0]);
-    hipLaunchKernelGGL(k_skin_jac, dim3(grid_for(n, 16)), dim3(kThreads), kLdsSkin, s, fd, (const float*)w.x0raw,
-                       (const int*)w.listA, (const int*)&cntB[0], 0, w.jac_lbs, &w.ctr->n_skin_jac);
-    // d sdf / d x at the normalised start point == d(metric sdf)/d(metric x)  (RFU:408-413)
-    LAUNCH_ENGINE(fd.split, (k_sdf_eval<true, true>), (k_sdf_eval<true, false>), dim3(gm), dim3(kThreads), kLdsSdfGrad, s,
-                  fd, (const float*)w.xcur, (const int*)w.listA, (const int*)&cntB[0], 0, w.u_gx /*scratch: sdf*/,
-                  (float*)nullptr, w.grad_sdf, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
-    Broyden4State st{w.u_eval, w.u_step, w.u_gx, w.u_Jinv, w.err_best_ray, w.xbest_ray, w.zbest_ray, T};
-    hipLaunchKernelGGL(k_joint_init, dim3(grid_for(n, 256)), dim3(256), 0, s, fd, st, rs, (const int*)w.listA,
-                       (const int*)&cntB[0], (const float*)w.grad_sdf, (const float*)w.jac_lbs, (const float*)w.xcur,
-                       (const float*)w.t, w.x0raw);
-    for (int it = 0; it <= kBroydenSteps; ++it) {
-        int* lin = (it & 1) ? w.listB : w.listA;
-        int* lout = (it & 1) ? w.listA : w.listB;
-        if (it == 0)
-            LAUNCH_ENGINE(fd.split, (k_joint_iter<true, true>), (k_joint_iter<true, false>), dim3(gm), dim3(kThreads),
-                          kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
-                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
-        else
-            LAUNCH_ENGINE(fd.split, (k_joint_iter<false, true>), (k_joint_iter<false, false>), dim3(gm), dim3(kThreads),
-                          kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
-                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
-    }
+    joint_impl(fd, w, rs, n, T, s);
     hipLaunchKernelGGL(k_trace_finalize, dim3(gb), dim3(256), 0, s, fd, n, near_far, (const float*)w.xbest_ray,
                        (const float*)w.zbest_ray, (const float*)w.err_best_ray, points_hat_norm, conv, start, end);
     return check_launch();
@@ -2890,6 +2936,28 @@ int arah_trace(const ArahFrame* f, const float* cam_loc, int32_t rays_per_cam, c
     if (int arc = setup_attributes()) return arc;
     return trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, root_find_all, points_hat_norm, T, conv, start,
                       end, reinterpret_cast<hipStream_t>(stream));
+}
+
+int arah_joint_root_find(const ArahFrame* f, const float* cam_loc, int32_t rays_per_cam, const float* dirs,
+                         const uint8_t* valid, const float* x0, const float* z0, const float* T0, int32_t n, float* x,
+                         float* z, float* T, uint8_t* conv, void* workspace, size_t wbytes, void* stream) {
+    if (!f || n < 0 || !workspace) return ARAH_E_BADARG;
+    if (n == 0) return ARAH_OK;
+    if (!cam_loc || !dirs || !valid || !x0 || !z0 || !T0 || !x || !z || !T || !conv) return ARAH_E_BADARG;
+    Workspace w = carve(workspace, n, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    const RaySet rs = make_rays(cam_loc, dirs, rays_per_cam);
+    const int gb = (n + 255) / 256;
+    hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
+    hipLaunchKernelGGL(k_joint_seed, dim3(gb), dim3(256), 0, s, fd, n, x0, z0, T0, valid, w.x0raw, w.xcur, w.t, w.xbest_ray,
+                       w.zbest_ray, T, w.err_best_ray, w.listA, &w.counts[kNumCounts]);
+    joint_impl(fd, w, rs, n, T, s);
+    hipLaunchKernelGGL(k_joint_seam_out, dim3(gb), dim3(256), 0, s, n, (const float*)w.xbest_ray, (const float*)w.zbest_ray,
+                       (const float*)w.err_best_ray, valid, x, z, conv);
+    return check_launch();
 }
 
 // ---- sampler + loop C -------------------------------------------------------------------------

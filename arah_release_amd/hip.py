@@ -77,7 +77,7 @@ COUNTER_BYTES = C.sizeof(ArahCounters)
 
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
-           "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_trace", "arah_sample_canonicalize",
+           "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events"]
 
@@ -408,6 +408,26 @@ def broyden3_lbs(frame, ws, tgt, x0, T0):
                                  _ptr(err), _ptr(conv), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
            "arah_broyden3_lbs")
     return x, T, err, conv.bool()
+
+
+@_guarded
+def joint_root_find(frame, ws, cam_loc, dirs, valid, x0, z0, T0):
+    """Loop B on caller-supplied starts: cam_loc (B,3), dirs (N,3), valid (N,) bool/uint8, x0 (N,3) raw canonical,
+    z0 (N,), T0 (N,4,4) -> x, z, T, conv."""
+    lib = load_library()
+    cam, d, x0, z0, T0 = _f32(cam_loc), _f32(dirs), _f32(x0), _f32(z0), _f32(T0)
+    v = valid.to(torch.uint8).contiguous()
+    n = d.shape[0]
+    buf = ws.ensure(n, 1)
+    dev = d.device
+    x = torch.empty(n, 3, device=dev)
+    z = torch.empty(n, device=dev)
+    T = torch.empty(n, 4, 4, device=dev)
+    conv = torch.empty(n, dtype=torch.uint8, device=dev)
+    _check(lib.arah_joint_root_find(C.byref(frame.handle), _ptr(cam), C.c_int32(n // cam.shape[0]), _ptr(d), _ptr(v),
+                                    _ptr(x0), _ptr(z0), _ptr(T0), C.c_int32(n), _ptr(x), _ptr(z), _ptr(T), _ptr(conv),
+                                    _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_joint_root_find")
+    return x, z, T, conv.bool()
 
 
 @_guarded

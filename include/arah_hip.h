@@ -24,6 +24,7 @@
  *                           (pytorch3d.ops.knn_points K=1 + nearest-vertex inverse LBS)
  *   arah_broyden3_lbs       search_canonical_corr on caller-supplied initial guesses
  *                           (broyden.py:4-78 with g = LBS(x) - target)
+ *   arah_joint_root_find    search_iso_surface_depth on caller-supplied starts  root_finding_utils.py:365-484
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name starts with "h_"; the caller owns all
@@ -195,6 +196,14 @@ int arah_nearest_inverse_lbs(const ArahFrame* h_frame, const float* pts, int32_t
 int arah_broyden3_lbs(const ArahFrame* h_frame, const float* tgt, const float* x0, const float* T0,
                       int32_t n_pts, float* x, float* T, float* err, uint8_t* conv, void* workspace,
                       size_t workspace_bytes, void* stream);
+
+/* joint root find on u = (x_hat, depth) from caller-supplied starts (search_iso_surface_depth, root_finding_utils.py:
+ * 365-484): valid [N], x0 [N,3] raw canonical, z0 [N], T0 [N,16]  ->  x [N,3], z [N], T [N,16], conv [N].
+ * Rays outside `valid` keep (x0, z0, T0) and are reported as not converged. */
+int arah_joint_root_find(const ArahFrame* h_frame, const float* cam_loc, int32_t rays_per_cam, const float* dirs,
+                         const uint8_t* valid, const float* x0, const float* z0, const float* T0, int32_t n_rays,
+                         float* x, float* z, float* T, uint8_t* conv, void* workspace, size_t workspace_bytes,
+                         void* stream);
 
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* rays: cam_loc [n_cams,3], ray r belongs to camera r / rays_per_cam; dirs [N,3]; near_far [N,2].
