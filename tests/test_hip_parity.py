@@ -136,9 +136,11 @@ def test_sdf_eval(ctx, ctx_fp32, eng):
     g = golden("f3_sdf.npz")
     hip = ctx["hip"]
     sdf, feat, grad = hip.sdf_eval(ctx["frame"], ctx["ws"], T(g["x_norm"]), want_feat=True, want_grad=True)
-    np.testing.assert_allclose(sdf.cpu().numpy(), g["sdf"], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=1e-4, atol=5e-5)
-    np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=1e-3, atol=2e-4)
+    # SURVEY 8c tolerances for fp32 kernels (rtol 1e-4 / atol 1e-5), on both engines; measured worst absolute errors
+    # on the MI355X: sdf 2e-7, feature 6.5e-6, gradient 3e-6 (profiles/r02_tolerance_probe.txt)
+    np.testing.assert_allclose(sdf.cpu().numpy(), g["sdf"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(feat.cpu().numpy(), g["feat"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(grad.cpu().numpy(), g["grad"], rtol=1e-4, atol=1e-5)
     sdf2, _, _ = hip.sdf_eval(ctx["frame"], ctx["ws"], T(g["x_norm"]))
     np.testing.assert_array_equal(sdf2.cpu().numpy(), sdf.cpu().numpy())   # fwd-only kernel == fwd+grad kernel
     # ragged tile (n not a multiple of 64) and a single point
@@ -153,11 +155,12 @@ def test_skin_lbs_and_jacobian(ctx):
     g = golden("f2_pointwise.npz")
     hip = ctx["hip"]
     w, xb, Tm = hip.skin_lbs(ctx["frame"], ctx["ws"], T(g["x_hat"]))
-    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=2e-3, atol=2e-5)
-    np.testing.assert_allclose(xb.cpu().numpy(), g["x_bar"], rtol=1e-4, atol=2e-5)
-    np.testing.assert_allclose(Tm.cpu().numpy(), g["T"], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xb.cpu().numpy(), g["x_bar"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(Tm.cpu().numpy(), g["T"], rtol=1e-4, atol=1e-5)
     jac = hip.skin_jacobian(ctx["frame"], ctx["ws"], T(g["x_hat"]))
-    np.testing.assert_allclose(jac.cpu().numpy(), g["jac"], rtol=2e-3, atol=3e-4)
+    # entries reach 27 (x20 logits, steep sigmoids): worst measured error 1.1e-4 absolute = 4e-6 of the largest entry
+    np.testing.assert_allclose(jac.cpu().numpy(), g["jac"], rtol=1e-4, atol=3e-5)
 
 
 @gpu
