@@ -141,8 +141,10 @@ struct ColSegs {
 };
 
 // dst: packed [M_pad/16][KC][64][4]; element (row, col) = transpose ? src[col_src*ld + row] : src[row*ld + col_src]
+// with col_src = segment map of col.  transpose == 2 (transposed operand whose OUTPUT rows are the permuted ones):
+// element (row, col) = src[col*ld + row_src], row_src = segment map of row, col < ncol2.
 __global__ void k_pack(float* __restrict__ dst, const float* __restrict__ src, int M, int ld, int m_tiles, int KC,
-                       ColSegs segs, int transpose) {
+                       ColSegs segs, int transpose, int ncol2) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int total = m_tiles * KC * 64;
     if (idx >= total) return;
@@ -151,6 +153,18 @@ __global__ void k_pack(float* __restrict__ dst, const float* __restrict__ src, i
     const int kc = tile % KC, mt = tile / KC;
     const int row = mt * 16 + (lane & 15);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (transpose == 2) {
+        int sr = -1;
+        for (int s = 0; s < segs.n; ++s)
+            if (row >= segs.dst0[s] && row < segs.dst0[s] + segs.len[s]) sr = segs.src0[s] + (row - segs.dst0[s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = kc * 16 + 4 * (lane >> 4) + t;
+            if (sr >= 0 && col < ncol2) v[t] = src[(size_t)col * ld + sr];
+        }
+        reinterpret_cast<f32x4*>(dst)[idx] = v;
+        return;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         const int col = kc * 16 + 4 * (lane >> 4) + t;
@@ -2239,6 +2253,10 @@ __global__ void k_points_cam(FrameDev fr, int n, RaySet rs, const float* dists, 
     }
 }
 
+}  // namespace
+#include "train.hpp"
+namespace {
+
 // ------------------------------------------------------------------------------------------
 // host side: workspace carving, launch helpers
 // ------------------------------------------------------------------------------------------
@@ -2422,6 +2440,10 @@ int setup_attributes() {
     allow_lds(k_shade<true, true>, lds_shade<true>());
     allow_lds(k_color_eval<false>, lds_color<false>());
     allow_lds(k_color_eval<true>, lds_color<true>());
+    allow_lds(k_shade_train<false, false>, lds_shade_train<false>());
+    allow_lds(k_shade_train<false, true>, lds_shade_train<false>());
+    allow_lds(k_shade_train<true, false>, lds_shade_train<true>());
+    allow_lds(k_shade_train<true, true>, lds_shade_train<true>());
     if (g_attr_failed) return ARAH_E_LAUNCH;
     done[dev] = true;
     return ARAH_OK;
@@ -2472,6 +2494,7 @@ struct FrameLayout {
     size_t sdf_wps[5], sdf_fw, sdf_pw, sdf_fws, sdf_amax;
     size_t skin_w0, skin_wp[3], skin_w4p, skin_bias, skin_wps[4], skin_scales, skin_amax;
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
+    size_t col_w0pT, col_w1pT, col_w2pT, col_w3apT, col_w3bpT, col_w4pT;   // transposed packings (training backward)
     size_t verts4, knn_spheres, knn_grid, knn_cells, scalars;
     size_t bytes;
 };
@@ -2515,6 +2538,12 @@ FrameLayout frame_layout(int col_mode) {
     L.col_w4p = take(256 * 256);
     L.col_w5 = take(3 * 256);
     L.col_bias = take(256 + 256 + 128 + 256 + 256 + 4);
+    L.col_w0pT = take((size_t)kin_pad * 256);
+    L.col_w1pT = take(256 * 256);
+    L.col_w2pT = take(256 * 128);
+    L.col_w3apT = take((size_t)kin_pad * 256);
+    L.col_w3bpT = take(128 * 256);
+    L.col_w4pT = take(256 * 256);
     L.verts4 = take((size_t)kMaxClusters * kClusterSize * 4);
     L.knn_spheres = take((size_t)kMaxClusters * 4);
     L.knn_grid = take(sizeof(GridInfo) / 4);
@@ -2525,9 +2554,10 @@ FrameLayout frame_layout(int col_mode) {
 }
 
 void launch_pack(float* dst, const float* src, int M, int ld, int m_tiles, int KC, const ColSegs& segs, int transpose,
-                 hipStream_t s) {
+                 hipStream_t s, int ncol2 = 0) {
     const int total = m_tiles * KC * 64;
-    hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, s, dst, src, M, ld, m_tiles, KC, segs, transpose);
+    hipLaunchKernelGGL(k_pack, dim3((total + 255) / 256), dim3(256), 0, s, dst, src, M, ld, m_tiles, KC, segs, transpose,
+                       ncol2);
 }
 
 ColSegs one_seg(int len) {
@@ -2650,6 +2680,13 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         launch_pack(P(L.col_w1p), nets->col_w[1], 256, 256, 16, 16, one_seg(256), 0, s);
         launch_pack(P(L.col_w2p), nets->col_w[2], 128, 256, 8, 16, one_seg(256), 0, s);
         launch_pack(P(L.col_w4p), nets->col_w[4], 256, 256, 16, 16, one_seg(256), 0, s);
+        // transposed operands of the training backward: rows = (permuted) inputs of the layer, K = its outputs
+        launch_pack(P(L.col_w0pT), nets->col_w[0], kin_pad, in_dim, kc0, 16, sg, 2, s, 256);
+        launch_pack(P(L.col_w3apT), nets->col_w[3], kin_pad, in_dim + 128, kc0, 16, sg, 2, s, 256);
+        launch_pack(P(L.col_w3bpT), nets->col_w[3], 128, in_dim + 128, 8, 16, sb, 2, s, 256);
+        launch_pack(P(L.col_w1pT), nets->col_w[1], 256, 256, 16, 16, one_seg(256), 1, s);
+        launch_pack(P(L.col_w2pT), nets->col_w[2], 256, 256, 16, 8, one_seg(128), 1, s);
+        launch_pack(P(L.col_w4pT), nets->col_w[4], 256, 256, 16, 16, one_seg(256), 1, s);
         hipLaunchKernelGGL(k_copy, dim3(3), dim3(256), 0, s, P(L.col_w5), nets->col_w[5], 3 * 256, 3 * 256);
         float* cb = P(L.col_bias);
         hipLaunchKernelGGL(k_fold_bias, dim3(1), dim3(256), 0, s, cb, nets->col_b[0], nets->col_w[0], in_dim,
@@ -2701,6 +2738,12 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->col_w4p = P(L.col_w4p);
     out->col_w5 = P(L.col_w5);
     out->col_bias = P(L.col_bias);
+    out->col_w0pT = P(L.col_w0pT);
+    out->col_w1pT = P(L.col_w1pT);
+    out->col_w2pT = P(L.col_w2pT);
+    out->col_w3apT = P(L.col_w3apT);
+    out->col_w3bpT = P(L.col_w3bpT);
+    out->col_w4pT = P(L.col_w4pT);
     out->verts4 = P(L.verts4);
     out->knn_spheres = P(L.knn_spheres);
     out->knn_grid = base + L.knn_grid;
@@ -3058,6 +3101,78 @@ int arah_shade_composite(const ArahFrame* f, const ArahSampling* cfg, const floa
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     if (int arc = setup_attributes()) return arc;
     return shade_impl(f, cfg, w, dirs, z, pts, T, mask, n, rgb, acc, vol_mask, reinterpret_cast<hipStream_t>(stream));
+}
+
+// ---- loop D with gradients (training) -------------------------------------------------------------
+static ColNetT colT_of(const ArahFrame& f) {
+    return ColNetT{f.col_w0pT, f.col_w1pT, f.col_w2pT, f.col_w3apT, f.col_w3bpT, f.col_w4pT};
+}
+
+size_t arah_shade_train_slab_bytes(void) { return (size_t)kMaxGrid / 2 * kTrainSlabPerWg * sizeof(f32x4); }
+
+int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* sdf, float* rgb4, void* workspace,
+                             size_t wbytes, void* stream) {
+    if (!f || !in || !sdf || !rgb4 || !workspace || in->n < 0) return ARAH_E_BADARG;
+    if (in->n == 0) return ARAH_OK;
+    if (!in->x || !in->view || (in->rotate_normal && !in->T) || (in->ray_augm && !in->view_orig)) return ARAH_E_BADARG;
+    Workspace w = carve(workspace, 1, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    TrainIn ti{in->n, in->x, in->T, in->view, in->view_orig, in->rotate_normal, in->ray_augm, nullptr, nullptr};
+    TrainOut to;
+    memset(&to, 0, sizeof(to));
+    to.sdf = sdf;
+    to.rgb = rgb4;
+    const int g = min(grid_for(in->n, kTile), kMaxGrid / 2);   // one workgroup per CU (140 KB of LDS)
+    if (f->col_mode == ARAH_COLOR_IDR)
+        hipLaunchKernelGGL((k_shade_train<true, false>), dim3(g), dim3(kThreads), lds_shade_train<true>(), s, fd,
+                           colT_of(*f), ti, to, w.spill, (f32x4*)nullptr);
+    else
+        hipLaunchKernelGGL((k_shade_train<false, false>), dim3(g), dim3(kThreads), lds_shade_train<false>(), s, fd,
+                           colT_of(*f), ti, to, w.spill, (f32x4*)nullptr);
+    return check_launch();
+}
+
+int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const ArahTrainGrads* gr, void* slab,
+                              size_t slab_bytes, void* workspace, size_t wbytes, void* stream) {
+    if (!f || !in || !gr || !slab || !workspace || in->n < 0) return ARAH_E_BADARG;
+    if (in->n == 0) return ARAH_OK;
+    if (!in->x || !in->view || (in->rotate_normal && !in->T) || (in->ray_augm && !in->view_orig) || !in->g_s || !in->g_rgb)
+        return ARAH_E_BADARG;
+    if (slab_bytes < arah_shade_train_slab_bytes()) return ARAH_E_WORKSPACE;
+    Workspace w = carve(workspace, 1, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    TrainIn ti{in->n, in->x, in->T, in->view, in->view_orig, in->rotate_normal, in->ray_augm, in->g_s, in->g_rgb};
+    TrainOut to;
+    to.sdf = gr->sdf;
+    to.rgb = gr->rgb4;
+    to.gx = gr->gx4;
+    to.film_f = gr->film_freq;
+    to.film_p = gr->film_phase;
+    for (int k = 0; k < 6; ++k) {
+        to.h[k] = gr->h[k];
+        to.av[k] = gr->av[k];
+        to.avd[k] = gr->avd[k];
+        to.d[k] = gr->d[k];
+    }
+    for (int k = 0; k < 7; ++k) to.hd[k] = gr->hd[k];
+    for (int k = 0; k < 5; ++k) to.c[k] = gr->c[k];
+    to.cin = gr->cin;
+    if (hipMemsetAsync(gr->film_freq, 0, 6 * 256 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
+    if (hipMemsetAsync(gr->film_phase, 0, 6 * 256 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
+    const int g = min(grid_for(in->n, kTile), kMaxGrid / 2);
+    if (f->col_mode == ARAH_COLOR_IDR)
+        hipLaunchKernelGGL((k_shade_train<true, true>), dim3(g), dim3(kThreads), lds_shade_train<true>(), s, fd,
+                           colT_of(*f), ti, to, w.spill, reinterpret_cast<f32x4*>(slab));
+    else
+        hipLaunchKernelGGL((k_shade_train<false, true>), dim3(g), dim3(kThreads), lds_shade_train<false>(), s, fd,
+                           colT_of(*f), ti, to, w.spill, reinterpret_cast<f32x4*>(slab));
+    return check_launch();
 }
 
 // ---- whole eval forward -------------------------------------------------------------------------

@@ -406,13 +406,39 @@ __device__ __forceinline__ void film_sine(const f32x4 v, const f32x4 fw, const f
     }
 }
 
+// Training taps (csrc/train.hpp): what the hand-written backward of loop D needs from the forward pass.
+//   NoTap     : nothing (inference).
+//   TrainTap  : the pre-activations v_k = W_k h_{k-1} of all six layers go to a per-workgroup slab in fragment
+//               order (a software register spill, read back lane by lane), and the layer inputs h_0 .. h_5 are
+//               streamed to HBM as dense [P][width] matrices (operands of the weight-gradient GEMMs).
+struct NoTap {
+    static constexpr bool on = false;
+};
+struct TrainTap {
+    static constexpr bool on = true;
+    f32x4* aslab;        // [6][kWaves][kSdfMT*kNT][64] pre-activations
+    float* h[6];         // h[0]: [P][4] (x), h[1..5]: [P][256]
+    long long row0;      // first sample of the tile
+    int rows;            // valid samples in the tile (<= 64)
+};
+
+// rows [0, rows) of an LDS matrix (row stride ld floats, `width` floats wide, width % 4 == 0) -> dense global rows
+__device__ __forceinline__ void stream_rows(const float* lds, int ld, int width, float* dst, long long row0, int rows,
+                                            int tid) {
+    const int w4 = width >> 2;
+    for (int e = tid; e < rows * w4; e += kThreads) {
+        const int r = e / w4, c4 = e - r * w4;
+        reinterpret_cast<f32x4*>(dst + (row0 + r) * width)[c4] = *reinterpret_cast<const f32x4*>(lds + r * ld + c4 * 4);
+    }
+}
+
 // Forward trunk on a tile of 16 NT points.  xin: LDS [16 NT][4] normalised coords.  act: LDS rows of ld floats,
 // receives h6 -- as fp32 [256] (exact engine) or as split planes (hi at byte 0, lo at byte 512; SPLIT).
 // GRAD: dact factors of layers 1..5 go to `spill` (global, this workgroup's private slab of
 // 5*8*8*64 f32x4), layer 6's stay in `dlast`.
-template <bool GRAD, int NT = kNT, bool SPLIT = false>
+template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap>
 __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
-                                          f32x4 (&dlast)[kSdfMT][NT], int wave, int lane) {
+                                          f32x4 (&dlast)[kSdfMT][NT], int wave, int lane, const TAP& tap = TAP()) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
     constexpr float amp = SPLIT ? kActScale : 1.0f;
@@ -438,6 +464,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
                 for (int r = 0; r < 4; ++r)   // explicit chain: every instantiation must round identically
                     v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
                 no_pack(v);
+                if constexpr (TAP::on) tap.aslab[((0 * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = v;
                 film_sine<GRAD>(v, fw, pw, f, amp, h, d);
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
@@ -445,6 +472,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             }
         }
     }
+    if constexpr (TAP::on) stream_rows(xin, 4, 4, tap.h[0], tap.row0, tap.rows, wave * 64 + lane);
     ARAH_SYNC();
 #pragma unroll 1
     for (int k = 1; k < 6; ++k) {
@@ -453,6 +481,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
+        if constexpr (TAP::on) stream_rows(act, ld, 256, tap.h[k], tap.row0, tap.rows, wave * 64 + lane);   // h_k: read only
         if (SPLIT) gemm_acc_split<8, kSdfMT, NT, GRAD>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);   // GRAD kernels: 2 waves/SIMD
         else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
         ARAH_SYNC();   // everyone is done reading the layer input
@@ -465,6 +494,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 f32x4 h, d;
+                if constexpr (TAP::on) tap.aslab[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = acc[m][n];
                 film_sine<GRAD>(acc[m][n], fw, pw, f, amp, h, d);
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
@@ -742,11 +772,19 @@ __device__ __forceinline__ void relu_store(const f32x4 (&acc)[MT][kNT], const fl
     }
 }
 
+struct ColTap {         // training: the colour MLP's input and hidden activations as dense [P][width] streams
+    float* cin;         // [P][kInPad]
+    float* c[5];        // c1 [P][256], c2 [P][256], c3 [P][128], c4 [P][256], c5 [P][256]
+    long long row0;
+    int rows;
+};
+
 // A: LDS [64][kLdA] full input (feature in cols 0..255, extras after, zero padded); B: LDS [64][260].
 // rgb (after sigmoid) -> out[pt*ostride + 0..2].  Needs a barrier between the writers of A and the call.
+// tap != nullptr (training): A and every hidden activation are streamed out; B holds c5 on return.
 template <bool IDR>
 __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, float* B, float* out, int ostride,
-                                          int wave, int lane, int tid) {
+                                          int wave, int lane, int tid, const ColTap* tap = nullptr) {
     typedef ColDims<IDR> D;
     constexpr int ldB = kSdfLd;
     {
@@ -759,6 +797,10 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         relu_store<2>(acc, net.bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
     }
     ARAH_SYNC();
+    if (tap) {
+        stream_rows(A, D::kLdA, D::kInPad, tap->cin, tap->row0, tap->rows, tid);
+        stream_rows(B, ldB, 256, tap->c[0], tap->row0, tap->rows, tid);
+    }
     {
         f32x4 acc[2][kNT];
 #pragma unroll
@@ -770,6 +812,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         relu_store<2>(acc, net.bias + 256, B, ldB, wave * 2, lane);
     }
     ARAH_SYNC();
+    if (tap) stream_rows(B, ldB, 256, tap->c[1], tap->row0, tap->rows, tid);
     {
         f32x4 acc[1][kNT];
 #pragma unroll
@@ -779,6 +822,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         relu_store<1>(acc, net.bias + 512, B, ldB, wave, lane);   // cols 0..127
     }
     ARAH_SYNC();
+    if (tap) stream_rows(B, ldB, 128, tap->c[2], tap->row0, tap->rows, tid);
     {
         f32x4 acc[2][kNT];
 #pragma unroll
@@ -791,6 +835,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         relu_store<2>(acc, net.bias + 640, B, ldB, wave * 2, lane);
     }
     ARAH_SYNC();
+    if (tap) stream_rows(B, ldB, 256, tap->c[3], tap->row0, tap->rows, tid);
     {
         f32x4 acc[2][kNT];
 #pragma unroll
@@ -802,6 +847,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         relu_store<2>(acc, net.bias + 896, B, ldB, wave * 2, lane);
     }
     ARAH_SYNC();
+    if (tap) stream_rows(B, ldB, 256, tap->c[4], tap->row0, tap->rows, tid);
     {
         const int pt = tid >> 3, part = tid & 7;
         float c0 = 0.f, c1 = 0.f, c2 = 0.f;

@@ -61,10 +61,23 @@ class ArahFrame(C.Structure):
                 ("skin_wps", _fp * 4), ("skin_scales", _fp),
                 ("col_w0p", _fp), ("col_w1p", _fp), ("col_w2p", _fp), ("col_w3ap", _fp), ("col_w3bp", _fp),
                 ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
+                ("col_w0pT", _fp), ("col_w1pT", _fp), ("col_w2pT", _fp), ("col_w3apT", _fp), ("col_w3bpT", _fp),
+                ("col_w4pT", _fp),
                 ("verts4", _fp), ("knn_spheres", _fp), ("knn_grid", _fp), ("knn_cells", _fp),
                 ("verts", _fp), ("vert_weights", _fp), ("bones", _fp),
                 ("scalars", _fp), ("n_verts", C.c_int32),
                 ("col_mode", C.c_int32), ("precision", C.c_int32)]
+
+
+class ArahTrainIn(C.Structure):
+    _fields_ = [("n", C.c_int32), ("rotate_normal", C.c_int32), ("ray_augm", C.c_int32), ("pad", C.c_int32),
+                ("x", _fp), ("T", _fp), ("view", _fp), ("view_orig", _fp), ("g_s", _fp), ("g_rgb", _fp)]
+
+
+class ArahTrainGrads(C.Structure):
+    _fields_ = [("sdf", _fp), ("rgb4", _fp), ("gx4", _fp), ("film_freq", _fp), ("film_phase", _fp),
+                ("h", _fp * 6), ("hd", _fp * 7), ("av", _fp * 6), ("avd", _fp * 6), ("cin", _fp), ("c", _fp * 5),
+                ("d", _fp * 6)]
 
 
 class ArahCounters(C.Structure):
@@ -78,7 +91,8 @@ COUNTER_BYTES = C.sizeof(ArahCounters)
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
-           "arah_shade_composite", "arah_render", "arah_dominant_kernel", "arah_set_shade_events",
+           "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
+           "arah_shade_train_backward", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events"]
 
 _lib = None
@@ -97,6 +111,7 @@ def load_library():
     lib.arah_workspace_bytes.restype = C.c_size_t
     lib.arah_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.arah_dominant_kernel.restype = C.c_char_p
+    lib.arah_shade_train_slab_bytes.restype = C.c_size_t
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the symbol is missing
     _lib = lib
@@ -488,6 +503,71 @@ def shade_composite(frame, ws, sampling, dirs, z, pts, T, mask):
                                     _ptr(acc), _ptr(vol), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
            "arah_shade_composite")
     return rgb, acc, vol
+
+
+# ------------------------------------------------------------------------------------------------
+# loop D with gradients: the pair of entry points behind training.ShadeSamples (torch.autograd.Function)
+# ------------------------------------------------------------------------------------------------
+KIN_PAD = {COLOR_NO_VIEW_DIR: 272, COLOR_IDR: 304}   # colour input [feat(256) | x(3) | n(3) | PE(view)(27)] padded to 16
+
+
+def _train_in(x, T, view, view_orig, rotate_normal, ray_augm, g_s=None, g_rgb=None):
+    t = ArahTrainIn()
+    t.n, t.rotate_normal, t.ray_augm = int(x.shape[0]), int(bool(rotate_normal)), int(bool(ray_augm))
+    t.x, t.T, t.view, t.view_orig = _ptr(x), _ptr(T), _ptr(view), _ptr(view_orig)
+    t.g_s, t.g_rgb = _ptr(g_s), _ptr(g_rgb)
+    return t
+
+
+@_guarded
+def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_augm):
+    """x (P,3) normalised canonical points, T (P,4,4) or None, view / view_orig (P,3) -> sdf (P,), rgb (P,3)."""
+    lib = load_library()
+    x, view = _f32(x), _f32(view)
+    T = _f32(T) if (T is not None and rotate_normal) else None
+    vo = _f32(view_orig) if (view_orig is not None and ray_augm) else None
+    n = x.shape[0]
+    buf = ws.ensure(1, 1)
+    sdf = torch.empty(n, device=x.device)
+    rgb4 = torch.empty(n, 4, device=x.device)
+    tin = _train_in(x, T, view, vo, rotate_normal, ray_augm)
+    _check(lib.arah_shade_train_forward(C.byref(frame.handle), C.byref(tin), _ptr(sdf), _ptr(rgb4), _ptr(buf),
+                                        C.c_size_t(buf.numel()), _stream()), "arah_shade_train_forward")
+    return sdf, rgb4[:, :3]
+
+
+@_guarded
+def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_augm, g_s, g_rgb):
+    """Recomputes the forward and returns the per-sample gradient dL/dx (P,3), the FiLM gradients (6,256) x 2 and the
+    operand streams of the weight-gradient GEMMs (dict of dense (P, width) tensors, see ArahTrainGrads)."""
+    lib = load_library()
+    x, view, g_s, g_rgb = _f32(x), _f32(view), _f32(g_s), _f32(g_rgb)
+    T = _f32(T) if (T is not None and rotate_normal) else None
+    vo = _f32(view_orig) if (view_orig is not None and ray_augm) else None
+    n, dev = x.shape[0], x.device
+    buf = ws.ensure(1, 1)
+    kin = KIN_PAD[frame.color_mode]
+    E = lambda *shape: torch.empty(*shape, device=dev)
+    st = {"sdf": E(n), "rgb4": E(n, 4), "gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256),
+          "h": [E(n, 4)] + [E(n, 256) for _ in range(5)], "hd": [E(n, 4)] + [E(n, 256) for _ in range(6)],
+          "av": [E(n, 256) for _ in range(6)], "avd": [E(n, 256) for _ in range(6)], "cin": E(n, kin),
+          "c": [E(n, w) for w in (256, 256, 128, 256, 256)],
+          "d": [E(n, w) for w in (256, 256, 128, 256, 256)] + [E(n, 4)]}
+    g = ArahTrainGrads()
+    for k in ("sdf", "rgb4", "gx4", "film_freq", "film_phase", "cin"):
+        setattr(g, k, _ptr(st[k]))
+    for k in ("h", "hd", "av", "avd", "c", "d"):
+        arr = getattr(g, k)
+        for i, t in enumerate(st[k]):
+            arr[i] = _ptr(t).value
+    nslab = lib.arah_shade_train_slab_bytes()
+    if getattr(ws, "train_slab", None) is None or ws.train_slab.numel() < nslab:
+        ws.train_slab = torch.empty(nslab, dtype=torch.uint8, device=dev)
+    tin = _train_in(x, T, view, vo, rotate_normal, ray_augm, g_s, g_rgb)
+    _check(lib.arah_shade_train_backward(C.byref(frame.handle), C.byref(tin), C.byref(g), _ptr(ws.train_slab),
+                                         C.c_size_t(ws.train_slab.numel()), _ptr(buf), C.c_size_t(buf.numel()),
+                                         _stream()), "arah_shade_train_backward")
+    return st
 
 
 def set_shade_events(start=None, stop=None):

@@ -177,6 +177,11 @@ class IDHRNetwork(nn.Module):
         pred_weights = None
         if "points_skinning" in input:
             pred_weights = training.query_weights(input["points_skinning"], cmin, cmax, center, self.skinning_model)
+        # one packed frame per step serves the ray tracer (loops A-C) and the hand-written loop-D op
+        use_hip_shading = os.environ.get("ARAH_TRAIN_AUTOGRAD", "0") != "1"
+        frame = build_frame(sdf_network, self.skinning_model, self.rendering_network, self.deviation_network, pose_cond,
+                            input["smpl_verts"], input["skinning_weights"], input["bone_transforms"], input["trans"],
+                            cmin, cmax, center)
         with torch.no_grad():
             xn, _, _, s_pts, s_z, s_T, s_mask = self.ray_tracer(
                 sdf_network, self.skinning_model, cam_loc=cam_loc, ray_directions=ray_dirs,
@@ -184,7 +189,7 @@ class IDHRNetwork(nn.Module):
                 sc_factor=input["sc_factor"], smpl_verts=input["smpl_verts"], smpl_verts_cano=input["minimal_shape"],
                 skinning_weights=input["skinning_weights"], vol_feat=input["vol_feat"],
                 bone_transforms=input["bone_transforms"], trans=input["trans"], coord_min=cmin, coord_max=cmax,
-                center=center, eval_mode=False)
+                center=center, eval_mode=False, frame=frame)
         inside_sdf = sdf_network(input["points_inside"]).squeeze(0) if "points_inside" in input else None
         n_reg = 1024
         eik = ((draw_uniform((B, n_reg, 3), dev, "eikonal") - 0.5) * 2).reshape(-1, 3)
@@ -207,7 +212,8 @@ class IDHRNetwork(nn.Module):
         rgb_hit, w_hit = training.shade_composite_train(
             self, sdf_network, s_pts[vol_mask], s_z[vol_mask], s_T[vol_mask], s_mask[vol_mask], dirs_in[vol_mask],
             ray_dirs[vol_mask], pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
-            self.ray_tracer.n_steps, ray_augm=ray_augm)
+            self.ray_tracer.n_steps, ray_augm=ray_augm, frame=frame if use_hip_shading else None,
+            ws=self.ray_tracer.workspace(dev))
         rgb = torch.zeros_like(xn).masked_scatter(vol_mask.unsqueeze(-1), rgb_hit)
         acc = torch.zeros(B, N, device=dev).masked_scatter(vol_mask, w_hit)
         out = {"rgb_values": rgb, "sdf_output": acc, "network_body_mask": vol_mask, "body_mask": input["body_mask"],

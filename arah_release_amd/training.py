@@ -87,9 +87,108 @@ def input_jacobian(y, x):
 # ------------------------------------------------------------------------------------------------
 # loop D with gradients (IDR:261-396, self.training branches)
 # ------------------------------------------------------------------------------------------------
+class ShadeSamples(torch.autograd.Function):
+    """Per-sample part of loop D as ONE custom op on the HIP kernels (csrc/train.hpp): SDF value, normal, colour in
+    the forward; in the backward the kernel recomputes the forward, sweeps the colour MLP and the SIREN backwards
+    (second-order path through the normal included) and streams the operands of the weight-gradient outer products,
+    which are finished here with library GEMMs.  Replaces `sdf_network[:-1](x)`, `gradient(sdf, x)` with
+    create_graph=True and `rendering_network(...)` of the reference (IDR:336-361) and their autograd graphs.
+
+    apply(meta, x, *params) with meta = dict(frame, ws, T, view, view_orig, rotate_normal, ray_augm, mode, n_pose) and
+    params = 7 SDF weights (out,in), 7 SDF biases, freq (6*256), phase (6*256), 6 folded colour weights, 6 colour
+    biases, pose vector (n_pose,) -- passed so that autograd knows them; their VALUES are the ones packed in `frame`.
+    Returns sdf (P,) in normalised units and rgb (P,3)."""
+
+    @staticmethod
+    def forward(ctx, meta, x, *params):
+        from . import hip
+        sdf, rgb = hip.shade_train_forward(meta["frame"], meta["ws"], x, meta["T"], meta["view"], meta["view_orig"],
+                                           meta["rotate_normal"], meta["ray_augm"])
+        ctx.meta = meta
+        ctx.save_for_backward(x, *params)
+        return sdf, rgb
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_rgb):
+        from . import hip
+        meta = ctx.meta
+        x, *params = ctx.saved_tensors
+        st = hip.shade_train_backward(meta["frame"], meta["ws"], x, meta["T"], meta["view"], meta["view_orig"],
+                                      meta["rotate_normal"], meta["ray_augm"], g_sdf.contiguous(), g_rgb.contiguous())
+        sdf_w, sdf_b = params[0:7], params[7:14]
+        col_w, col_b, pose = params[16:22], params[22:28], params[28]
+        grads = []
+        # ---- SIREN: dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1}
+        for k in range(6):
+            n_in = sdf_w[k].shape[-1]
+            grads.append((st["av"][k].t() @ st["h"][k][:, :n_in] + st["avd"][k].t() @ st["hd"][k][:, :n_in])
+                         .reshape(sdf_w[k].shape))
+        feat = st["cin"][:, :256]
+        grads.append((g_sdf.reshape(1, -1) @ feat + st["hd"][6].sum(0, keepdim=True)).reshape(sdf_w[6].shape))
+        for k in range(6):
+            grads.append(st["av"][k].sum(0).reshape(sdf_b[k].shape))
+        grads.append(g_sdf.sum().reshape(sdf_b[6].shape))
+        grads.append(st["film_freq"].reshape(params[14].shape))
+        grads.append(st["film_phase"].reshape(params[15].shape))
+        # ---- colour MLP: dW_l = delta_l^T X_l; stream columns are [feat | x | n | PE(view) | 0]
+        idr = meta["mode"] == "idr"
+        n_pose = meta["n_pose"]
+        cin, c, d = st["cin"], st["c"], st["d"]
+        n_view = 27 if idr else 0
+
+        def to_reference_columns(m, tail=None):   # (out, kin) in stream order -> (out, in_dim [+128]) in the reference's
+            parts = [m[:, 256:259]]
+            if idr:
+                parts.append(m[:, 262:289])
+            parts += [m[:, 259:262], m[:, :256]]
+            return parts
+
+        s0, s3 = d[0].sum(0), d[3].sum(0)
+        m0 = to_reference_columns(d[0].t() @ cin)
+        m3 = to_reference_columns(d[3].t() @ cin)
+        if n_pose:
+            m0.append(torch.outer(s0, pose.reshape(-1)))
+            m3.append(torch.outer(s3, pose.reshape(-1)))
+        m3.append(d[3].t() @ c[2])
+        gw = [torch.cat(m0, dim=1), d[1].t() @ c[0], d[2].t() @ c[1], torch.cat(m3, dim=1), d[4].t() @ c[3],
+              d[5][:, :3].t() @ c[4]]
+        gb = [s0, d[1].sum(0), d[2].sum(0), s3, d[4].sum(0), d[5][:, :3].sum(0)]
+        grads += [g.reshape(w.shape) for g, w in zip(gw, col_w)]
+        grads += [g.reshape(b.shape) for g, b in zip(gb, col_b)]
+        if n_pose:
+            p0 = 3 + n_view + 3 + 256
+            grads.append((col_w[0][:, p0:p0 + n_pose].t() @ s0 + col_w[3][:, p0:p0 + n_pose].t() @ s3).reshape(pose.shape))
+        else:
+            grads.append(None)
+        return (None, st["gx4"][:, :3]) + tuple(grads)
+
+
+def shade_samples_hip(idhr, frame, ws, sdf_network, x, T, view, view_orig, pose_cond, ray_augm):
+    """x (P,3) -> sdf (P,1) normalised units, rgb (P,3), differentiable w.r.t. x and every network parameter."""
+    from .nets import folded_weight
+    rn = idhr.rendering_network
+    n = len(sdf_network)
+    sdf_w = [sdf_network[i][0].weights[0] for i in range(n - 1)] + [sdf_network[n - 1].weights[0]]
+    sdf_b = [sdf_network[i][0].biases.reshape(-1) for i in range(n - 1)] + [sdf_network[n - 1].biases.reshape(-1)]
+    freq = torch.cat([sdf_network[i][0].freq.reshape(-1) for i in range(n - 1)])
+    phase = torch.cat([sdf_network[i][0].phase_shift.reshape(-1) for i in range(n - 1)])
+    col_w = [folded_weight(getattr(rn, "lin%d" % l)) for l in range(rn.num_layers - 1)]
+    col_b = [getattr(rn, "lin%d" % l).bias for l in range(rn.num_layers - 1)]
+    pose = rn.pose_vector(pose_cond)
+    n_pose = 0 if pose is None else int(pose.numel())
+    meta = dict(frame=frame, ws=ws, T=T.detach().contiguous() if T is not None else None, view=view.detach().contiguous(),
+                view_orig=view_orig.detach().contiguous() if view_orig is not None else None,
+                rotate_normal=not idhr.cano_view_dirs, ray_augm=bool(ray_augm), mode=rn.mode, n_pose=n_pose)
+    params = sdf_w + sdf_b + [freq, phase] + col_w + col_b + [pose.reshape(-1) if n_pose else x.new_zeros(1)]
+    sdf, rgb = ShadeSamples.apply(meta, x.contiguous(), *params)
+    return sdf.unsqueeze(-1), rgb
+
+
 def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, converge_mask, view_dirs,
                           view_dirs_orig, pose_cond, bone_transforms, coord_min, coord_max, center, n_steps,
-                          ray_augm=False, point_batch_size=100000):
+                          ray_augm=False, point_batch_size=100000, frame=None, ws=None):
+    """frame / ws given (GPU training): the per-sample networks run in the hand-written HIP forward / backward
+    (ShadeSamples); otherwise plain autograd (the restatement the HIP op is tested against)."""
     n_rays, S, _ = points.shape
     dev = points.device
     lengths = converge_mask.sum(-1)
@@ -116,6 +215,11 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
                 x_lbs, _ = forward_skinning(x_hat, coord_min, coord_max, center, idhr.skinning_model, bone_transforms)
                 Jinv = torch.linalg.inv(input_jacobian(x_lbs, pi)).detach()
                 pi = pi - torch.matmul(Jinv, (x_lbs - x_lbs.detach()).unsqueeze(-1)).squeeze(-1)
+            if frame is not None:
+                sdf, rgb = shade_samples_hip(idhr, frame, ws, sdf_network, pi.squeeze(0), Ti, vi, vi0, pose_cond, ray_augm)
+                sdf_all.append(sdf / 2.0 * 1.1 * (coord_max.squeeze() - coord_min.squeeze()))
+                rgb_all.append(rgb)
+                continue
             feat = sdf_network[:-1](pi).squeeze(0)
             sdf = sdf_network[-1](feat)
             normal = torch.autograd.grad(sdf, pi, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]

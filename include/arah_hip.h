@@ -143,6 +143,12 @@ typedef struct ArahFrame {
     const float* col_w4p;       /* packed [256][256] */
     const float* col_w5;        /* [3][256] */
     const float* col_bias;      /* b0'[256] b1[256] b2[128] b3'[256] b4[256] b5[4] */
+    const float* col_w0pT;      /* transposed packings of the colour MLP (reverse sweep of the training backward) */
+    const float* col_w1pT;
+    const float* col_w2pT;
+    const float* col_w3apT;
+    const float* col_w3bpT;
+    const float* col_w4pT;
     const float* verts4;        /* [256][28][4] k-d clustered vertices (x, y, z, original index) */
     const float* knn_spheres;   /* [256][4] bounding spheres of the clusters */
     const void* knn_grid;       /* grid geometry (device) */
@@ -204,6 +210,49 @@ int arah_joint_root_find(const ArahFrame* h_frame, const float* cam_loc, int32_t
                          const uint8_t* valid, const float* x0, const float* z0, const float* T0, int32_t n_rays,
                          float* x, float* z, float* T, uint8_t* conv, void* workspace, size_t workspace_bytes,
                          void* stream);
+
+/* ---- loop D with gradients (training; get_rbg_value_vol_sdf with self.training, IDR:261-396) ---------
+ * Per-sample forward (SDF value, normal, colour) and its hand-written backward incl. the second-order path through
+ * the normal.  Compositing and the loss stay with the caller (autograd); this pair is the custom op in between. */
+typedef struct ArahTrainIn {
+    int32_t n;                  /* P valid samples, dense */
+    int32_t rotate_normal;      /* !cano_view_dirs: the colour net sees R n with R = T[:3,:3] (IDR:339-340) */
+    int32_t ray_augm;           /* IDR:342-350: where n . view <= 0 the un-augmented view is used */
+    int32_t pad;
+    const float* x;             /* [P,3] normalised canonical points */
+    const float* T;             /* [P,16] forward transforms (rotate_normal) or NULL */
+    const float* view;          /* [P,3] view input of the colour net */
+    const float* view_orig;     /* [P,3] (ray_augm) or NULL */
+    const float* g_s;           /* [P]   dL/d sdf (normalised units)   -- backward only */
+    const float* g_rgb;         /* [P,3] dL/d rgb                      -- backward only */
+} ArahTrainIn;
+
+/* Outputs of the backward.  Weight gradients are sums of outer products over all samples; the kernel streams their
+ * operands as dense row-major [P,width] matrices and the caller finishes them with library GEMMs:
+ *   dW_k = av[k]^T h[k] + avd[k]^T hd[k]  (k = 0..5, SDF layer k+1),  db_k = colsum(av[k]),
+ *   dw_7 = g_s^T cin[:, :256] + colsum(hd[6]),  db_7 = sum(g_s),
+ *   colour layer l: dW_l = d[l]^T X_l with X_0 = cin, X_1..X_2 = c[0..1], X_3 = [cin | c[2]], X_4..X_5 = c[3..4]. */
+typedef struct ArahTrainGrads {
+    float* sdf;                 /* [P]   forward values again (recomputed) */
+    float* rgb4;                /* [P,4] */
+    float* gx4;                 /* [P,4] dL/dx */
+    float* film_freq;           /* [6,256] dL/d freq  */
+    float* film_phase;          /* [6,256] dL/d phase */
+    float* h[6];                /* h_0 [P,4] (x), h_1..h_5 [P,256] */
+    float* hd[7];               /* tangent stream: hd_0 = dL/dn [P,4], hd_1..hd_6 [P,256] */
+    float* av[6];               /* adj v_1..v_6 [P,256] */
+    float* avd[6];              /* adj vd_1..vd_6 [P,256] */
+    float* cin;                 /* [P,KIN_PAD] colour input, columns [feat(256) | x | n | PE(view) | 0] */
+    float* c[5];                /* colour hidden activations: 256, 256, 128, 256, 256 wide */
+    float* d[6];                /* colour deltas: 256, 256, 128, 256, 256 wide, delta_5 [P,4] */
+} ArahTrainGrads;
+
+size_t arah_shade_train_slab_bytes(void);   /* scratch of the backward (pre-activation spill, per workgroup) */
+/* -> sdf [P] (normalised units), rgb4 [P,4] */
+int arah_shade_train_forward(const ArahFrame* h_frame, const ArahTrainIn* h_in, float* sdf, float* rgb4,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int arah_shade_train_backward(const ArahFrame* h_frame, const ArahTrainIn* h_in, const ArahTrainGrads* h_out,
+                              void* slab, size_t slab_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* rays: cam_loc [n_cams,3], ray r belongs to camera r / rays_per_cam; dirs [N,3]; near_far [N,2].

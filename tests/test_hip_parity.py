@@ -53,7 +53,7 @@ def test_struct_sizes_match_header():
     # pointers ..., col_mode, n_pose (8 bytes), beta (device pointer), precision (+ 4 bytes of tail padding)
     assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 8 + 8 + 8
     assert C.sizeof(hip.ArahBody) == 8 * 7 + 8   # seven device pointers, n_verts (+ padding)
-    n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 8 + 4 + 3 + 1   # sdf, skin, colour, knn, body, scalars
+    n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 8 + 6 + 4 + 3 + 1   # sdf, skin, colour (+6 transposed), knn, body, scalars
     assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * 3 + 4   # three ints (+ padding)
     assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
     assert C.sizeof(hip.ArahCounters) == 64
@@ -643,3 +643,90 @@ def test_edge_cases(ctx, scene):
     assert torch.equal(one[0][0], many[0][1000])
     with pytest.raises(ValueError):
         hip.Sampling(dev, 16, 16, 16)           # n_steps < near + far + 1 (RT:346)
+
+
+@gpu
+@pytest.mark.parametrize("name,ray_augm", [("zju313", True), ("zju377_mono", False), ("h36m", False)])
+def test_shade_samples_op_against_autograd(scene, name, ray_augm):
+    """The hand-written forward / backward of loop D's per-sample part (training.ShadeSamples over csrc/train.hpp)
+    against plain autograd on the same tensors: values, dL/dx and the gradient of EVERY parameter that reaches it
+    (7 emitted SDF layers, FiLM frequencies / phases, the colour MLP's weight_g / weight_v / bias, the latent code),
+    second-order path through the normal included, for the three config families (normal rotated by T / view
+    canonicalised, both colour modes) and with the view-augmentation revert (IDR:342-350)."""
+    from arah_release_amd import nets, renderer, training
+    dev = torch.device("cuda:0")
+    model, cfg = get_model(name, dev)
+    idhr = model.idhr_network
+    inputs = scene.make_inputs(64, 64, frame_idx=4, device=dev)
+    g = torch.Generator().manual_seed(11)
+    P = 200   # ragged: 3 full tiles + 8
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})["decoder"]
+    # leaf copies of the emitted network so that gradients land on them
+    layers, leaves = [], []
+    for i in range(6):
+        lin = dec[i][0]
+        w, b = lin.weights.clone().requires_grad_(True), lin.biases.clone().requires_grad_(True)
+        f, p = lin.freq.clone().requires_grad_(True), lin.phase_shift.clone().requires_grad_(True)
+        leaves += [w, b, f, p]
+        layers.append(torch.nn.Sequential(nets.EmittedFiLMLinear(w, b, f, p), nets.Sine()))
+    w7, b7 = dec[6].weights.clone().requires_grad_(True), dec[6].biases.clone().requires_grad_(True)
+    leaves += [w7, b7]
+    sdf_network = torch.nn.Sequential(*layers, nets.EmittedLinear(w7, b7))
+    pose_cond = dict(inputs["pose_cond"])
+    latent = model.latent(pose_cond["latent_code_idx"]).detach().clone().requires_grad_(True)
+    pose_cond["latent_code"] = latent
+    col_params = [p for p in idhr.rendering_network.parameters()]
+    x = ((torch.rand(P, 3, generator=g) * 1.2 - 0.6)).to(dev).requires_grad_(True)
+    R = torch.linalg.qr(torch.randn(P, 3, 3, generator=g))[0]
+    T = torch.eye(4).repeat(P, 1, 1)
+    T[:, :3, :3] = R * (1.0 + 0.05 * torch.randn(P, 1, 1, generator=g))
+    T = T.to(dev)
+    view = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    view0 = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1).to(dev)
+    g_s = torch.randn(P, generator=g).to(dev)
+    g_rgb = torch.randn(P, 3, generator=g).to(dev)
+    everything = [x] + leaves + col_params + [latent]
+
+    def autograd_path():
+        xi = x.unsqueeze(0)
+        feat = sdf_network[:-1](xi).squeeze(0)
+        sdf = sdf_network[-1](feat)
+        normal = torch.autograd.grad(sdf, xi, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0].squeeze(0)
+        if not idhr.cano_view_dirs:
+            normal = torch.einsum("pij,pj->pi", T[:, :3, :3], normal)
+        vi = view
+        if ray_augm:
+            with torch.no_grad():
+                back = (torch.nn.functional.normalize(normal, dim=-1) * view).sum(-1) <= 0
+            vi = torch.where(back[:, None], view0, view)
+        rgb = idhr.rendering_network(x, normal, vi, feat, pose_cond)
+        return sdf.reshape(-1), rgb
+
+    def grads_of(sdf, rgb):
+        loss = (sdf * g_s).sum() + (rgb * g_rgb).sum()
+        return torch.autograd.grad(loss, everything, allow_unused=True)
+
+    sdf_ref, rgb_ref = autograd_path()
+    ref = grads_of(sdf_ref, rgb_ref)
+    with torch.no_grad():
+        frame = renderer.build_frame(sdf_network, model.skinning_model, idhr.rendering_network, model.deviation_decoder,
+                                     pose_cond, inputs["smpl_verts"], inputs["skinning_weights"],
+                                     inputs["bone_transforms"], inputs["trans"], inputs["coord_min"], inputs["coord_max"],
+                                     inputs["center"])
+    ws = idhr.ray_tracer.workspace(dev)
+    sdf_hip, rgb_hip = training.shade_samples_hip(idhr, frame, ws, sdf_network, x, T, view, view0, pose_cond, ray_augm)
+    got = grads_of(sdf_hip.reshape(-1), rgb_hip)
+    np.testing.assert_allclose(sdf_hip.reshape(-1).detach().cpu().numpy(), sdf_ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rgb_hip.detach().cpu().numpy(), rgb_ref.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    names = ["x"] + ["sdf%d.%s" % (i // 4, "wbfp"[i % 4]) for i in range(24)] + ["sdf6.w", "sdf6.b"] + \
+        ["col.%s" % n for n, _ in idhr.rendering_network.named_parameters()] + ["latent"]
+    assert len(names) == len(everything)
+    for nm, a, b in zip(names, got, ref):
+        assert (a is None) == (b is None), nm
+        if a is None:
+            continue
+        a, b = a.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(b).max() + 1e-12
+        assert np.abs(a - b).max() <= 2e-3 * scale, (nm, np.abs(a - b).max(), scale)
