@@ -179,9 +179,11 @@ class IDHRNetwork(nn.Module):
             pred_weights = training.query_weights(input["points_skinning"], cmin, cmax, center, self.skinning_model)
         # one packed frame per step serves the ray tracer (loops A-C) and the hand-written loop-D op
         use_hip_shading = os.environ.get("ARAH_TRAIN_AUTOGRAD", "0") != "1"
-        frame = build_frame(sdf_network, self.skinning_model, self.rendering_network, self.deviation_network, pose_cond,
-                            input["smpl_verts"], input["skinning_weights"], input["bone_transforms"], input["trans"],
-                            cmin, cmax, center)
+        frame = None
+        if ray_dirs.is_cuda:   # (CPU: only reachable with a stubbed ray tracer, e.g. the gloo DDP test; autograd loop D)
+            frame = build_frame(sdf_network, self.skinning_model, self.rendering_network, self.deviation_network,
+                                pose_cond, input["smpl_verts"], input["skinning_weights"], input["bone_transforms"],
+                                input["trans"], cmin, cmax, center)
         with torch.no_grad():
             xn, _, _, s_pts, s_z, s_T, s_mask = self.ray_tracer(
                 sdf_network, self.skinning_model, cam_loc=cam_loc, ray_directions=ray_dirs,
@@ -213,7 +215,7 @@ class IDHRNetwork(nn.Module):
             self, sdf_network, s_pts[vol_mask], s_z[vol_mask], s_T[vol_mask], s_mask[vol_mask], dirs_in[vol_mask],
             ray_dirs[vol_mask], pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
             self.ray_tracer.n_steps, ray_augm=ray_augm, frame=frame if use_hip_shading else None,
-            ws=self.ray_tracer.workspace(dev))
+            ws=self.ray_tracer.workspace(dev) if frame is not None else None)
         rgb = torch.zeros_like(xn).masked_scatter(vol_mask.unsqueeze(-1), rgb_hit)
         acc = torch.zeros(B, N, device=dev).masked_scatter(vol_mask, w_hit)
         out = {"rgb_values": rgb, "sdf_output": acc, "network_body_mask": vol_mask, "body_mask": input["body_mask"],

@@ -204,11 +204,25 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
     else:
         vin, vin0 = -vd, -vd0
     sdf_all, rgb_all = [], []
+    if frame is not None:
+        point_batch_size = max(point_batch_size, pts.shape[0])   # the HIP op streams its operands: no chunking needed
     for c in range(0, pts.shape[0], point_batch_size):
         pi = pts[c:c + point_batch_size].unsqueeze(0).requires_grad_(True)
         vi, vi0, Ti = vin[c:c + point_batch_size], vin0[c:c + point_batch_size], Tf[c:c + point_batch_size]
         with torch.enable_grad():
-            if idhr.train_skinning_net:
+            if idhr.train_skinning_net and frame is not None:
+                # Same re-attachment (IDR:315-334) with the Jacobian from the HIP seam (forward-mode tangents through the
+                # skinning MLP, arah_skin_jacobian) instead of three autograd passes: d x_hat = -J^-1 d LBS only needs
+                # the graph from the skinning parameters to x_lbs, the terms in d(pi) cancel identically.
+                from . import hip
+                pd = pi.detach()
+                x_hat = unnormalize_canonical_points(pd, coord_min, coord_max, center)
+                x_lbs, _ = forward_skinning(x_hat, coord_min, coord_max, center, idhr.skinning_model, bone_transforms)
+                span = (coord_max.reshape(-1)[0] - coord_min.reshape(-1)[0]) * 1.1 / 2.0     # d x_hat / d pi
+                J = hip.skin_jacobian(frame, ws, x_hat[0]) * span
+                Jinv = torch.linalg.inv(J).unsqueeze(0)
+                pi = pd - torch.matmul(Jinv, (x_lbs - x_lbs.detach()).unsqueeze(-1)).squeeze(-1)
+            elif idhr.train_skinning_net:
                 # x_hat is a root of LBS(x_hat) = x_bar found without a graph; re-attach it with the implicit
                 # function theorem: d x_hat = -J^-1 d LBS  (IDR:315-334)
                 x_hat = unnormalize_canonical_points(pi, coord_min, coord_max, center)

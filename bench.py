@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--config", default="zju377_mono")
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
     ap.add_argument("--passes", default="all", choices=["all", "default"],
                     help="'default': only the product's default path (profiling runs); 'all' adds the full-shading, "
                          "exact-engine and strict passes over the same frames")
@@ -147,20 +148,95 @@ def main():
 
     near = far = args.n_steps // 4
     model, cfg = config.build_synthetic_model(args.config, args.n_steps, near, far, device=dev)
-    scene = synthetic.SyntheticScene(0)
+    rt = GpuRuntime(world, rank, dev, dist if world > 1 else None, model, cfg, synthetic.SyntheticScene(0), hip)
+    line = run(args, rt)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+class GpuRuntime:
+    """What run() needs from the machine: the model, the scene, device synchronisation, events around the dominant
+    kernel.  tests/test_bench_sharding.py drives the same run() on two gloo ranks with a stub of this class."""
+
+    def __init__(self, world, rank, dev, dist, model, cfg, scene, hip):
+        self.world, self.rank, self.dev, self.dist = world, rank, dev, dist
+        self.model, self.cfg, self.scene, self.hip = model, cfg, scene, hip
+        self.tracer = model.idhr_network.ray_tracer
+        self.ev0 = torch.cuda.Event(enable_timing=True)
+        self.ev1 = torch.cuda.Event(enable_timing=True)
+
+    def make_inputs(self, size, frame_idx):
+        return self.scene.make_inputs(size, size, frame_idx=frame_idx, device=self.dev)
+
+    def render(self, inputs):
+        return self.model(inputs, eval=True)
+
+    def device_sync(self):
+        torch.cuda.synchronize()
+
+    def set_events(self, full_shading, on):
+        setter = self.hip.set_shade_events if full_shading else self.hip.set_density_events
+        setter(self.ev0, self.ev1) if on else setter(None, None)
+
+    def event_ms(self):
+        return self.ev0.elapsed_time(self.ev1)
+
+    def split_engine(self):
+        return self.hip.default_precision() == self.hip.PRECISION_SPLIT_F16
+
+    def cpu_baseline(self, args, near, far):
+        return cpu_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.cpu_sample_rays,
+                            model_gpu=self.model, dev=self.dev)
+
+    def training_line(self, steps=5, warmup=2):
+        """Training step of BASELINE.json configs[2] (ZJUMOCAP-313 shapes, one view of 2048 rays on this GPU): forward
+        (HIP ray tracer + hand-written loop D) + IDHRLoss + backward + Adam."""
+        from arah_release_amd import config, training
+        model, cfg = config.build_synthetic_model("zju313", device=self.dev)
+        model.train()
+        opt = training.configure_optimizers(model, cfg)
+        crit = training.build_loss(cfg)
+        batches = [self.scene.make_inputs(512, 512, frame_idx=k, max_rays=2048, eval_mode=False, device=self.dev)
+                   for k in range(steps + warmup)]
+
+        def step(inp):
+            opt.zero_grad(set_to_none=True)
+            losses = training.training_step(model, crit, inp)
+            losses["loss"].backward()
+            opt.step()
+
+        with torch.enable_grad():
+            for k in range(warmup):
+                step(batches[k])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(warmup, warmup + steps):
+                step(batches[k])
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        return {"note": "ZJUMOCAP-313 training step, 1 view x 2048 rays on one GPU: HIP ray tracer (no_grad) + hand-written "
+                        "loop-D forward/backward (k_shade_train) + regularisers / loss / hypernetwork on autograd + Adam",
+                "value": 2048 * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
+
+
+def run(args, rt):
+    """Everything after the model exists: frame sharding, the timed passes, whole-job aggregation, the JSON line."""
+    world, rank, dist = rt.world, rt.rank, rt.dist
+    tracer = rt.tracer
+    near = far = args.n_steps // 4
+    cfg = rt.cfg
     warm_frames, timed_frames = shard_frames(rank, world, args.steps, args.warmup)
-    warm_inputs = [scene.make_inputs(args.size, args.size, frame_idx=f, device=dev) for f in warm_frames]
-    timed_inputs = [scene.make_inputs(args.size, args.size, frame_idx=f, device=dev) for f in timed_frames]
+    warm_inputs = [rt.make_inputs(args.size, f) for f in warm_frames]
+    timed_inputs = [rt.make_inputs(args.size, f) for f in timed_frames]
     n_rays_local = sum(int(i["ray_dirs"].shape[1]) for i in timed_inputs)
 
     def sync():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
-
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    tracer = model.idhr_network.ray_tracer
+        rt.device_sync()
 
     n_rays_max = max(int(i["ray_dirs"].shape[1]) for i in warm_inputs + timed_inputs)
 
@@ -169,31 +245,30 @@ def main():
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
         tracer.full_shading = full_shading
         os.environ["ARAH_PRECISION"] = precision
-        ws = tracer.workspace(dev)
+        ws = tracer.workspace(rt.dev)
         ws.ensure(n_rays_max, args.n_steps)   # sized for the largest frame before anything is timed or counted
         for inp in warm_inputs:
-            model(inp, eval=True)
+            rt.render(inp)
         sync()
         ws.reset_counters()
         t0 = time.perf_counter()
         for inp in timed_inputs:
-            model(inp, eval=True)
+            rt.render(inp)
         sync()
         dt = time.perf_counter() - t0
         ctr = ws.counters()
-        setter = hip.set_shade_events if full_shading else hip.set_density_events
-        setter(ev0, ev1)
+        rt.set_events(full_shading, True)
         ms = []
         for inp in timed_inputs:
-            model(inp, eval=True)
-            torch.cuda.synchronize()
-            ms.append(ev0.elapsed_time(ev1))
-        setter(None, None)
+            rt.render(inp)
+            rt.device_sync()
+            ms.append(rt.event_ms())
+        rt.set_events(full_shading, False)
         os.environ["ARAH_PRECISION"] = default_engine
         return dt, ctr, ms
 
     default_engine = os.environ.get("ARAH_PRECISION", "split")
-    split = hip.default_precision() == hip.PRECISION_SPLIT_F16
+    split = rt.split_engine()
     with torch.no_grad():
         elapsed, counters, dens_ms = timed_pass(False, default_engine)          # the product's default path
         elapsed_full = elapsed_exact = elapsed_strict = None
@@ -204,10 +279,11 @@ def main():
             elapsed_strict, counters_strict, strict_ms = timed_pass(True, "fp32")   # all of the reference's work, fp32 MFMA only
         tracer.full_shading = False
 
-    total_rays, t_max = aggregate(n_rays_local, elapsed, dist if world > 1 else None)
-    t_max_full = aggregate(n_rays_local, elapsed_full, dist if world > 1 else None)[1] if elapsed_full else None
-    t_max_exact = aggregate(n_rays_local, elapsed_exact, dist if world > 1 else None)[1] if elapsed_exact else None
-    t_max_strict = aggregate(n_rays_local, elapsed_strict, dist if world > 1 else None)[1] if elapsed_strict else None
+    total_rays, t_max = aggregate(n_rays_local, elapsed, dist)
+    t_max_full = aggregate(n_rays_local, elapsed_full, dist)[1] if elapsed_full else None
+    t_max_exact = aggregate(n_rays_local, elapsed_exact, dist)[1] if elapsed_exact else None
+    t_max_strict = aggregate(n_rays_local, elapsed_strict, dist)[1] if elapsed_strict else None
+    line = None
     if rank == 0:
         mode = cfg["model"]["renderer_kwargs"]["mode"]
 
@@ -288,15 +364,13 @@ def main():
                                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                            "avg_launch_ms": sum(strict_ms) / n_l}}
+        if world == 1 and not args.no_train:
+            line["training"] = rt.training_line()
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(scene, args.config, args.size, args.n_steps, near, far,
-                                                args.cpu_sample_rays, model_gpu=model, dev=dev)
+            line["cpu_baseline"] = rt.cpu_baseline(args, near, far)
             line["psnr_vs_oracle_db"] = line["cpu_baseline"].get("psnr_vs_oracle_db")
             line["mask_agreement"] = line["cpu_baseline"].get("mask_agreement")
-        print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return line
 
 
 if __name__ == "__main__":

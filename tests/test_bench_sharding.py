@@ -49,3 +49,98 @@ def test_aggregate_two_ranks_gloo():
         assert rays == 3000.0          # sum over ranks
         assert secs == 1.0             # max over ranks
     assert bench.aggregate(10, 2.0, None) == (10.0, 2.0)
+
+
+# ---- the real bench.run() on two gloo ranks with a stub of the GPU runtime --------------------------------------------
+class _StubWorkspace:
+    def __init__(self):
+        self.n = 0
+
+    def ensure(self, n_rays, n_steps):
+        pass
+
+    def reset_counters(self):
+        self.n = 0
+
+    def counters(self):
+        keys = ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn", "n_density")
+        return {k: 100 * self.n for k in keys}
+
+
+class _StubTracer:
+    def __init__(self):
+        self.full_shading = False
+        self.ws = _StubWorkspace()
+
+    def workspace(self, dev):
+        return self.ws
+
+
+class _StubRuntime:
+    """Same surface as bench.GpuRuntime; a 'render' costs 2 ms per frame on rank 0 and 4 ms on rank 1, a frame has
+    1000 + frame_idx rays."""
+
+    def __init__(self, world, rank):
+        self.world, self.rank, self.dev, self.dist = world, rank, "cpu", dist
+        self.cfg = {"model": {"renderer_kwargs": {"mode": "no_view_dir"}}}
+        self.tracer = _StubTracer()
+        self.rendered = []
+
+    def make_inputs(self, size, frame_idx):
+        return {"ray_dirs": torch.zeros(1, 1000 + frame_idx, 3), "frame": frame_idx}
+
+    def render(self, inputs):
+        import time
+        time.sleep(0.002 * (self.rank + 1))
+        self.tracer.ws.n += 1
+        self.rendered.append(inputs["frame"])
+
+    def device_sync(self):
+        pass
+
+    def set_events(self, full_shading, on):
+        pass
+
+    def event_ms(self):
+        return 1.0
+
+    def split_engine(self):
+        return False
+
+
+def _run_worker(rank, world, port, out):
+    import argparse
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = argparse.Namespace(gpus=world, steps=3, warmup=1, size=64, n_steps=64, config="zju377_mono",
+                              cpu_sample_rays=16, no_cpu_baseline=True, no_train=True, passes="default")
+    rt = _StubRuntime(world, rank)
+    line = bench.run(args, rt)
+    out[rank] = (line, list(rt.rendered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_run_two_ranks_gloo():
+    """bench.run() end to end on two ranks: disjoint frames per rank, value = all ranks' rays / the SLOWER rank's
+    time, one JSON line on rank 0 only, with the fields the driver parses."""
+    world = 2
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_run_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    line0, frames0 = out[0]
+    line1, frames1 = out[1]
+    assert line1 is None and line0 is not None
+    # frame i -> rank i mod 2; each pass renders warm-up + timed + the event-timing repeat of the timed frames
+    assert set(frames0) == {0, 2, 4, 6} and set(frames1) == {1, 3, 5, 7}
+    assert frames0 == [0, 2, 4, 6, 2, 4, 6]
+    rays = sum(1000 + f for f in (2, 4, 6)) + sum(1000 + f for f in (3, 5, 7))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line0, key
+    assert line0["n_gpus"] == 2 and line0["steps"] == 3 and line0["scaling"] == "weak" and line0["unit"] == "rays/s"
+    t = line0["ms_per_step"] * 3 / 1e3
+    assert abs(line0["value"] - rays / t) < 1e-6 * line0["value"]
+    assert 3 * 0.004 <= t < 3 * 0.004 + 0.2          # the slower rank (4 ms per frame) sets the time
+    assert "workload" in line0["config"] and "model" not in line0["config"]
