@@ -959,7 +959,8 @@ template <bool GRAD, bool SPLIT>
 __global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(FrameDev fr, const float* x_norm, const int* list,
                                                         const int* count, int n_direct, float* sdf_out,
                                                         float* feat_out, float* grad_out, f32x4* spill_all,
-                                                        unsigned long long* ctr_fwd, unsigned long long* ctr_grad) {
+                                                        unsigned long long* ctr_fwd, unsigned long long* ctr_grad,
+                                                        int grid_n) {
     const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                       // [64][4]
@@ -976,7 +977,16 @@ __global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(
             const int id = i < n ? (list ? list[i] : i) : -1;
             ids[tid] = id;
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (id >= 0) x = f32x4{x_norm[(size_t)id * 3], x_norm[(size_t)id * 3 + 1], x_norm[(size_t)id * 3 + 2], 0.f};
+            if (id >= 0 && grid_n > 0) {
+                // lattice point id = (ix * N + iy) * N + iz of [-1, 1]^3, coordinates as sdf_meshing.py:26-38 forms them
+                const float vs = 2.0f / (float)(grid_n - 1);
+                const int iz = id % grid_n, iy = (id / grid_n) % grid_n, ix = id / (grid_n * grid_n);
+                // product and sum rounded separately, like the two tensor operations of the reference (no fma contraction)
+                x = f32x4{__fadd_rn(__fmul_rn((float)ix, vs), -1.0f), __fadd_rn(__fmul_rn((float)iy, vs), -1.0f),
+                          __fadd_rn(__fmul_rn((float)iz, vs), -1.0f), 0.f};
+            } else if (id >= 0) {
+                x = f32x4{x_norm[(size_t)id * 3], x_norm[(size_t)id * 3 + 1], x_norm[(size_t)id * 3 + 2], 0.f};
+            }
             reinterpret_cast<f32x4*>(xin)[tid] = x;
         }
         __syncthreads();
@@ -2803,11 +2813,69 @@ int arah_sdf_eval(const ArahFrame* f, const float* x_norm, int32_t n, float* sdf
     if (grad)
         LAUNCH_ENGINE(fd.split, (k_sdf_eval<true, true>), (k_sdf_eval<true, false>), dim3(g), dim3(kThreads), kLdsSdfGrad,
                       s, fd, x_norm, (const int*)nullptr, (const int*)nullptr, n, sdf, feat, grad, w.spill,
-                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
+                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, 0);
     else
         LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(g), dim3(kThreads),
                       kLdsSdfFwd, s, fd, x_norm, (const int*)nullptr, (const int*)nullptr, n, sdf, feat, (float*)nullptr,
-                      (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr);
+                      (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, 0);
+    return check_launch();
+}
+
+// SDF on the N^3 lattice of [-1, 1]^3 (create_mesh_vertices_and_faces, utils/sdf_meshing.py:13-70: N = 256, the
+// reference evaluates it in 64 chunks with a host copy each): one launch, coordinates formed in the kernel, the
+// values stay on the device.  sdf[(ix * N + iy) * N + iz], normalised units.
+int arah_sdf_grid(const ArahFrame* f, int32_t n_side, float* sdf, void* workspace, size_t wbytes, void* stream) {
+    if (!f || !sdf || !workspace || n_side < 2 || n_side > 1024) return ARAH_E_BADARG;
+    Workspace w = carve(workspace, 1, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    const long long n = (long long)n_side * n_side * n_side;
+    if (n > 0x7fffffffLL) return ARAH_E_BADARG;
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(n, kTile)), dim3(kThreads),
+                  kLdsSdfFwd, s, fd, (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, (int)n, sdf,
+                  (float*)nullptr, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr,
+                  (int)n_side);
+    return check_launch();
+}
+
+// ---- triangle rasteriser (pix_to_face of pytorch3d's MeshRasterizer as models/__init__.py:232-237,268-276 use it:
+// one face per pixel, no blur, no culling).  tri [F][3][3] = (u, v, z) per corner in PIXEL coordinates (pixel (i, j)
+// has its centre at u = j + 0.5, v = i + 0.5) and view-space depth z > 0.  zbuf [H*W] 64-bit keys
+// (depth bits << 32 | face), pre-set to ~0 by the caller; the nearest covering face wins.
+__global__ void k_raster(const float* __restrict__ tri, int n_faces, int H, int W, float z_near,
+                         unsigned long long* __restrict__ zbuf) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_faces) return;
+    const float* t = tri + (size_t)f * 9;
+    const float x0 = t[0], y0 = t[1], z0 = t[2], x1 = t[3], y1 = t[4], z1 = t[5], x2 = t[6], y2 = t[7], z2 = t[8];
+    if (!(z0 > z_near && z1 > z_near && z2 > z_near)) return;   // faces that reach the near plane are dropped (also NaNs)
+    const float area = (x1 - x0) * (y2 - y0) - (x2 - x0) * (y1 - y0);
+    if (area == 0.f || !(area == area)) return;
+    const float inv_area = 1.0f / area;
+    int j0 = max(0, (int)floorf(fminf(x0, fminf(x1, x2)) - 0.5f)), j1 = min(W - 1, (int)ceilf(fmaxf(x0, fmaxf(x1, x2)) - 0.5f));
+    int i0 = max(0, (int)floorf(fminf(y0, fminf(y1, y2)) - 0.5f)), i1 = min(H - 1, (int)ceilf(fmaxf(y0, fmaxf(y1, y2)) - 0.5f));
+    if (j1 - j0 > 4096 || i1 - i0 > 4096) return;
+    for (int i = i0; i <= i1; ++i)
+        for (int j = j0; j <= j1; ++j) {
+            const float px = (float)j + 0.5f, py = (float)i + 0.5f;
+            const float w0 = ((x1 - px) * (y2 - py) - (x2 - px) * (y1 - py)) * inv_area;
+            const float w1 = ((x2 - px) * (y0 - py) - (x0 - px) * (y2 - py)) * inv_area;
+            const float w2 = 1.0f - w0 - w1;
+            if (w0 < 0.f || w1 < 0.f || w2 < 0.f) continue;
+            const float z = w0 * z0 + w1 * z1 + w2 * z2;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | (unsigned)f;
+            atomicMin(&zbuf[(size_t)i * W + j], key);
+        }
+}
+
+int arah_rasterize(const float* tri_uvz, int32_t n_faces, int32_t H, int32_t W, float z_near, uint64_t* zbuf, void* stream) {
+    if (n_faces < 0 || H <= 0 || W <= 0 || !zbuf) return ARAH_E_BADARG;
+    if (n_faces == 0) return ARAH_OK;
+    if (!tri_uvz) return ARAH_E_BADARG;
+    hipLaunchKernelGGL(k_raster, dim3((n_faces + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), tri_uvz,
+                       (int)n_faces, (int)H, (int)W, z_near, reinterpret_cast<unsigned long long*>(zbuf));
     return check_launch();
 }
 
@@ -2916,7 +2984,7 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
     // d sdf / d x at the normalised start point == d(metric sdf)/d(metric x)  (RFU:408-413)
     LAUNCH_ENGINE(fd.split, (k_sdf_eval<true, true>), (k_sdf_eval<true, false>), dim3(gm), dim3(kThreads), kLdsSdfGrad, s,
                   fd, (const float*)w.xcur, (const int*)w.listA, (const int*)&cntB[0], 0, w.u_gx /*scratch: sdf*/,
-                  (float*)nullptr, w.grad_sdf, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad);
+                  (float*)nullptr, w.grad_sdf, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, 0);
     Broyden4State st{w.u_eval, w.u_step, w.u_gx, w.u_Jinv, w.err_best_ray, w.xbest_ray, w.zbest_ray, T};
     hipLaunchKernelGGL(k_joint_init, dim3(grid_for(n, 256)), dim3(256), 0, s, fd, st, rs, (const int*)w.listA,
                        (const int*)&cntB[0], (const float*)w.grad_sdf, (const float*)w.jac_lbs, (const float*)w.xcur,

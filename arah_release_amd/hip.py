@@ -89,7 +89,7 @@ class ArahCounters(C.Structure):
 COUNTER_BYTES = C.sizeof(ArahCounters)
 
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
-           "arah_counters_read", "arah_sdf_eval", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
+           "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
            "arah_shade_train_backward", "arah_dominant_kernel", "arah_set_shade_events",
@@ -354,6 +354,31 @@ def sdf_eval(frame, ws, x_norm, want_feat=False, want_grad=False):
     _check(lib.arah_sdf_eval(C.byref(frame.handle), _ptr(x), C.c_int32(n), _ptr(sdf), _ptr(feat), _ptr(grad),
                              _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_sdf_eval")
     return sdf, feat, grad
+
+
+@_guarded
+def sdf_grid(frame, ws, n_side=256):
+    """SDF on the n_side^3 lattice of [-1,1]^3 -> (n_side, n_side, n_side) tensor [ix, iy, iz], on the device."""
+    lib = load_library()
+    buf = ws.ensure(1, 1)
+    out = torch.empty(n_side, n_side, n_side, device=frame.device)
+    _check(lib.arah_sdf_grid(C.byref(frame.handle), C.c_int32(int(n_side)), _ptr(out), _ptr(buf), C.c_size_t(buf.numel()),
+                             _stream()), "arah_sdf_grid")
+    return out
+
+
+def rasterize(tri_uvz, height, width, z_near=1e-4):
+    """tri_uvz (F,3,3) pixel-space corners (u, v, view depth) -> pix_to_face (H,W) int64, -1 where nothing covers."""
+    require_gpu()
+    lib = load_library()
+    tri = _f32(tri_uvz)
+    dev = tri.device
+    with _on_device(dev):
+        zbuf = torch.full((height * width,), -1, dtype=torch.int64, device=dev)   # all bits set
+        _check(lib.arah_rasterize(_ptr(tri), C.c_int32(int(tri.shape[0])), C.c_int32(int(height)), C.c_int32(int(width)),
+                                  C.c_float(float(z_near)), _ptr(zbuf), _stream()), "arah_rasterize")
+    face = (zbuf & 0xffffffff).reshape(height, width)
+    return torch.where(zbuf.reshape(height, width) == -1, torch.full_like(face, -1), face)
 
 
 @_guarded

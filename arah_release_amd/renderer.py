@@ -242,6 +242,7 @@ class IDHRNetwork(nn.Module):
                             self.deviation_network, input["pose_cond"], input["smpl_verts"],
                             input["skinning_weights"], input["bone_transforms"], input["trans"],
                             input["coord_min"], input["coord_max"], input["center"])
+        self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
         ws = self.ray_tracer.workspace(dev)
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
@@ -289,9 +290,6 @@ class MetaAvatarRender(nn.Module):
             self.frames = kwargs.get("frames")
 
     def forward(self, inputs, gen_cano_mesh=False, eval=False):
-        if gen_cano_mesh:
-            raise NotImplementedError("canonical mesh extraction (marching cubes + rasteriser) is outside "
-                                      "the hot path (SURVEY 8f-1)")
         rots, Jtrs = inputs["rots"], inputs["Jtrs"]
         B, dev = rots.size(0), rots.device
         decoder_input = {"coords": torch.zeros(1, 1, 3, dtype=torch.float32, device=dev),
@@ -321,4 +319,13 @@ class MetaAvatarRender(nn.Module):
             inputs["pose_cond"]["latent_code"] = self.latent(inputs["pose_cond"]["latent_code_idx"])
         model_outputs = self.idhr_network(inputs)
         model_outputs.update({"sdf_params": out["params"]})
+        if gen_cano_mesh:   # models/__init__.py:203-311: canonical mesh + the three normal maps, all on the device
+            from . import meshing
+            frame = getattr(self.idhr_network, "last_frame", None)
+            if frame is None:   # training-mode forward: pack the emitted network once for the meshing kernels
+                frame = build_frame(inputs["sdf_network"], self.skinning_model, None, None, None, inputs["smpl_verts"],
+                                    inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
+                                    inputs["coord_min"], inputs["coord_max"], inputs["center"])
+            maps, _ = meshing.canonical_mesh_outputs(frame, self.idhr_network.ray_tracer.workspace(dev), inputs)
+            model_outputs.update(maps)
         return model_outputs

@@ -25,6 +25,10 @@
  *   arah_broyden3_lbs       search_canonical_corr on caller-supplied initial guesses
  *                           (broyden.py:4-78 with g = LBS(x) - target)
  *   arah_joint_root_find    search_iso_surface_depth on caller-supplied starts  root_finding_utils.py:365-484
+ *   arah_sdf_grid           create_mesh_vertices_and_faces' lattice evaluation  utils/sdf_meshing.py:13-70
+ *   arah_rasterize          pytorch3d MeshRasterizer (pix_to_face) as used at metaavatar_render/models/__init__.py:232-276
+ *   arah_shade_train_*      get_rbg_value_vol_sdf with self.training: per-sample forward and backward
+ *                           renderer/implicit_differentiable_renderer.py:291-361, diff_operators.py:39-50
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name starts with "h_"; the caller owns all
@@ -184,6 +188,13 @@ int arah_counters_read(const void* workspace, ArahCounters* h_out, void* stream)
 /* x_norm [P,3] -> sdf [P] (normalised units), optional feat [P,256], optional grad [P,3] */
 int arah_sdf_eval(const ArahFrame* h_frame, const float* x_norm, int32_t n_pts, float* sdf, float* feat,
                   float* grad, void* workspace, size_t workspace_bytes, void* stream);
+/* SDF on the N^3 lattice of [-1,1]^3 (utils/sdf_meshing.py:13-70): sdf[(ix*N + iy)*N + iz], normalised units */
+int arah_sdf_grid(const ArahFrame* h_frame, int32_t n_side, float* sdf, void* workspace, size_t workspace_bytes,
+                  void* stream);
+/* nearest covering face per pixel (pix_to_face of the rasteriser models/__init__.py:232-237 uses): tri [F,3,3] =
+ * (u, v, z) per corner in pixel coordinates / view depth; zbuf [H*W] keys (depth bits << 32 | face), pre-set to ~0 */
+int arah_rasterize(const float* tri_uvz, int32_t n_faces, int32_t height, int32_t width, float z_near,
+                   uint64_t* zbuf, void* stream);
 /* raw canonical x_hat [P,3] -> optional w [P,24], x_bar [P,3], T [P,16] */
 int arah_skin_lbs(const ArahFrame* h_frame, const float* x_hat, int32_t n_pts, float* w, float* x_bar,
                   float* T, void* workspace, size_t workspace_bytes, void* stream);
