@@ -91,33 +91,95 @@ def _color_feature_dim(cfg):
     return 256 + extra[enc]
 
 
-def get_render_model(cfg, mode="test", low_vram=False, checkpoint_path=None, n_data_points=None, **kwargs):
-    """metaavatar_render.config.get_model: returns the bare MetaAvatarRender module."""
+def _load_pretrained(module, path, prefix, what):
+    """MetaAvatar initialisation (metaavatar_render/config.py:32-45,72-84): entries of ckpt['model'] under `prefix`
+    (after an optional 'module.'), loaded non-strictly like the reference -- but a checkpoint that names the path and
+    does not exist, or that contributes NOTHING to the module, is an error here instead of a silently untrained net."""
+    if not os.path.exists(path):
+        raise FileNotFoundError("%s initialisation %r not found (cfg['model'] names it; mode 'val'/'test' skips it)"
+                                % (what, path))
+    ckpt = torch.load(path, map_location="cpu")
+    sd = {}
+    for k, v in ckpt["model"].items():
+        if k.startswith("module"):
+            k = k[7:]
+        if k.startswith(prefix):
+            sd[k[len(prefix) + 1:]] = v
+    res = module.load_state_dict(sd, strict=False)
+    used = [k for k in sd if k not in res.unexpected_keys]
+    if not used:
+        raise ValueError("%s: no entry of %r matches the %s network" % (path, prefix, what))
+    return res
+
+
+def get_render_model(cfg, mode="test", low_vram=False, checkpoint_path=None, n_data_points=None, dataset=None,
+                     **kwargs):
+    """metaavatar_render.config.get_model (config.py:147-302): returns the bare MetaAvatarRender module.
+    `dataset` (mode 'train'/'val'): object with ``cam_names``, ``cameras`` and ``data`` (list of dicts with 'cam_idx',
+    'frame_idx', 'model_file', 'gender') as the reference's datasets expose them."""
     m = cfg["model"]
+    init_weights = mode not in ("val", "test")                               # config.py:154-160
     sdf_decoder = nets.decoder_dict[m["decoder"]](**m["decoder_kwargs"])
-    skinning = nets.SkinningModel(nets.decoder_dict[m["skinning_decoder"]](**m["skinning_decoder_kwargs"]))
+    if init_weights and m.get("geometry_net"):
+        _load_pretrained(sdf_decoder, m["geometry_net"], "decoder", "SDF")
+    skin_dec = nets.decoder_dict[m["skinning_decoder"]](**m["skinning_decoder_kwargs"])
+    if init_weights and m.get("skinning_net2"):
+        _load_pretrained(skin_dec, m["skinning_net2"], "skinning_decoder_fwd", "skinning")
+    skinning = nets.SkinningModel(skin_dec)
     color = nets.RenderingNetwork(d_feature=_color_feature_dim(cfg), pose_encoder=m["color_pose_encoder"],
                                   **m["renderer_kwargs"])
     deviation = nets.SingleVarianceNetwork(1e-3)
-    if m.get("train_cameras") and mode in ("train", "val"):
-        raise NotImplementedError("train_cameras needs the dataset's camera files")
-    if m.get("train_smpl") and mode in ("train", "val"):
-        raise NotImplementedError("train_smpl needs body_models/misc/*.npz (not redistributable)")
+    model_kwargs = {}
+    train_cameras = bool(m.get("train_cameras")) and mode in ("train", "val")
+    if train_cameras:                                                        # config.py:166-177
+        from scipy.spatial.transform import Rotation
+        cams = dataset.cameras
+        model_kwargs["cam_rots"] = np.stack([Rotation.from_matrix(np.asarray(cams[c]["R"])).as_quat().astype(np.float32)
+                                             for c in dataset.cam_names], axis=0)
+        model_kwargs["cam_trans"] = np.stack([np.asarray(cams[c]["T"], np.float32).ravel() for c in dataset.cam_names],
+                                             axis=0)
+    train_smpl = bool(m.get("train_smpl")) and mode in ("train", "val")
+    if train_smpl:                                                           # config.py:179-224
+        from . import data as data_mod
+        acc = {k: [] for k in ("root_orient", "pose_body", "pose_hand", "trans", "frames")}
+        cam_idx = dataset.data[0]["cam_idx"]
+        betas, gender = None, None
+        for d_idx, item in enumerate(dataset.data):
+            if item["cam_idx"] != cam_idx:
+                break                      # one batch = one frame: the parameters of one camera view are enough
+            md = data_mod.load_model_npz(item["model_file"])
+            for key, width in (("root_orient", 3), ("pose_body", 3), ("pose_hand", 3)):
+                v = md[key].astype(np.float32).reshape(-1, width)
+                v[(v == 0.0).all(axis=-1)] += 1e-8                          # exact zeros have no axis
+                acc[key].append(v.reshape(-1))
+            if d_idx == 0:
+                betas, gender = md["betas"].astype(np.float32), item["gender"]
+            acc["trans"].append(md["trans"].astype(np.float32))
+            acc["frames"].append(item["frame_idx"])
+        model_kwargs.update(acc, betas=betas, gender=gender, body_model=kwargs.get("body_model"))
     train_latent = m["color_pose_encoder"] in ("hybrid", "latent")
     train_geo_latent = m["geo_pose_encoder"] in ("latent",)
     ckpt = None
     if checkpoint_path is not None:
         ckpt = torch.load(checkpoint_path, map_location="cpu")
-    model_kwargs = {}
-    if train_latent or train_geo_latent:
+    if (train_latent or train_geo_latent) and mode in ("train", "val") and dataset is not None:   # config.py:233-250
+        cam_idx = dataset.data[0]["cam_idx"]
+        frames = []
+        for item in dataset.data:
+            if item["cam_idx"] != cam_idx:
+                break
+            frames.append(item["frame_idx"])
+        model_kwargs.update(n_data_points=len(frames), frames=frames)
+    elif train_latent or train_geo_latent:
         if ckpt is not None:
             n_data_points = ckpt["state_dict"]["model.latent.weight"].size(0)   # config.py:253-257
         if n_data_points is None:
             raise ValueError("need n_data_points or a checkpoint to size the latent embedding")
-        model_kwargs.update(n_data_points=n_data_points, frames=[])
+        model_kwargs.update(n_data_points=n_data_points)
+        model_kwargs.setdefault("frames", [])
     t = cfg.get("training", {})
     model = MetaAvatarRender(sdf_decoder=sdf_decoder, skinning_model=skinning, color_decoder=color,
-                             deviation_decoder=deviation, train_cameras=False, train_smpl=False,
+                             deviation_decoder=deviation, train_cameras=train_cameras, train_smpl=train_smpl,
                              train_latent_code=train_latent, train_geo_latent_code=train_geo_latent,
                              cano_view_dirs=m["cano_view_dirs"], near_surface_samples=m["near_surface_samples"],
                              far_surface_samples=m["far_surface_samples"], n_steps=m["n_steps"],
@@ -132,22 +194,152 @@ def get_render_model(cfg, mode="test", low_vram=False, checkpoint_path=None, n_d
 
 
 class LightningModel(nn.Module):
-    """Minimal stand-in for the reference's Lightning harness (lightning_model.py:101-653): holds
-    ``model`` under the same attribute so that checkpoints keep the 'model.' prefix; the harness itself
-    (dataset composition, metrics, image writing) is the caller and out of scope."""
+    """The model-facing half of the reference's Lightning harness (metaavatar_render/lightning_model.py:101-653):
+    ``compose_inputs`` (dataset dict -> model inputs, on the device, incl. the train_cameras / train_smpl branches),
+    ``compute_loss``, ``training_step`` / ``validation_step`` / ``test_step`` (image scatter included) and
+    ``configure_optimizers`` with the reference's parameter groups.  ``model`` sits under the same attribute so that
+    checkpoints keep the 'model.' prefix.  Metrics (LPIPS / SSIM), image writing and the Lightning runtime itself are
+    the caller's."""
 
     def __init__(self, model, cfg, val_size=None):
         super().__init__()
         self.model = model
         self.cfg = cfg
         self.val_size = val_size
+        from . import training
+        self.criteria = training.build_loss(cfg) if "training" in cfg else None
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
 
     def forward(self, inputs, gen_cano_mesh=False, eval=True):
         return self.model(inputs, gen_cano_mesh=gen_cano_mesh, eval=eval)
 
-    def test_step(self, inputs):
+    def configure_optimizers(self):
+        from . import training
+        opt = training.configure_optimizers(self.model, self.cfg)
+        if self.model.train_cameras:
+            opt.add_param_group({"params": list(self.model.camera_parameters()), "lr": 1e-4})     # lightning_model.py:431-437
+        if self.model.train_smpl:
+            opt.add_param_group({"params": list(self.model.smpl_parameters()), "lr": 1e-4})       # :440-446
+        return opt
+
+    def compose_inputs(self, data, eval):
+        """lightning_model.py:463-634, tensor for tensor; everything stays on the device `data` lives on."""
+        from . import smpl, training
+        model = self.model
+        smpl_verts = data.get("image.smpl_vertices")
+        cam_idx = data.get("inputs.cam_idx")
+        if model.train_cameras and not eval:          # optimised extrinsics: rays from the stored pixel coordinates
+            uv = data.get("inputs.uv")
+            cam_rot = smpl.quaternion_to_rotation_matrix_xyzw(model.cam_rots[cam_idx])
+            cam_trans = model.cam_trans[cam_idx]
+            rays = torch.matmul(uv, cam_rot)
+            ray_dirs = rays / (torch.norm(rays, p=2, dim=-1, keepdim=True) + 1e-12)
+            cam_loc = torch.matmul(-cam_rot.transpose(1, 2), cam_trans.unsqueeze(-1)).squeeze(-1)
+        else:
+            ray_dirs, cam_loc = data.get("inputs.ray_dirs"), data.get("image.cam_loc")
+            cam_rot, cam_trans = data.get("image.R"), data.get("image.T")
+        B = smpl_verts.size(0)
+        f_idx = int(data.get("inputs.frame_idx")[0])
+        if data.get("inputs.novel_seq") is not None:
+            f_idx = -1
+        if model.train_smpl and f_idx in model.frames:
+            bp = model.body_poses
+            root_orient, pose_body = bp["root_orient_%d" % f_idx].unsqueeze(0), bp["pose_body_%d" % f_idx].unsqueeze(0)
+            pose_hand, trans = bp["pose_hand_%d" % f_idx].unsqueeze(0), bp["trans_%d" % f_idx].unsqueeze(0)
+            verts_posed, Jtrs, Jtrs_posed, bone_transforms, minimal_shape = model.forward_smpl(
+                model.betas, root_orient, pose_body, pose_hand, trans)
+            smpl_verts = (verts_posed + trans.unsqueeze(1)).repeat(B, 1, 1)
+            b02v = smpl.get_transforms_02v(Jtrs.squeeze(0))
+            T = torch.matmul(model.lbs_weights, b02v.reshape(-1, 16)).reshape(-1, 4, 4)
+            shape_v = torch.matmul(T[:, :3, :3], minimal_shape.reshape(-1, 3, 1)).squeeze(-1) + T[:, :3, -1]
+            center = torch.mean(shape_v, dim=0, keepdim=True)
+            centred = shape_v - center
+            center = center.view(1, 1, -1).repeat(B, 1, 1)
+            coord_max = centred.max().view(1, 1, -1).repeat(B, 1, 1)
+            coord_min = centred.min().view(1, 1, -1).repeat(B, 1, 1)
+            minimal_shape = shape_v.reshape(1, -1, 3).repeat(B, 1, 1)
+            b02v = b02v.unsqueeze(0).repeat(B, 1, 1, 1)
+            bone_transforms = bone_transforms.repeat(B, 1, 1, 1)
+            Jtrs = training.normalize_canonical_points(Jtrs, coord_min[:1], coord_max[:1], center[:1]).repeat(B, 1, 1)
+            Jtrs_posed = Jtrs_posed + trans.unsqueeze(1)
+            full_pose = torch.cat([root_orient, pose_body, pose_hand], dim=-1).reshape(-1, 3)
+            full_mat = smpl.angle_axis_to_rotation_matrix(full_pose).reshape(-1, 9)
+            local = torch.cat([torch.eye(3, device=full_mat.device).reshape(1, 9), full_mat[1:]], dim=0)
+            rots, rots_full = local.unsqueeze(0).repeat(B, 1, 1), full_mat.unsqueeze(0)
+        else:
+            minimal_shape, rots, Jtrs = data.get("image.minimal_shape"), data.get("image.rots"), data.get("image.Jtrs")
+            rots_full, Jtrs_posed = data.get("image.rots_full"), data.get("image.Jtrs_posed")
+            coord_min = data.get("image.coord_min").view(B, 1, -1)
+            coord_max = data.get("image.coord_max").view(B, 1, -1)
+            center = data.get("image.center").view(B, 1, -1)
+            bone_transforms, b02v = data.get("image.bone_transforms"), data.get("image.bone_transforms_02v")
+            trans = data.get("image.trans").unsqueeze(1)
+        bone_transforms = torch.matmul(bone_transforms, torch.inverse(b02v))   # Vitruvian canonical pose -> posed, no translation
+        pose = torch.cat([nn.functional.pad(cam_rot, pad=(0, 0, 0, 1)),
+                          nn.functional.pad(cam_trans, pad=(0, 1), value=1).unsqueeze(-1)], dim=-1)
+        pose_cond = {"rots_full": rots_full, "Jtrs_posed": Jtrs_posed}
+
+        def code_index():
+            if f_idx in model.frames:
+                return data.get("inputs.data_idx")[:1]
+            return torch.tensor([model.latent.num_embeddings - 1], dtype=torch.int64, device=smpl_verts.device)
+
+        if model.train_latent_code:
+            pose_cond["latent_code_idx"] = code_index()
+        inputs = {"intrinsics": data.get("image.K"), "ray_dirs": ray_dirs,
+                  "body_bounds_intersections": data.get("inputs.body_bounds_intersections"), "cam_loc": cam_loc,
+                  "cam_rot": cam_rot, "cam_trans": cam_trans, "pose": pose, "body_mask": data.get("inputs.mask_erode"),
+                  "smpl_verts": smpl_verts, "skinning_weights": data.get("image.skinning_weights"),
+                  "bone_transforms": bone_transforms, "trans": trans, "coord_min": coord_min, "coord_max": coord_max,
+                  "center": center, "minimal_shape": minimal_shape, "pose_cond": pose_cond, "Jtrs": Jtrs, "rots": rots,
+                  "cam_idx": cam_idx}
+        if model.train_geo_latent_code:
+            inputs["geo_latent_code_idx"] = code_index()
+        if not eval:
+            inputs["rgb_values"] = data.get("inputs")
+            for key in ("sampled_weights", "points_skinning", "points_inside", "points_uniform"):
+                if data.get("image." + key) is not None:
+                    inputs[key] = data.get("image." + key)
+        else:
+            inputs["image_mask"] = data.get("inputs.image_mask")
+            inputs["ray_dirs_cam"] = data.get("inputs.ray_dirs_cam")
+        return inputs
+
+    def compute_loss(self, data):
+        """lightning_model.py:636-653."""
+        inputs = self.compose_inputs(data, eval=False)
+        out = self.model(inputs)
+        gt = {"rgb": inputs["rgb_values"]}
+        if "sampled_weights" in inputs:
+            gt["sampled_weights"] = inputs["sampled_weights"]
+        return self.criteria(out, gt)
+
+    def training_step(self, data, data_idx=None):
+        return self.compute_loss(data)["loss"]
+
+    def render_image(self, data, gen_cano_mesh=False):
+        """The model half of validation_step / test_step (lightning_model.py:158-181,300-330): forward in eval mode,
+        then pred_pixels.masked_scatter_(image_mask, rgb) into a (B,H,W,3) image."""
+        inputs = self.compose_inputs(data, eval=True)
         with torch.no_grad():
-            return self.model(inputs, gen_cano_mesh=False, eval=True)
+            out = self.model(inputs, gen_cano_mesh=gen_cano_mesh, eval=True)
+        mask = inputs["image_mask"]
+        img = torch.zeros(*mask.shape, 3, device=mask.device)
+        img.masked_scatter_(mask.unsqueeze(-1), out["rgb_values"].reshape(-1, 3))
+        out["image"] = img
+        return out
+
+    def validation_step(self, data, data_idx=None):
+        return self.render_image(data, gen_cano_mesh=False)
+
+    def test_step(self, data, data_idx=None):
+        if not isinstance(data, dict) or "inputs.ray_dirs" not in data:   # already-composed model inputs
+            with torch.no_grad():
+                return self.model(data, gen_cano_mesh=False, eval=True)
+        return self.render_image(data, gen_cano_mesh=True)                # lightning_model.py:320
 
 
 class _Method:

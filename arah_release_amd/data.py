@@ -1,0 +1,192 @@
+"""Data side of the hot path: the reference builds the model's inputs on CPU workers in numpy
+(data/zju_mocap_odp.py:200-415: SMPL posing, projected-box pixel mask, ray directions, near/far) -- at ~20 ms per frame
+of rendering that becomes the bottleneck of a sharded sequence, so here the same arithmetic runs as tensor
+operations on the device the frame will be rendered on.  Also the readers of the on-disk formats the
+reference's preprocessing writes (preprocess_datasets/preprocess_ZJU-MoCap.py:150-158, preprocess_aist.py:116-124):
+
+    <subject>/cam_params.json       {"all_cam_names": [...], "<cam>": {"K": 3x3, "D": [...], "R": 3x3, "T": 3x1}}
+    <subject>/models/*.npz          minimal_shape (6890,3), betas (1,10), Jtr_posed (24,3), bone_transforms (24,4,4),
+                                    trans (3,), root_orient (3,), pose_body (63,), pose_hand (6,)
+"""
+import glob
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import smpl
+
+MODEL_KEYS = ("minimal_shape", "betas", "Jtr_posed", "bone_transforms", "trans", "root_orient", "pose_body", "pose_hand")
+MODEL_SHAPES = {"minimal_shape": (6890, 3), "Jtr_posed": (24, 3), "bone_transforms": (24, 4, 4), "trans": (3,),
+                "root_orient": (3,), "pose_body": (63,), "pose_hand": (6,)}
+
+
+def load_cam_params(path):
+    """cam_params.json -> {"all_cam_names": [...], name: {"K","D","R","T"} as float32 arrays}."""
+    with open(path, "r") as f:
+        raw = json.load(f)
+    if "all_cam_names" not in raw:
+        raise ValueError("%s: no 'all_cam_names' entry" % path)
+    out = {"all_cam_names": list(raw["all_cam_names"])}
+    for name in out["all_cam_names"]:
+        if name not in raw:
+            raise ValueError("%s: camera %r listed but not described" % (path, name))
+        c = raw[name]
+        out[name] = {"K": np.asarray(c["K"], np.float32).reshape(3, 3), "D": np.asarray(c.get("D", []), np.float32).ravel(),
+                     "R": np.asarray(c["R"], np.float32).reshape(3, 3), "T": np.asarray(c["T"], np.float32).reshape(3)}
+    return out
+
+
+def load_model_npz(path):
+    """One frame's SMPL registration; raises on a missing key or a wrong shape (float16 minimal shapes are accepted)."""
+    with np.load(path) as a:
+        missing = [k for k in MODEL_KEYS if k not in a.files]
+        if missing:
+            raise ValueError("%s: missing %s" % (path, ", ".join(missing)))
+        out = {k: np.asarray(a[k]) for k in MODEL_KEYS}
+    for k, shp in MODEL_SHAPES.items():
+        if tuple(out[k].reshape(shp).shape) != shp:
+            raise ValueError("%s: %s has shape %s, expected %s" % (path, k, out[k].shape, shp))
+        out[k] = out[k].reshape(shp).astype(np.float32)
+    out["betas"] = out["betas"].astype(np.float32).reshape(1, -1)
+    return out
+
+
+def list_sequence(subject_dir, pose_dir="models", start_frame=0, end_frame=-1, sampling_rate=1):
+    """(frame indices, model files) like the dataset constructor slices them (zju_mocap_odp.py:103-112)."""
+    files = sorted(glob.glob(os.path.join(subject_dir, pose_dir, "*.npz")))
+    frames = list(range(len(files)))
+    sl = slice(start_frame, end_frame if end_frame > 0 else None, sampling_rate)
+    return frames[sl], files[sl]
+
+
+# ------------------------------------------------------------------------------------------------
+# rays (utils/utils.py:16-73, zju_mocap_odp.py:160-180,285-315) on the device
+# ------------------------------------------------------------------------------------------------
+_QUADS = ((0, 1, 3, 2), (4, 5, 7, 6, 5), (0, 1, 5, 4), (2, 3, 7, 6), (0, 2, 6, 4), (1, 3, 7, 5))   # utils.py:48-53 verbatim
+
+
+def bound_corners(bounds):
+    (x0, y0, z0), (x1, y1, z1) = bounds[0], bounds[1]
+    return torch.stack([torch.stack(c) for c in ((x0, y0, z0), (x0, y0, z1), (x0, y1, z0), (x0, y1, z1),
+                                                 (x1, y0, z0), (x1, y0, z1), (x1, y1, z0), (x1, y1, z1))])
+
+
+def bound_2d_mask(bounds, K, pose34, H, W):
+    """Pixels of the projected bounding box (get_bound_2d_mask, utils.py:43-54): the eight corners are projected and
+    ROUNDED to integers, then six polygons are filled -- one of them listed as (4,5,7,6,5), i.e. a triangle plus a
+    segment, kept as written.  cv2.fillPoly is not in this image: a pixel is taken when its integer coordinate is
+    inside or on the boundary of a polygon (exact integer arithmetic), which is cv2's rule for simple polygons."""
+    dev = bounds.device
+    c3 = bound_corners(bounds)
+    xyz = c3 @ pose34[:, :3].t() + pose34[:, 3]
+    xyz = xyz @ K.t()
+    c2 = torch.round(xyz[:, :2] / xyz[:, 2:]).to(torch.int64)
+    ys, xs = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    mask = torch.zeros(H, W, dtype=torch.bool, device=dev)
+    for quad in _QUADS:
+        poly = c2[list(quad)]
+        n = poly.shape[0]
+        winding = torch.zeros(H, W, dtype=torch.int64, device=dev)
+        on_edge = torch.zeros(H, W, dtype=torch.bool, device=dev)
+        for i in range(n):
+            (ax, ay), (bx, by) = poly[i], poly[(i + 1) % n]
+            cross = (bx - ax) * (ys - ay) - (by - ay) * (xs - ax)
+            up = (ay <= ys) & (by > ys) & (cross > 0)
+            down = (ay > ys) & (by <= ys) & (cross < 0)
+            winding += up.to(torch.int64) - down.to(torch.int64)
+            within = (xs >= torch.minimum(ax, bx)) & (xs <= torch.maximum(ax, bx)) & (ys >= torch.minimum(ay, by)) & \
+                (ys <= torch.maximum(ay, by))
+            on_edge |= (cross == 0) & within
+        mask |= (winding != 0) | on_edge
+    return mask
+
+
+def near_far(bounds, ray_o, ray_d):
+    """get_near_far (utils.py:56-73): slab test against the axis-aligned box, with the reference's epsilon rules."""
+    norm = ray_d.norm(dim=-1, keepdim=True)
+    v = ray_d / norm
+    v = torch.where((v < 1e-5) & (v > -1e-10), torch.full_like(v, 1e-5), v)
+    v = torch.where((v > -1e-5) & (v < 1e-10), torch.full_like(v, -1e-5), v)
+    tmin = (bounds[:1] - ray_o[:1]) / v
+    tmax = (bounds[1:2] - ray_o[:1]) / v
+    near = torch.minimum(tmin, tmax).max(dim=-1)[0]
+    far = torch.maximum(tmin, tmax).min(dim=-1)[0]
+    ok = near < far
+    return near / norm[..., 0], far / norm[..., 0], ok
+
+
+def frame_item(model, camera, body, img_size, orig_img_size, box_margin=0.05, device="cpu", cam_idx=0, frame_idx=0,
+               data_idx=0, gender="neutral"):
+    """Device-side counterpart of ZJUMOCAPODPDataset.__getitem__ in test mode (zju_mocap_odp.py:200-415) + the default
+    collate (leading batch dimension of 1): the flat 'image.*' / 'inputs.*' dict LightningModel.compose_inputs takes.
+    model: load_model_npz dict (numpy); camera: {"K","R","T"}; body: smpl.BodyModel (numpy arrays)."""
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=device)
+    H, W = (img_size, img_size) if np.isscalar(img_size) else img_size
+    oh, ow = (orig_img_size, orig_img_size) if np.isscalar(orig_img_size) else orig_img_size
+    K, R, T = f32(camera["K"]).clone(), f32(camera["R"]), f32(camera["T"]).reshape(3)
+    cam_loc = -R.t() @ T
+    side = float(max(oh, ow))
+    K[0, 0], K[1, 1] = K[0, 0] / side * max(H, W), K[1, 1] / side * max(H, W)
+    K[:2, 2] = K[:2, 2] / side * max(H, W)
+    K_inv = torch.linalg.inv(K)
+    trans, minimal_shape = f32(model["trans"]), f32(model["minimal_shape"])
+    bone_transforms = f32(model["bone_transforms"])
+    pose = torch.cat([f32(model["root_orient"]), f32(model["pose_body"]), f32(model["pose_hand"])]).reshape(-1, 3)
+    rot_full = _rotvec_to_matrix(pose)                                  # scipy Rotation.from_rotvec(...).as_matrix()
+    rots = torch.cat([torch.eye(3, device=device).unsqueeze(0), rot_full[1:]], dim=0).reshape(24, 9)
+    J_regressor, posedirs, weights = f32(body.J_regressor), f32(body.posedirs), f32(body.lbs_weights)
+    Jtr = J_regressor @ minimal_shape
+    pose_feature = (rot_full[1:] - torch.eye(3, device=device)).reshape(207)
+    minimal_shape = minimal_shape + (pose_feature @ posedirs).reshape(-1, 3)
+    Tv = (weights @ bone_transforms.reshape(24, 16)).reshape(-1, 4, 4)
+    verts = torch.einsum("vij,vj->vi", Tv[:, :3, :3], minimal_shape) + Tv[:, :3, 3] + trans
+    bounds = torch.stack([verts.min(dim=0)[0] - box_margin, verts.max(dim=0)[0] + box_margin])
+    mask = bound_2d_mask(bounds, K, torch.cat([R, T.reshape(3, 1)], dim=1), H, W)
+    y_inds, x_inds = torch.nonzero(mask, as_tuple=True)
+    homo = torch.stack([x_inds.float(), y_inds.float(), torch.ones_like(x_inds, dtype=torch.float32)], dim=-1)
+    uv = homo @ K_inv.t()
+    rays_cam = uv / (uv.norm(dim=-1, keepdim=True) + 1e-12)
+    rays = uv @ R
+    rays = rays / (rays.norm(dim=-1, keepdim=True) + 1e-12)
+    near, far, ok = near_far(bounds, cam_loc.expand_as(rays), rays)
+    image_mask = torch.zeros(H, W, dtype=torch.bool, device=device)
+    image_mask[y_inds[ok], x_inds[ok]] = True
+    b02v = smpl.get_transforms_02v(Jtr)
+    T02 = (weights @ b02v.reshape(24, 16)).reshape(-1, 4, 4)
+    shape_v = torch.einsum("vij,vj->vi", T02[:, :3, :3], minimal_shape) + T02[:, :3, 3]
+    center = shape_v.mean(dim=0)
+    cmax, cmin = (shape_v - center).max(), (shape_v - center).min()
+    pad = (cmax - cmin) * 0.05
+    Jn = (((Jtr - center) - cmin + pad) / (cmax - cmin) / 1.1 - 0.5) * 2.0
+    n_rays = int(ok.sum())
+    b = lambda t: t.unsqueeze(0)
+    return {
+        "image.trans": b(trans), "image.bone_transforms": b(bone_transforms), "image.bone_transforms_02v": b(b02v),
+        "image.coord_max": b(cmax), "image.coord_min": b(cmin), "image.center": b(center),
+        "image.minimal_shape": b(shape_v), "image.smpl_vertices": b(verts), "image.skinning_weights": b(weights),
+        "image.root_orient": b(f32(model["root_orient"])), "image.pose_hand": b(f32(model["pose_hand"])),
+        "image.pose_body": b(f32(model["pose_body"])), "image.rots": b(rots), "image.Jtrs": b(Jn),
+        "image.rots_full": b(rot_full.reshape(24, 9)), "image.Jtrs_posed": b(f32(model["Jtr_posed"])),
+        "image.center_cam": b(K[:2, 2].clone()), "image.focal_length": b(torch.stack([K[0, 0], K[1, 1]])),
+        "image.K": b(K), "image.R": b(R), "image.T": b(T), "image.cam_loc": b(cam_loc),
+        "inputs": torch.zeros(1, n_rays, 3, device=device), "inputs.mask": torch.ones(1, n_rays, dtype=torch.bool, device=device),
+        "inputs.mask_erode": torch.ones(1, n_rays, dtype=torch.bool, device=device), "inputs.uv": b(uv[ok]),
+        "inputs.ray_dirs": b(rays[ok]), "inputs.ray_dirs_cam": b(rays_cam[ok]),
+        "inputs.body_bounds_intersections": b(torch.stack([near[ok], far[ok]], dim=-1)), "inputs.gender": [gender],
+        "inputs.img_height": torch.tensor([H]), "inputs.img_width": torch.tensor([W]),
+        "inputs.cam_idx": torch.tensor([cam_idx], device=device), "inputs.frame_idx": torch.tensor([frame_idx]),
+        "inputs.data_idx": torch.tensor([data_idx], device=device), "inputs.novel_seq": torch.tensor([True]),
+        "inputs.image_mask": b(image_mask),
+    }
+
+
+def _rotvec_to_matrix(rv):
+    """scipy.spatial.transform.Rotation.from_rotvec(rv).as_matrix() through the quaternion, in float32 on the device."""
+    angle = rv.norm(dim=1)
+    small = angle <= 1e-3
+    a2 = angle * angle
+    scale = torch.where(small, 0.5 - a2 / 48 + a2 * a2 / 3840, torch.sin(angle / 2) / angle.clamp_min(1e-30))
+    q = torch.cat([rv * scale.unsqueeze(1), torch.cos(angle / 2).unsqueeze(1)], dim=1)
+    return smpl.quaternion_to_rotation_matrix_xyzw(q)

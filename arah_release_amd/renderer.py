@@ -265,9 +265,6 @@ class MetaAvatarRender(nn.Module):
                  render_last_pt=False, pose_input_noise=True, view_input_noise=True, nv_noise_type="rotation",
                  low_vram=False, n_steps=64, **kwargs):
         super().__init__()
-        if train_cameras or train_smpl:
-            raise NotImplementedError("train_cameras / train_smpl need SMPL data files that are not "
-                                      "redistributable; use mode='val'/'test' style construction")
         self.sdf_decoder = sdf_decoder
         self.skinning_model = skinning_model
         self.color_decoder = color_decoder
@@ -282,12 +279,62 @@ class MetaAvatarRender(nn.Module):
                                         cano_view_dirs=cano_view_dirs, train_skinning_net=train_skinning_net,
                                         render_last_pt=render_last_pt, low_vram=low_vram)
         self.train_cameras = train_cameras
+        if train_cameras:   # models/__init__.py:81-89: per-camera extrinsics (XYZW quaternion + translation) become parameters
+            cam_trans, cam_rots = kwargs.get("cam_trans"), kwargs.get("cam_rots")
+            assert cam_trans is not None and cam_rots is not None
+            self.register_parameter("cam_trans", nn.Parameter(torch.as_tensor(np.asarray(cam_trans, np.float32))))
+            self.register_parameter("cam_rots", nn.Parameter(torch.as_tensor(np.asarray(cam_rots, np.float32))))
         self.train_smpl = train_smpl
+        if train_smpl:      # models/__init__.py:91-123: SMPL templates as buffers, per-frame poses / translation + betas as parameters
+            from . import smpl
+            body = kwargs.get("body_model")   # reference: np.load('body_models/misc/*.npz')[gender] (licence-gated files)
+            if body is None:
+                body = smpl.BodyModel.from_files(kwargs.get("gender"))
+            f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32))
+            self.register_buffer("v_template", f32(body.v_template).unsqueeze(0))
+            self.register_buffer("posedirs", f32(body.posedirs))
+            self.register_buffer("shapedirs", f32(body.shapedirs))
+            self.register_buffer("J_regressor", f32(body.J_regressor))
+            self.register_buffer("lbs_weights", f32(body.lbs_weights))
+            self.register_buffer("kintree_table", torch.as_tensor(np.asarray(body.kintree_table, np.int32)))
+            frames = kwargs.get("frames")
+            self.frames = frames
+            params = {}
+            for key in ("root_orient", "pose_body", "pose_hand", "trans"):
+                vals = kwargs.get(key)
+                params.update({"%s_%s" % (key, fr): nn.Parameter(f32(vals[i])) for i, fr in enumerate(frames)})
+            self.body_poses = nn.ParameterDict(params)
+            self.register_parameter("betas", nn.Parameter(f32(kwargs.get("betas"))))
         self.train_latent_code = train_latent_code
         self.train_geo_latent_code = train_geo_latent_code
         if train_latent_code or train_geo_latent_code:
             self.latent = nn.Embedding(kwargs.get("n_data_points"), 128)
-            self.frames = kwargs.get("frames")
+            if not train_smpl:
+                self.frames = kwargs.get("frames")
+
+    def forward_smpl(self, betas, root_orient, pose_body, pose_hand, trans):
+        """SMPL linear blend skinning of the template (models/__init__.py:317-339):
+        -> verts_posed (B,V,3) without translation, Jtrs (rest), Jtrs_posed, bone_transforms (B,24,4,4), minimal_shape."""
+        from . import smpl
+        full_pose = torch.cat([root_orient, pose_body, pose_hand], dim=-1)
+        verts, J_posed, J, A, _, v_posed = smpl.lbs(betas, full_pose, self.v_template, self.shapedirs, self.posedirs,
+                                                    self.J_regressor, self.kintree_table[0].long(), self.lbs_weights)
+        return verts, J, J_posed, A, v_posed
+
+    def network_parameters(self):
+        for name, param in self.named_parameters():
+            if name not in ["cam_rots", "cam_trans", "root_orient", "pose_body", "pose_hand", "trans", "betas"]:
+                yield param
+
+    def camera_parameters(self):
+        for name, param in self.named_parameters():
+            if name in ["cam_rots", "cam_trans"]:
+                yield param
+
+    def smpl_parameters(self):
+        for name, param in self.named_parameters():
+            if name.startswith(("body_poses", "betas")):
+                yield param
 
     def forward(self, inputs, gen_cano_mesh=False, eval=False):
         rots, Jtrs = inputs["rots"], inputs["Jtrs"]

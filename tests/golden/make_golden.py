@@ -195,7 +195,116 @@ def make_f1_d4():
          z_opt=zo[0], T_opt=To[0], converged=conv[0])
 
 
+def make_f9():
+    """F9: the callers' side -- SMPL LBS (human_body_prior.lbs), Vitruvian-pose transforms (torch and numpy twins),
+    box / ray helpers, and LightningModel.compose_inputs in both branches (dataset-provided SMPL; optimised SMPL +
+    cameras), on the synthetic body model.  The dataset's __getitem__ itself needs cv2.fillPoly and cannot run here:
+    the data dict comes from the build's device-side counterpart (arah_release_amd.data.frame_item) and is stored."""
+    import torch.nn as nn
+    from human_body_prior.body_model.lbs import lbs as ref_lbs
+    from im2mesh.metaavatar_render import lightning_model as ref_lm
+    from im2mesh.metaavatar_render import models as ref_models
+    from im2mesh.data.zju_mocap_odp import get_02v_bone_transforms
+    from im2mesh.utils.utils import get_near_far
+    from scipy.spatial.transform import Rotation
+    from arah_release_amd import data as my_data, smpl as my_smpl
+    torch.set_num_threads(os.cpu_count())
+    scene = synthetic.SyntheticScene(seed=0)
+    body = my_smpl.BodyModel.synthetic(scene)
+    rng = np.random.RandomState(9)
+    t = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+    out = {}
+    # ---- lbs
+    betas = t(rng.randn(1, 10) * 0.5)
+    pose = t(rng.randn(1, 72) * 0.3)
+    verts, J_t, J, A, abs_A, v_posed = ref_lbs(betas=betas, pose=pose, v_template=t(body.v_template)[None],
+                                               clothed_v_template=None, shapedirs=t(body.shapedirs), posedirs=t(body.posedirs),
+                                               J_regressor=t(body.J_regressor),
+                                               parents=torch.from_numpy(body.kintree_table[0].astype(np.int64)),
+                                               lbs_weights=t(body.lbs_weights), dtype=torch.float32)
+    out.update(lbs_betas=betas, lbs_pose=pose, lbs_verts=verts[0], lbs_J_posed=J_t[0], lbs_J=J[0], lbs_A=A[0],
+               lbs_v_posed=v_posed[0])
+    # ---- 02v transforms
+    out.update(v02_torch=ref_lm.get_transforms_02v(J[0]),
+               v02_numpy=get_02v_bone_transforms(J[0].numpy(), Rotation.from_euler("z", 45, degrees=True).as_matrix(),
+                                                 Rotation.from_euler("z", -45, degrees=True).as_matrix()))
+    # ---- rays / near-far
+    bounds = np.array([[-0.4, -0.9, 2.6], [0.5, 0.8, 3.3]], np.float32)
+    ray_d = rng.randn(512, 3).astype(np.float32)
+    ray_d[:, 2] = np.abs(ray_d[:, 2]) + 1.0
+    ray_d[:8, 0] = 0.0
+    ray_o = np.broadcast_to(np.array([0.02, -0.01, 0.0], np.float32), ray_d.shape)
+    near, far, ok = get_near_far(bounds, ray_o, ray_d.copy())
+    Rm = Rotation.from_rotvec([0.1, -0.2, 0.05]).as_matrix().astype(np.float32)
+    uv = rng.randn(1, 256, 3).astype(np.float32)
+    out.update(nf_bounds=bounds, nf_ray_o=ray_o[:1], nf_ray_d=ray_d, nf_near=near, nf_far=far, nf_ok=ok, cam_R=Rm,
+               cam_uv=uv[0], cam_rays=ref_lm.get_camera_rays(t(Rm)[None], t(uv))[0],
+               cam_loc=ref_lm.get_camera_location(t(Rm)[None], t([[0.3, -0.1, 2.0]]))[0])
+    # ---- compose_inputs
+    aa = rng.randn(24, 3) * 0.25
+    Aposed = scene.frame(3)
+    model_dict = dict(minimal_shape=scene.verts_cano, betas=np.zeros((1, 10), np.float32), Jtr_posed=Aposed["joints_posed"],
+                      bone_transforms=Aposed["bone_transforms"], trans=np.array([0.1, 0.0, 3.0], np.float32),
+                      root_orient=aa[0], pose_body=aa[1:22].reshape(-1), pose_hand=aa[22:].reshape(-1))
+    model_dict = {k: np.asarray(v, np.float32) for k, v in model_dict.items()}
+    cam = {"K": np.array([[76.8, 0, 32], [0, 76.8, 32], [0, 0, 1]], np.float32), "R": Rotation.from_rotvec([0.0, 0.05, 0.0]).as_matrix(),
+           "T": np.array([0.02, 0.0, 0.1], np.float32)}
+    item = my_data.frame_item(model_dict, cam, body, 64, 64, frame_idx=5, data_idx=1)
+    cfg = ref_config.load_config(REF_CFG["zju313"], "configs/default.yaml")
+    my_cfg = my_config.builtin_config("zju313")
+    sd = my_config.synthetic_state_dict(my_cfg)
+    fake = "/tmp/arah_fake_ckpt_f9.ckpt"
+    torch.save({"state_dict": {"model.latent.weight": sd["latent.weight"]}}, fake)
+    model = ref_render_config.get_model(cfg, mode="test", checkpoint_path=fake)
+    lm = ref_lm.LightningModel.__new__(ref_lm.LightningModel)
+    nn.Module.__init__(lm)
+    lm.model, lm.cfg = model, cfg
+    object.__setattr__(lm, "device", torch.device("cpu"))
+    model.frames = []
+    a = lm.compose_inputs(dict(item), eval=True)
+    keep = ("ray_dirs", "cam_loc", "pose", "bone_transforms", "trans", "coord_min", "coord_max", "center", "Jtrs", "rots",
+            "smpl_verts", "minimal_shape", "cam_rot", "cam_trans")
+    out.update({"ciA." + k: a[k] for k in keep})
+    out.update({"ciA.rots_full": a["pose_cond"]["rots_full"], "ciA.Jtrs_posed": a["pose_cond"]["Jtrs_posed"],
+                "ciA.latent_code_idx": a["pose_cond"]["latent_code_idx"], "ciA.geo_latent_code_idx": a["geo_latent_code_idx"]})
+    # branch B: what MetaAvatarRender.__init__ registers with train_smpl / train_cameras (models/__init__.py:81-123);
+    # the constructor itself reads body_models/misc/*.npz, which do not exist here
+    model.train_smpl = model.train_cameras = True
+    model.frames = [4, 5]
+    for name in ("posedirs", "shapedirs", "J_regressor", "lbs_weights"):
+        model.register_buffer(name, t(getattr(body, name)))
+    model.register_buffer("v_template", t(body.v_template).unsqueeze(0))
+    model.register_buffer("kintree_table", torch.from_numpy(body.kintree_table.astype(np.int32)))
+    pd = {}
+    smpl_b = {}
+    for fr in (4, 5):
+        p = rng.randn(24, 3).astype(np.float32) * 0.2
+        smpl_b[fr] = dict(root_orient=p[0], pose_body=p[1:22].reshape(-1), pose_hand=p[22:].reshape(-1),
+                          trans=np.array([0.05 * fr, 0.01, 3.0], np.float32))
+        pd.update({"%s_%d" % (k, fr): nn.Parameter(t(v)) for k, v in smpl_b[fr].items()})
+    model.body_poses = nn.ParameterDict(pd)
+    model.register_parameter("betas", nn.Parameter(t(rng.randn(1, 10) * 0.3)))
+    quat = Rotation.from_rotvec([[0.02, -0.04, 0.01]]).as_quat().astype(np.float32)
+    model.register_parameter("cam_rots", nn.Parameter(t(quat)))
+    model.register_parameter("cam_trans", nn.Parameter(t([[0.01, 0.02, 0.12]])))
+    itemB = dict(item)
+    itemB["inputs.novel_seq"] = None
+    itemB["inputs"] = torch.rand(1, item["inputs.uv"].shape[1], 3)
+    b = lm.compose_inputs(itemB, eval=False)
+    out.update({"ciB." + k: b[k] for k in keep})
+    out.update({"ciB.rots_full": b["pose_cond"]["rots_full"], "ciB.Jtrs_posed": b["pose_cond"]["Jtrs_posed"],
+                "ciB.latent_code_idx": b["pose_cond"]["latent_code_idx"], "ciB.betas": model.betas, "ciB.cam_rots": model.cam_rots,
+                "ciB.cam_trans": model.cam_trans, "ciB.rgb_values": b["rgb_values"]})
+    for fr in (4, 5):
+        out.update({"ciB.%s_%d" % (k, fr): v for k, v in smpl_b[fr].items()})
+    out.update({"md." + k: v for k, v in model_dict.items()})
+    out.update({"cam." + k: np.asarray(v, np.float32) for k, v in cam.items()})
+    save("f9_callers.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f9":
+        return make_f9()
     if len(sys.argv) > 1 and sys.argv[1] == "f1d4":
         return make_f1_d4()
     if len(sys.argv) > 1 and sys.argv[1] == "f8":

@@ -87,6 +87,24 @@ def install():
             parent, child = name.rsplit(".", 1)
             setattr(sys.modules[parent], child, sys.modules[name])
     sys.modules["pytorch3d.ops"].knn_points = _knn_points
+    # kornia 0.5.10 conversions used by LightningModel.compose_inputs (lightning_model.py:477,539): third-party, restated
+    # from kornia's documented formulas (the same restatement the build uses: these two functions pin nothing)
+    import enum
+    from arah_release_amd import smpl as _smpl
+
+    class QuaternionCoeffOrder(enum.Enum):
+        XYZW = "xyzw"
+        WXYZ = "wxyz"
+
+    conv = sys.modules["kornia.geometry.conversions"]
+    conv.QuaternionCoeffOrder = QuaternionCoeffOrder
+    conv.angle_axis_to_rotation_matrix = _smpl.angle_axis_to_rotation_matrix
+
+    def _q2r(q, order=QuaternionCoeffOrder.XYZW):
+        assert order == QuaternionCoeffOrder.XYZW
+        return _smpl.quaternion_to_rotation_matrix_xyzw(q)
+
+    conv.quaternion_to_rotation_matrix = _q2r
     pl = sys.modules["pytorch_lightning"]
     pl.LightningModule = nn.Module
     # the reference tree must win over this repo's own ``im2mesh`` drop-in package

@@ -1,0 +1,255 @@
+"""Callers and data formats either side of the hot path (VERDICT "missing" #3): SMPL linear blend
+skinning, Vitruvian-pose transforms, ray / box helpers and LightningModel.compose_inputs against fixture F9 (generated
+by the reference's own human_body_prior.lbs, get_transforms_02v / get_02v_bone_transforms, get_near_far,
+get_camera_rays / get_camera_location and LightningModel.compose_inputs in both branches); the on-disk formats; the
+train_smpl / train_cameras construction; the pre-trained initialisation of get_model."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden
+
+T = lambda a: torch.from_numpy(np.asarray(a, np.float32))
+
+
+@pytest.fixture(scope="module")
+def body(scene):
+    from arah_release_amd import smpl
+    return smpl.BodyModel.synthetic(scene)
+
+
+def test_lbs_against_reference(body):
+    from arah_release_amd import smpl
+    g = golden("f9_callers.npz")
+    verts, J_posed, J, A, _, v_posed = smpl.lbs(T(g["lbs_betas"]), T(g["lbs_pose"]), T(body.v_template)[None],
+                                                T(body.shapedirs), T(body.posedirs), T(body.J_regressor),
+                                                torch.from_numpy(body.kintree_table[0].astype(np.int64)),
+                                                T(body.lbs_weights))
+    for got, key in ((verts, "lbs_verts"), (J_posed, "lbs_J_posed"), (J, "lbs_J"), (A, "lbs_A"), (v_posed, "lbs_v_posed")):
+        np.testing.assert_allclose(got[0].numpy(), g[key], rtol=1e-5, atol=1e-6)
+
+
+def test_vitruvian_transforms_against_reference():
+    from arah_release_amd import smpl
+    g = golden("f9_callers.npz")
+    got = smpl.get_transforms_02v(T(g["lbs_J"])).numpy()
+    np.testing.assert_allclose(got, g["v02_torch"], rtol=1e-6, atol=1e-6)      # lightning_model.py:37-99
+    np.testing.assert_allclose(got, g["v02_numpy"], rtol=1e-5, atol=1e-6)      # the dataset's numpy twin
+
+
+def test_rays_and_box_against_reference():
+    from arah_release_amd import data
+    g = golden("f9_callers.npz")
+    near, far, ok = data.near_far(T(g["nf_bounds"]), T(g["nf_ray_o"]).expand(512, 3), T(g["nf_ray_d"]))
+    np.testing.assert_array_equal(ok.numpy(), g["nf_ok"])
+    np.testing.assert_allclose(near.numpy(), g["nf_near"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(far.numpy(), g["nf_far"], rtol=1e-5, atol=1e-5)
+    R, uv = T(g["cam_R"]), T(g["cam_uv"])
+    rays = uv @ R
+    rays = rays / (rays.norm(dim=-1, keepdim=True) + 1e-12)
+    np.testing.assert_allclose(rays.numpy(), g["cam_rays"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose((-R.t() @ T([0.3, -0.1, 2.0])).numpy(), g["cam_loc"], rtol=1e-6, atol=1e-6)
+
+
+def _item(g, body):
+    from arah_release_amd import data
+    md = {k[3:]: g[k] for k in g.files if k.startswith("md.")}
+    cam = {k[4:]: g[k] for k in g.files if k.startswith("cam.")}
+    return data.frame_item(md, cam, body, 64, 64, frame_idx=5, data_idx=1)
+
+
+_KEEP = ("ray_dirs", "cam_loc", "pose", "bone_transforms", "trans", "coord_min", "coord_max", "center", "Jtrs", "rots",
+         "smpl_verts", "minimal_shape", "cam_rot", "cam_trans")
+
+
+def test_compose_inputs_dataset_branch_against_reference(body):
+    """Dataset-provided SMPL, eval: lightning_model.py:463-634 with train_smpl / train_cameras off."""
+    from arah_release_amd import config
+    g = golden("f9_callers.npz")
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=4)
+    lm.model.frames = []
+    item = _item(g, body)
+    inp = lm.compose_inputs(item, eval=True)
+    for k in _KEEP:
+        np.testing.assert_allclose(inp[k].numpy(), g["ciA." + k], rtol=1e-5, atol=1e-5, err_msg=k)
+    np.testing.assert_allclose(inp["pose_cond"]["rots_full"].numpy(), g["ciA.rots_full"], rtol=1e-5, atol=1e-6)
+    assert int(inp["pose_cond"]["latent_code_idx"]) == int(np.ravel(g["ciA.latent_code_idx"])[0]) == 3     # unseen frame: last code
+    assert int(inp["geo_latent_code_idx"]) == int(np.ravel(g["ciA.geo_latent_code_idx"])[0])
+    assert "image_mask" in inp and "ray_dirs_cam" in inp and "rgb_values" not in inp
+
+
+def test_compose_inputs_optimised_smpl_and_cameras_against_reference(body):
+    """train_smpl + train_cameras, training: the SMPL parameters and the camera extrinsics come from the model's own
+    nn.Parameters (forward_smpl -> LBS, Vitruvian transforms, re-normalisation; quaternion -> rays)."""
+    from arah_release_amd import config
+    g = golden("f9_callers.npz")
+
+    class DS:
+        cam_names = ["0"]
+        cameras = {"0": {"R": np.eye(3), "T": np.zeros(3)}}
+        data = []
+
+    cfg = config.builtin_config("zju313")
+    cfg["model"].update(train_smpl=False, train_cameras=False)
+    lm = config.get_model(cfg, mode="test", n_data_points=4)
+    m = lm.model
+    # the constructor path is exercised in test_train_smpl_construction; here the fixture's parameter values go in
+    from arah_release_amd import renderer
+    kw = dict(frames=[4, 5], betas=g["ciB.betas"], body_model=body, cam_rots=g["ciB.cam_rots"], cam_trans=g["ciB.cam_trans"],
+              n_data_points=4)
+    for key in ("root_orient", "pose_body", "pose_hand", "trans"):
+        kw[key] = [g["ciB.%s_%d" % (key, fr)] for fr in (4, 5)]
+    m2 = renderer.MetaAvatarRender(m.sdf_decoder, m.skinning_model, m.color_decoder, m.deviation_decoder, train_cameras=True,
+                                   train_smpl=True, train_latent_code=True, train_geo_latent_code=True, **kw)
+    lm.model = m2
+    item = _item(g, body)
+    item["inputs.novel_seq"] = None
+    item["inputs"] = T(g["ciB.rgb_values"])
+    inp = lm.compose_inputs(item, eval=False)
+    for k in _KEEP:
+        np.testing.assert_allclose(inp[k].detach().numpy(), g["ciB." + k], rtol=2e-5, atol=2e-5, err_msg=k)
+    np.testing.assert_allclose(inp["pose_cond"]["rots_full"].detach().numpy(), g["ciB.rots_full"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(inp["pose_cond"]["Jtrs_posed"].detach().numpy(), g["ciB.Jtrs_posed"], rtol=1e-5, atol=1e-5)
+    assert int(inp["pose_cond"]["latent_code_idx"]) == int(np.ravel(g["ciB.latent_code_idx"])[0]) == 1     # seen frame: its data index
+    # the inputs depend on the optimised parameters
+    inp["smpl_verts"].sum().backward()
+    assert m2.body_poses["pose_body_5"].grad is not None and m2.betas.grad is not None
+    assert m2.body_poses["pose_body_4"].grad is None
+
+
+def test_bound_mask_is_the_projected_box(body):
+    """Pixels of the projected box: every pixel whose ray hits the box is inside the mask (the mask is what the reference
+    then filters with near < far), and the mask is not much larger than that set."""
+    from arah_release_amd import data
+    g = golden("f9_callers.npz")
+    item = _item(g, body)
+    mask = item["inputs.image_mask"][0]
+    H, W = mask.shape
+    assert 0.05 < float(mask.float().mean()) < 0.9
+    n = item["inputs.ray_dirs"].shape[1]
+    assert int(mask.sum()) == n
+    nf = item["inputs.body_bounds_intersections"][0]
+    assert bool((nf[:, 0] < nf[:, 1]).all())
+    d = item["inputs.ray_dirs"][0]
+    np.testing.assert_allclose(d.norm(dim=-1).numpy(), 1.0, atol=1e-5)
+
+
+def test_on_disk_formats_round_trip(tmp_path, scene, body):
+    """cam_params.json / models/*.npz as preprocess_ZJU-MoCap.py:150-158 writes them."""
+    from arah_release_amd import data
+    sub = tmp_path / "CoreView_000"
+    (sub / "models").mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    for f in range(5):
+        np.savez(sub / "models" / ("%06d.npz" % f), minimal_shape=scene.verts_cano.astype(np.float16 if f == 0 else np.float32),
+                 betas=np.zeros((1, 10), np.float32), Jtr_posed=scene.joints, bone_transforms=np.tile(np.eye(4, dtype=np.float32), (24, 1, 1)),
+                 trans=np.array([0.1, 0, 3.0], np.float32), root_orient=rng.randn(3).astype(np.float32),
+                 pose_body=rng.randn(63).astype(np.float32), pose_hand=np.zeros(6, np.float32))
+    cams = {"all_cam_names": ["1", "7"], "1": {"K": np.eye(3).tolist(), "D": [0] * 5, "R": np.eye(3).tolist(), "T": [[0], [0], [1.0]]},
+            "7": {"K": np.eye(3).tolist(), "D": [0] * 5, "R": np.eye(3).tolist(), "T": [[0], [0], [2.0]]}}
+    (sub / "cam_params.json").write_text(json.dumps(cams))
+    cp = data.load_cam_params(str(sub / "cam_params.json"))
+    assert cp["all_cam_names"] == ["1", "7"] and cp["7"]["T"].shape == (3,) and cp["7"]["T"][2] == 2.0
+    frames, files = data.list_sequence(str(sub), start_frame=1, end_frame=5, sampling_rate=2)
+    assert frames == [1, 3] and [os.path.basename(f) for f in files] == ["000001.npz", "000003.npz"]
+    md = data.load_model_npz(str(sub / "models" / "000000.npz"))
+    assert md["minimal_shape"].dtype == np.float32 and md["pose_body"].shape == (63,)
+    np.savez(sub / "models" / "bad.npz", minimal_shape=np.zeros((10, 3)))
+    with pytest.raises(ValueError):
+        data.load_model_npz(str(sub / "models" / "bad.npz"))
+    bad = dict(cams)
+    del bad["7"]
+    (sub / "bad.json").write_text(json.dumps(bad))
+    with pytest.raises(ValueError):
+        data.load_cam_params(str(sub / "bad.json"))
+
+
+def test_train_smpl_construction_from_a_dataset(tmp_path, scene, body):
+    """get_model(cfg, dataset=..., mode='train') with train_smpl / train_cameras (config.py:166-224, models/__init__.py:
+    81-123): one ParameterDict entry per frame of the first camera, exact zeros nudged, quaternions from the cameras."""
+    from arah_release_amd import config
+    from scipy.spatial.transform import Rotation
+    sub = tmp_path / "s"
+    (sub / "models").mkdir(parents=True)
+    files = []
+    for f in range(3):
+        p = sub / "models" / ("%06d.npz" % f)
+        np.savez(p, minimal_shape=scene.verts_cano, betas=np.full((1, 10), 0.1, np.float32), Jtr_posed=scene.joints,
+                 bone_transforms=np.tile(np.eye(4, dtype=np.float32), (24, 1, 1)), trans=np.array([0, 0, 3.0 + f], np.float32),
+                 root_orient=np.zeros(3, np.float32), pose_body=np.full(63, 0.01 * f, np.float32), pose_hand=np.zeros(6, np.float32))
+        files.append(str(p))
+
+    class DS:
+        cam_names = ["a", "b"]
+        cameras = {"a": {"R": np.eye(3), "T": [[0.0], [0.0], [0.0]]},
+                   "b": {"R": Rotation.from_rotvec([0, 0.3, 0]).as_matrix(), "T": [[1.0], [0.0], [0.0]]}}
+        data = [{"cam_idx": c, "frame_idx": 10 + f, "data_idx": f, "model_file": files[f], "gender": "neutral"}
+                for c in range(2) for f in range(3)]
+
+    cfg = config.builtin_config("zju313")
+    cfg["model"].update(train_smpl=True, train_cameras=True)
+    lm = config.get_model(cfg, dataset=DS, mode="train", body_model=body)
+    m = lm.model
+    assert m.frames == [10, 11, 12] and m.latent.num_embeddings == 3
+    assert set(m.body_poses.keys()) == {"%s_%d" % (k, f) for k in ("root_orient", "pose_body", "pose_hand", "trans") for f in (10, 11, 12)}
+    assert float(m.body_poses["root_orient_10"].detach().abs().max()) == pytest.approx(1e-8)       # zero rotation got its nudge
+    assert float(m.body_poses["trans_12"][2]) == 5.0 and tuple(m.betas.shape) == (1, 10)
+    np.testing.assert_allclose(m.cam_rots[1].detach().numpy(), Rotation.from_rotvec([0, 0.3, 0]).as_quat(), atol=1e-6)
+    assert len(list(m.smpl_parameters())) == 13 and len(list(m.camera_parameters())) == 2
+    n_all = len(list(m.parameters()))
+    assert len(list(m.network_parameters())) == n_all - 3           # cam_rots, cam_trans, betas (as in the reference)
+    assert len(lm.configure_optimizers().param_groups) == 8
+    # without the files and without an injected body model the reference's file lookup fails loudly
+    with pytest.raises(FileNotFoundError):
+        config.get_model(cfg, dataset=DS, mode="train")
+    # val / test construction takes none of this
+    assert not config.get_model(cfg, mode="test", n_data_points=3).model.train_smpl
+
+
+def test_pretrained_initialisation_is_loaded_or_refused(tmp_path):
+    """metaavatar_render/config.py:18-84: mode 'train' loads cfg['model']['geometry_net'] / ['skinning_net2']."""
+    from arah_release_amd import config
+    cfg = config.builtin_config("zju377_mono")
+    ref = config.get_model(cfg, mode="test", n_data_points=2).model
+    geo = {"module.decoder." + k: torch.full_like(v, 0.25) for k, v in ref.sdf_decoder.state_dict().items()}
+    geo["module.encoder.something"] = torch.zeros(1)
+    skin = {"skinning_decoder_fwd." + k: torch.full_like(v, 0.5) for k, v in ref.skinning_model.skinning_decoder_fwd.state_dict().items()}
+    torch.save({"model": geo}, tmp_path / "geo.pt")
+    torch.save({"model": skin}, tmp_path / "skin.pt")
+    cfg["model"].update(geometry_net=str(tmp_path / "geo.pt"), skinning_net2=str(tmp_path / "skin.pt"))
+    m = config.get_model(cfg, mode="train", n_data_points=2).model
+    assert all(bool((v == 0.25).all()) for v in m.sdf_decoder.state_dict().values())
+    assert all(bool((v == 0.5).all()) for v in m.skinning_model.skinning_decoder_fwd.state_dict().values())
+    m_test = config.get_model(cfg, mode="test", n_data_points=2).model               # val / test: no initialisation
+    assert not all(bool((v == 0.25).all()) for v in m_test.sdf_decoder.state_dict().values())
+    cfg["model"]["geometry_net"] = str(tmp_path / "missing.pt")
+    with pytest.raises(FileNotFoundError):
+        config.get_model(cfg, mode="train", n_data_points=2)
+    torch.save({"model": {"decoder.unrelated": torch.zeros(1)}}, tmp_path / "empty.pt")
+    cfg["model"]["geometry_net"] = str(tmp_path / "empty.pt")
+    with pytest.raises(ValueError):
+        config.get_model(cfg, mode="train", n_data_points=2)
+
+
+@pytest.mark.gpu
+def test_dataset_item_renders_on_the_device(body):
+    """frame_item -> compose_inputs -> MetaAvatarRender.forward on cuda:0: the callers' side feeds the hot path without a
+    host copy of the frame (the item moves to the device once; everything after is device tensors)."""
+    from arah_release_amd import config
+    g = golden("f9_callers.npz")
+    dev = torch.device("cuda:0")
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=4).to(dev).eval()
+    lm.model.frames = []
+    item = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in _item(g, body).items()}
+    inp = lm.compose_inputs(item, eval=True)
+    assert inp["ray_dirs"].is_cuda and inp["bone_transforms"].is_cuda
+    with torch.no_grad():
+        out = lm.model(inp, gen_cano_mesh=False, eval=True)
+    n = inp["ray_dirs"].shape[1]
+    assert tuple(out["rgb_values"].shape) == (1, n, 3) and bool(torch.isfinite(out["rgb_values"]).all())
+    assert 0 < int(out["network_body_mask"].sum()) <= n
