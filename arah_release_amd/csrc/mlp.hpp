@@ -273,16 +273,30 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
 }
 
 // 4 consecutive channels of one point, already multiplied by kActScale -> hi/lo planes
+// hi = f16(h) (round to nearest even), lo = f16(h - hi).  The residual is one mixed-precision FMA per channel that
+// reads its f16 operand straight out of the packed hi register and writes the f16 result into its half of the packed
+// lo register (v_fma_mixlo_f16 / v_fma_mixhi_f16: h * 1.0 - hi, exact in fp32, one rounding to f16): three VALU
+// operations per pair of channels, against seven for convert / convert back / subtract / convert.  Same bits.
+__device__ __forceinline__ unsigned split_residual2(float a, float b, unsigned hi_pk) {
+    unsigned lo_pk;
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo_pk) : "v"(a), "v"(hi_pk));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo_pk) : "v"(b), "v"(hi_pk));
+    return lo_pk;
+}
 __device__ __forceinline__ void store_split4(float* act, int ld, int lo_off, int pt, int ch0, const f32x4 hs) {
-    f16x4 hi, lo;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hi, lo;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        hi[r] = (_Float16)hs[r];
-        lo[r] = (_Float16)(hs[r] - (float)hi[r]);
+    for (int p = 0; p < 2; ++p) {
+        const f16x2 h2 = __builtin_convertvector(f32x2{hs[2 * p], hs[2 * p + 1]}, f16x2);
+        hi[p] = __builtin_bit_cast(unsigned, h2);
+        lo[p] = split_residual2(hs[2 * p], hs[2 * p + 1], hi[p]);
     }
     char* row = reinterpret_cast<char*>(act) + pt * ld * 4;
-    *reinterpret_cast<f16x4*>(row + ch0 * 2) = hi;
-    *reinterpret_cast<f16x4*>(row + lo_off + ch0 * 2) = lo;
+    *reinterpret_cast<u32x2*>(row + ch0 * 2) = hi;
+    *reinterpret_cast<u32x2*>(row + lo_off + ch0 * 2) = lo;
 }
 
 __device__ __forceinline__ float load_split(const float* act, int ld, int lo_off, int pt, int ch) {
