@@ -618,10 +618,6 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_clusters(const GridInfo* 
     }
 }
 
-struct CanonSeed {   // loop C's start state of one sample: {x0(3), id | T0 row-major} (see k_canon_solve)
-    f32x4 r[5];
-};
-
 struct KnnData {
     const float* sorted4;          // [kMaxVerts][4]  (x, y, z, original index)
     const float* spheres;          // [kMaxClusters][4]
@@ -658,24 +654,21 @@ __device__ __forceinline__ bool sphere_may_hold_nn(const f32x4 s, V3 p, float be
 // blend the nearest vertex's weights, invert, write the outputs of one query
 template <int SRC>
 __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const BodyConst& bc, const float* sb, int i, int id, V3 p, int bi,
-                                               int* idx_out, float* x_out, float* T_out, CanonSeed* rec_out) {
+                                               int* idx_out, float* x_out, float* T_out, int as_seed) {
     float T[16];
     blend(fr.vert_weights + (size_t)bi * 24, sb, T);
     V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
     V3 xh = inverse_affine_apply(T, y);
     if (SRC == SRC_RAYS) xh = normalize_pt(bc, xh);
     if (idx_out) idx_out[id] = bi;
-    if (SRC == SRC_SAMPLES && rec_out) {   // loop C starts from here: the seed IS the initial state
-        CanonSeed* r = rec_out + i;
-        r->r[0] = f32x4{xh.x, xh.y, xh.z, __int_as_float(id)};
-#pragma unroll
-        for (int c = 0; c < 3; ++c) r->r[1 + c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
-        r->r[4] = f32x4{y.x, y.y, y.z, T[15]};   // the target p - trans rides in the (exactly zero) T[3][0..2]
-        return;
-    }
     x_out[(size_t)id * 3 + 0] = xh.x;
     x_out[(size_t)id * 3 + 1] = xh.y;
     x_out[(size_t)id * 3 + 2] = xh.z;
+    if (SRC == SRC_SAMPLES && as_seed) {   // loop C starts from here: the target p - trans rides in the (exactly zero)
+        T[12] = y.x;                       // T[3][0..2] of the start transform, k_canon_solve takes it from there
+        T[13] = y.y;
+        T[14] = y.z;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c)
         reinterpret_cast<f32x4*>(T_out + (size_t)id * 16)[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
@@ -686,7 +679,7 @@ __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const BodyCon
 template <int SRC, int STRIDE>
 __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const BodyConst& bc, const KnnData& kd, const GridInfo& g,
                                                      const float* sv, const float* ssph, const float* sb, int i, int id,
-                                                     V3 p, int* idx_out, float* x_out, float* T_out, CanonSeed* rec_out) {
+                                                     V3 p, int* idx_out, float* x_out, float* T_out, int as_seed) {
     float best = 3.4e38f;
     int bi = 0x7fffffff;
     if (SRC == SRC_RAYS && idx_out) {   // sphere tracing: the previous step's nearest vertex bounds the search
@@ -746,7 +739,7 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const B
             if (sphere_may_hold_nn(reinterpret_cast<const f32x4*>(ssph)[c], p, fminf(best, cap)))
                 scan_cluster<STRIDE>(sv, c, p, best, bi);
     }
-    nearest_finish<SRC>(fr, bc, sb, i, id, p, bi, idx_out, x_out, T_out, rec_out);
+    nearest_finish<SRC>(fr, bc, sb, i, id, p, bi, idx_out, x_out, T_out, as_seed);
 }
 
 // (d2, index) minimum over the wave, lowest index on ties
@@ -846,7 +839,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
                                                                    const float* depth, int n_steps, const int* list,
                                                                    const int* count, int n_direct, int wave_below,
                                                                    int* idx_out, float* x_out, float* T_out,
-                                                                   CanonSeed* rec_out, unsigned long long* ctr) {
+                                                                   int as_seed, unsigned long long* ctr) {
     const BodyConst bc = load_bc(fr);
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
     if (n >= wave_below) return;
@@ -869,7 +862,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
             }
         }
         bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
-        if (lane == 0) nearest_finish<SRC>(fr, bc, fr.bones, i, id, p, bi, idx_out, x_out, T_out, rec_out);
+        if (lane == 0) nearest_finish<SRC>(fr, bc, fr.bones, i, id, p, bi, idx_out, x_out, T_out, as_seed);
     }
 }
 
@@ -878,7 +871,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
                                                                  const float* depth, int n_steps, const int* list,
                                                                  const int* count, int n_direct, int wave_below,
                                                                  int* idx_out, float* x_out, float* T_out,
-                                                                 CanonSeed* rec_out, unsigned long long* ctr) {
+                                                                 int as_seed, unsigned long long* ctr) {
     const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n = (SRC == SRC_POINTS) ? n_direct : *count;
@@ -907,7 +900,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         for (int i = blockIdx.x * per + t; i < end; i += blockDim.x) {
             int id;
             const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
-            nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
+            nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, as_seed);
         }
         return;
     }
@@ -917,7 +910,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         if (i >= n) continue;
         int id;
         const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
-        nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, rec_out);
+        nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, as_seed);
     }
 }
 
@@ -1363,7 +1356,7 @@ constexpr size_t kLdsCanonSolve =
     (64 * 4 + 64 * kLogitLd + 24 * 16 + 16 + 64 * ST_SIZE + 64 * 16) * 4 + (size_t)64 * kSkinLd * 4;
 
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const f32x4* __restrict__ seeds,
+__global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const int* __restrict__ list,
                                                              const int* count, int* queue_head, CanonOut outp,
                                                              unsigned long long* ctr, unsigned long long* clk_out) {
     const BodyConst bc = load_bc(fr);
@@ -1419,13 +1412,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
                 given += take;
                 need -= take;
             }
-            if (src >= 0) {
-                const f32x4 s0 = seeds[(size_t)src * 5];
-                const f32x4 s4 = seeds[(size_t)src * 5 + 4];   // {target, T0[3][3]}
-                f32x4 t0 = seeds[(size_t)src * 5 + 1 + g];
-                if (g == 3) t0 = f32x4{0.f, 0.f, 0.f, s4[3]};
+            if (src >= 0) {   // the start state sits where the result will go: x0 in pts[id], T0 (+ target in row 3) in T[id]
+                id = list[src];
+                f32x4 t0 = reinterpret_cast<const f32x4*>(outp.T + (size_t)id * 16)[g];
+                f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s4 = {0.f, 0.f, 0.f, 0.f};
+                if (g == 0) s0 = f32x4{outp.pts[(size_t)id * 3], outp.pts[(size_t)id * 3 + 1], outp.pts[(size_t)id * 3 + 2], 0.f};
+                if (g == 3) {
+                    s4 = t0;                                   // {target, T0[3][3]}
+                    t0 = f32x4{0.f, 0.f, 0.f, t0[3]};
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) s4[r] = __shfl(s4[r], j + 48);   // lane g == 0 files the target
                 *tb = t0;                                      // T0 doubles as the initial best T (broyden.py:41)
-                id = __float_as_int(s0[3]);
                 if (g == 0) {
                     const V3 tg = V3{s4[0], s4[1], s4[2]};
 #pragma unroll
@@ -1570,16 +1568,13 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
 #endif
 }
 
-// seeds from (x0, T0) stored densely by id and explicit targets
-__global__ void k_canon_seed(const int* list, const int* count, const float* x0, const float* T0, const float* tgt,
-                             f32x4* seeds) {
+// explicit targets (arah_broyden3_lbs): file them where k_canon_solve expects them, in row 3 of the start transform
+__global__ void k_canon_seed(const int* list, const int* count, const float* tgt, float* T0) {
     const int n = *count;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int id = list[i];
-        seeds[(size_t)i * 5] = f32x4{x0[(size_t)id * 3], x0[(size_t)id * 3 + 1], x0[(size_t)id * 3 + 2], __int_as_float(id)};
 #pragma unroll
-        for (int c = 0; c < 3; ++c) seeds[(size_t)i * 5 + 1 + c] = reinterpret_cast<const f32x4*>(T0 + (size_t)id * 16)[c];
-        seeds[(size_t)i * 5 + 4] = f32x4{tgt[(size_t)id * 3], tgt[(size_t)id * 3 + 1], tgt[(size_t)id * 3 + 2], T0[(size_t)id * 16 + 15]};
+        for (int c = 0; c < 3; ++c) T0[(size_t)id * 16 + 12 + c] = tgt[(size_t)id * 3 + c];
     }
 }
 
@@ -2302,7 +2297,6 @@ struct Workspace {
     uint8_t* o_conv;
     // per sample
     float* q_err;
-    CanonSeed* seeds;     // [Q] start states of loop C, in list order
     float *o_z, *o_pts, *o_T;
     uint8_t* o_mask;
     uint8_t* q_smask;
@@ -2344,7 +2338,6 @@ Workspace carve(void* base, int n_rays, int n_steps) {
     w.listA = c.take<int>(Q);
     w.listB = c.take<int>(Q);
     w.q_err = c.take<float>(Q);
-    w.seeds = c.take<CanonSeed>(Q);
     w.o_z = c.take<float>(Q);
     w.o_pts = c.take<float>(Q * 3);
     w.o_T = c.take<float>(Q * 16);
@@ -2470,7 +2463,7 @@ KnnData knn_of(const FrameDev& fd) {
 template <int SRC>
 void launch_nearest(hipStream_t s, const FrameDev& fd, long long n_max, const float* pts, const RaySet& rs,
                     const float* depth, int n_steps, const int* list, const int* count, int n_direct, int* idx_out,
-                    float* x_out, float* T_out, CanonSeed* rec_out, unsigned long long* ctr) {
+                    float* x_out, float* T_out, int as_seed, unsigned long long* ctr) {
     // list lengths below which one wave per query beats one thread per query (measured)
     // 512x512 frame: sphere-tracing lists (<= 1.5e5 rays, shrinking) 68.0 -> 65.4 ms per frame with the wave kernel below
     // 16k..64k entries; the 8.6e6-sample list of loop C wants the LDS table (86 ms when forced onto the wave kernel)
@@ -2482,12 +2475,12 @@ void launch_nearest(hipStream_t s, const FrameDev& fd, long long n_max, const fl
     if (gw < 1) gw = 1;
     if (n_max >= 0 && (SRC != SRC_POINTS || n_direct < wave_below))
         hipLaunchKernelGGL(k_nearest_wave<SRC>, dim3((int)gw), dim3(kKnnWaveThreads), 0, s, fd, knn_of(fd), pts, rs, depth,
-                           n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out, rec_out, ctr);
+                           n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out, as_seed, ctr);
     if (SRC != SRC_POINTS || n_direct >= wave_below)
         hipLaunchKernelGGL(k_nearest_invlbs<SRC>, dim3(SRC == SRC_SAMPLES ? grid_for(n_max, kKnnThreads) : min(256, grid_for(n_max, 64))),
                            dim3(kKnnThreads), kLdsKnn, s, fd,
                            knn_of(fd), pts, rs, depth, n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out,
-                           rec_out, ctr);
+                           as_seed, ctr);
 }
 
 RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
@@ -2932,23 +2925,22 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
     if (int arc = setup_attributes()) return arc;
     RaySet rs = make_rays(nullptr, nullptr, 1);
     launch_nearest<SRC_POINTS>(reinterpret_cast<hipStream_t>(stream), to_dev(*f), n, pts, rs, (const float*)nullptr, 1,
-                               (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, (CanonSeed*)nullptr,
+                               (const int*)nullptr, (const int*)nullptr, n, idx, x_hat0, T0, 0,
                                &w.ctr->n_knn);
     return check_launch();
 }
 
-// shared driver of loop C.  tgt == NULL: w.seeds[0 .. cnt[0]) are already written (k_nearest_invlbs<SAMPLES>); otherwise
-// (x0, T0) are stored densely by id in out.pts / out.T and the targets in tgt for every id in listA.  w.counts: [0] = number of seeds,
-// [1] = head of the seed queue (zeroed by the caller's memset of w.counts).
+// shared driver of loop C.  The start states of the ids in w.listA[0 .. cnt[0]) sit in outp.pts (x0) and outp.T (T0, with
+// the target in row 3 -- written there by k_nearest_invlbs<SAMPLES>, or here from tgt); the results replace them.
+// w.counts: [0] = number of entries, [1] = head of the queue (zeroed by the caller's memset of w.counts).
 static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, CanonOut outp, long long max_pts,
                         hipStream_t s) {
     int* cnt = w.counts;
     if (tgt)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
-                           (const int*)&cnt[0], (const float*)outp.pts, (const float*)outp.T, tgt,
-                           reinterpret_cast<f32x4*>(w.seeds));
+                           (const int*)&cnt[0], tgt, outp.T);
     LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
-                  kLdsCanonSolve, s, fd, reinterpret_cast<const f32x4*>(w.seeds), (const int*)&cnt[0], &cnt[1], outp,
+                  kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
                   &w.ctr->n_skin_fwd, w.ctr->clk);
     return check_launch();
 }
@@ -3022,7 +3014,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
         launch_nearest<SRC_RAYS>(s, fd, n, (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin,
-                                 (const int*)&cntA[it], 0, w.nn_idx, w.xcur, w.Tcur, (CanonSeed*)nullptr, &w.ctr->n_knn);
+                                 (const int*)&cntA[it], 0, w.nn_idx, w.xcur, w.Tcur, 0, &w.ctr->n_knn);
         LAUNCH_ENGINE(fd.split, k_sdf_march<true>, k_sdf_march<false>, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts,
                       (const int*)lin, (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
     }
@@ -3087,7 +3079,7 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     hipLaunchKernelGGL(k_build_list, dim3((int)((Q + 4095) / 4096)), dim3(1024), 0, s, (const uint8_t*)w.q_smask, (int)Q, w.listA, &w.counts[0]);
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
     launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA,
-                                (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, w.seeds, &w.ctr->n_knn);
+                                (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, 1, &w.ctr->n_knn);
     int rc = run_broyden3(fd, w, nullptr, CanonOut{pts, T, w.q_err}, Q, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_canon_finalize, dim3(gq), dim3(256), 0, s, fd, (int)Q, (const uint8_t*)w.q_smask,

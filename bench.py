@@ -157,6 +157,9 @@ def main():
         dist.destroy_process_group()
 
 
+WORKLOAD_NAMES = {"zju377_mono": "ZJUMOCAP-377-mono", "zju313": "ZJUMOCAP-313", "h36m": "H36M-S9 (idr colour mode)"}
+
+
 class GpuRuntime:
     """What run() needs from the machine: the model, the scene, device synchronisation, events around the dominant
     kernel.  tests/test_bench_sharding.py drives the same run() on two gloo ranks with a stub of this class."""
@@ -314,7 +317,7 @@ def run(args, rt):
             "dtype": "f32 (operands as hi+lo f16 pairs on the f16 MFMA pipe, fp32 accumulate)" if split else "f32",
             "data": "synthetic",
             "precision": engine,
-            "config": {"workload": "ZJUMOCAP-377-mono test.py inference, %dx%d, %d samples/ray (near %d / far %d), "
+            "config": {"workload": WORKLOAD_NAMES.get(args.config, args.config) + " test.py inference, %dx%d, %d samples/ray (near %d / far %d), "
                                    "synthetic capsule body + fitted SIREN, one frame per step" %
                                    (args.size, args.size, args.n_steps, near, far),
                        "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
