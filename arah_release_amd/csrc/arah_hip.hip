@@ -3235,6 +3235,38 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
     return check_launch();
 }
 
+// ---- skinny weight-gradient products of the training step -------------------------------------------------------
+// out[i][j] = sum_p a[p][i] b[p][j] with m <= 4 rows (the 1 x 256 SDF head, the 3 x 256 colour head, the 256 x 3 first
+// SIREN layer transposed): one pass over b at HBM speed.  A workgroup reduces kGramRows rows into partial[block][m][n];
+// the caller adds the partials up (fixed order: the result is deterministic).
+constexpr int kGramRows = 256;
+__global__ __launch_bounds__(256) void k_gram_skinny(const float* __restrict__ a, int lda, int m,
+                                                     const float* __restrict__ b, int ldb, int n, int P,
+                                                     float* __restrict__ partial) {
+    const int r0 = blockIdx.x * kGramRows, r1 = min(r0 + kGramRows, P);
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int p = r0; p < r1; ++p) {
+            const float bj = b[(size_t)p * ldb + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < m) acc[i] = fmaf(a[(size_t)p * lda + i], bj, acc[i]);
+        }
+        for (int i = 0; i < m; ++i) partial[((size_t)blockIdx.x * m + i) * n + j] = acc[i];
+    }
+}
+
+int32_t arah_gram_skinny_blocks(int32_t n_rows) { return n_rows > 0 ? (n_rows + kGramRows - 1) / kGramRows : 0; }
+
+int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int32_t ldb, int32_t n, int32_t n_rows,
+                     float* partial, void* stream) {
+    if (!a || !b || !partial || m < 1 || m > 4 || n < 1 || lda < m || ldb < n || n_rows < 0) return ARAH_E_BADARG;
+    if (n_rows == 0) return ARAH_OK;
+    hipLaunchKernelGGL(k_gram_skinny, dim3(arah_gram_skinny_blocks(n_rows)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), a, lda, m, b, ldb, n, n_rows, partial);
+    return check_launch();
+}
+
 // ---- whole eval forward -------------------------------------------------------------------------
 int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_loc, int32_t rays_per_cam,
                 const float* dirs, const float* near_far, const float* d_pose34, int32_t n, float* rgb,

@@ -92,7 +92,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "ar
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_dominant_kernel", "arah_set_shade_events",
+           "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events"]
 
 _lib = None
@@ -593,6 +593,25 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
                                          C.c_size_t(ws.train_slab.numel()), _ptr(buf), C.c_size_t(buf.numel()),
                                          _stream()), "arah_shade_train_backward")
     return st
+
+
+def gram_skinny(a, b):
+    """a^T b for a (P, m <= 4) and b (P, n), row strides free (column slices of wider streams are fine): (m, n)."""
+    lib = load_library()
+    dev = _same_device(a, b)
+    if a.dtype != torch.float32 or b.dtype != torch.float32 or a.stride(1) != 1 or b.stride(1) != 1:
+        raise ValueError("float32 operands with unit column stride required")
+    P, m = a.shape
+    n = b.shape[1]
+    if P == 0:
+        return torch.zeros(m, n, device=dev)
+    with _on_device(dev):
+        blocks = lib.arah_gram_skinny_blocks(C.c_int32(P))
+        partial = torch.empty(blocks, m, n, device=dev)
+        _check(lib.arah_gram_skinny(C.c_void_p(a.data_ptr()), C.c_int32(a.stride(0)), C.c_int32(m),
+                                    C.c_void_p(b.data_ptr()), C.c_int32(b.stride(0)),
+                                    C.c_int32(n), C.c_int32(P), _ptr(partial), _stream()), "arah_gram_skinny")
+    return partial.sum(0)
 
 
 def set_shade_events(start=None, stop=None):

@@ -20,6 +20,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .tall import gram, mv3
+
 
 # ------------------------------------------------------------------------------------------------
 # canonical-space helpers (root_finding_utils.py:13-113)
@@ -73,8 +75,8 @@ def query_weights(x_hat, coord_min, coord_max, center, skinning_model):
 def forward_skinning(x_hat, coord_min, coord_max, center, skinning_model, bone_transforms):
     """x_bar = (sum_j w_j A_j) [x_hat; 1] (root_finding_utils.py:147-167, 13-34)."""
     w = query_weights(x_hat, coord_min, coord_max, center, skinning_model)
-    T = torch.einsum("bpn,bnij->bpij", w, bone_transforms)
-    x_bar = torch.einsum("bpij,bpj->bpi", T[..., :3, :3], x_hat) + T[..., :3, 3]
+    T = torch.matmul(w, bone_transforms.reshape(bone_transforms.shape[0], 24, 16)).reshape(*w.shape[:2], 4, 4)
+    x_bar = mv3(T[..., :3, :3], x_hat) + T[..., :3, 3]
     return x_bar, T
 
 
@@ -121,10 +123,10 @@ class ShadeSamples(torch.autograd.Function):
         # ---- SIREN: dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1}
         for k in range(6):
             n_in = sdf_w[k].shape[-1]
-            grads.append((st["av"][k].t() @ st["h"][k][:, :n_in] + st["avd"][k].t() @ st["hd"][k][:, :n_in])
+            grads.append((gram(st["av"][k], st["h"][k][:, :n_in]) + gram(st["avd"][k], st["hd"][k][:, :n_in]))
                          .reshape(sdf_w[k].shape))
         feat = st["cin"][:, :256]
-        grads.append((g_sdf.reshape(1, -1) @ feat + st["hd"][6].sum(0, keepdim=True)).reshape(sdf_w[6].shape))
+        grads.append((gram(g_sdf.reshape(-1, 1), feat) + st["hd"][6].sum(0, keepdim=True)).reshape(sdf_w[6].shape))
         for k in range(6):
             grads.append(st["av"][k].sum(0).reshape(sdf_b[k].shape))
         grads.append(g_sdf.sum().reshape(sdf_b[6].shape))
@@ -144,14 +146,14 @@ class ShadeSamples(torch.autograd.Function):
             return parts
 
         s0, s3 = d[0].sum(0), d[3].sum(0)
-        m0 = to_reference_columns(d[0].t() @ cin)
-        m3 = to_reference_columns(d[3].t() @ cin)
+        m0 = to_reference_columns(gram(d[0], cin))
+        m3 = to_reference_columns(gram(d[3], cin))
         if n_pose:
             m0.append(torch.outer(s0, pose.reshape(-1)))
             m3.append(torch.outer(s3, pose.reshape(-1)))
-        m3.append(d[3].t() @ c[2])
-        gw = [torch.cat(m0, dim=1), d[1].t() @ c[0], d[2].t() @ c[1], torch.cat(m3, dim=1), d[4].t() @ c[3],
-              d[5][:, :3].t() @ c[4]]
+        m3.append(gram(d[3], c[2]))
+        gw = [torch.cat(m0, dim=1), gram(d[1], c[0]), gram(d[2], c[1]), torch.cat(m3, dim=1), gram(d[4], c[3]),
+              gram(d[5][:, :3], c[4])]
         gb = [s0, d[1].sum(0), d[2].sum(0), s3, d[4].sum(0), d[5][:, :3].sum(0)]
         grads += [g.reshape(w.shape) for g, w in zip(gw, col_w)]
         grads += [g.reshape(b.shape) for g, b in zip(gb, col_b)]
@@ -199,8 +201,8 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
     vd0 = view_dirs_orig[:, None, :].expand(n_rays, S, 3)[converge_mask]
     if idhr.cano_view_dirs:
         Rb = torch.linalg.inv(Tf).detach()[:, :3, :3]
-        vin = torch.einsum("pij,pj->pi", Rb, -vd)
-        vin0 = torch.einsum("pij,pj->pi", Rb, -vd0)
+        vin = mv3(Rb, -vd)
+        vin0 = mv3(Rb, -vd0)
     else:
         vin, vin0 = -vd, -vd0
     sdf_all, rgb_all = [], []
@@ -221,14 +223,14 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
                 span = (coord_max.reshape(-1)[0] - coord_min.reshape(-1)[0]) * 1.1 / 2.0     # d x_hat / d pi
                 J = hip.skin_jacobian(frame, ws, x_hat[0]) * span
                 Jinv = torch.linalg.inv(J).unsqueeze(0)
-                pi = pd - torch.matmul(Jinv, (x_lbs - x_lbs.detach()).unsqueeze(-1)).squeeze(-1)
+                pi = pd - mv3(Jinv, x_lbs - x_lbs.detach())
             elif idhr.train_skinning_net:
                 # x_hat is a root of LBS(x_hat) = x_bar found without a graph; re-attach it with the implicit
                 # function theorem: d x_hat = -J^-1 d LBS  (IDR:315-334)
                 x_hat = unnormalize_canonical_points(pi, coord_min, coord_max, center)
                 x_lbs, _ = forward_skinning(x_hat, coord_min, coord_max, center, idhr.skinning_model, bone_transforms)
                 Jinv = torch.linalg.inv(input_jacobian(x_lbs, pi)).detach()
-                pi = pi - torch.matmul(Jinv, (x_lbs - x_lbs.detach()).unsqueeze(-1)).squeeze(-1)
+                pi = pi - mv3(Jinv, x_lbs - x_lbs.detach())
             if frame is not None:
                 sdf, rgb = shade_samples_hip(idhr, frame, ws, sdf_network, pi.squeeze(0), Ti, vi, vi0, pose_cond, ray_augm)
                 sdf_all.append(sdf / 2.0 * 1.1 * (coord_max.squeeze() - coord_min.squeeze()))
@@ -238,7 +240,7 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
             sdf = sdf_network[-1](feat)
             normal = torch.autograd.grad(sdf, pi, torch.ones_like(sdf), create_graph=True, retain_graph=True)[0]
             if not idhr.cano_view_dirs:
-                normal = torch.einsum("pij,bpj->bpi", Ti[:, :3, :3], normal)
+                normal = mv3(Ti[:, :3, :3].unsqueeze(0), normal)
             if ray_augm:
                 with torch.no_grad():   # keep the un-rotated view where the augmented one looks at the back face
                     nn_ = normal / torch.linalg.norm(normal, dim=-1, keepdim=True)

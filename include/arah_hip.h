@@ -265,6 +265,13 @@ int arah_shade_train_forward(const ArahFrame* h_frame, const ArahTrainIn* h_in, 
 int arah_shade_train_backward(const ArahFrame* h_frame, const ArahTrainIn* h_in, const ArahTrainGrads* h_out,
                               void* slab, size_t slab_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Skinny weight-gradient product of the training step: partial[blk][i][j] = sum over the block's rows p of
+ * a[p*lda + i] * b[p*ldb + j], i < m <= 4, j < n; blk < arah_gram_skinny_blocks(n_rows).  The caller sums over blk.
+ * (The reference leaves these to autograd's matmul backward: IDR:336-361 through torch.autograd.) */
+int32_t arah_gram_skinny_blocks(int32_t n_rows);
+int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int32_t ldb, int32_t n, int32_t n_rows,
+                     float* partial, void* stream);
+
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* rays: cam_loc [n_cams,3], ray r belongs to camera r / rays_per_cam; dirs [N,3]; near_far [N,2].
  * root_find_all: 0 = joint root find on the non-diverged rays (eval), 1 = on every ray (training, RT:249).

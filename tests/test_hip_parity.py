@@ -730,3 +730,28 @@ def test_shade_samples_op_against_autograd(scene, name, ray_augm):
         a, b = a.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64)
         scale = np.abs(b).max() + 1e-12
         assert np.abs(a - b).max() <= 2e-3 * scale, (nm, np.abs(a - b).max(), scale)
+
+
+@gpu
+def test_gram_skinny_and_split_k_gram():
+    """Weight-gradient products of the training step: the one-pass skinny kernel and the batched split-K product
+    against a float64 matmul (column slices of wider streams, ragged row counts)."""
+    from arah_release_amd import hip, tall
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for P in (1, 255, 256, 257, 100003):
+        wide = torch.randn(P, 8, generator=g).to(dev)
+        b = torch.randn(P, 304, generator=g).to(dev)
+        for m, n in ((1, 256), (3, 256), (4, 289)):
+            got = hip.gram_skinny(wide[:, :m], b[:, :n])
+            ref = (wide[:, :m].double().t() @ b[:, :n].double())
+            assert float((got.double() - ref).abs().max()) <= 2e-4 * max(1.0, float(ref.abs().max()))
+    a = torch.randn(100003, 256, generator=g).to(dev)
+    b = torch.randn(100003, 304, generator=g).to(dev)
+    for aa, bb in ((a, b[:, :289]), (a, b[:, :3]), (a[:, :1], b[:, :256]), (a[:500], b[:500])):
+        got = tall.gram(aa, bb)
+        ref = aa.double().t() @ bb.double()
+        assert got.shape == ref.shape
+        assert float((got.double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+    with pytest.raises(ValueError):
+        hip.gram_skinny(a[:, ::2][:, :3], b)
