@@ -119,7 +119,7 @@ FrameDev to_dev(const ArahFrame& f) {
 }
 
 struct Counters {
-    unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, r0, r1;
+    unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, n_density, n_canon;
     unsigned long long clk[8 * 16];   // instrumented builds (-DARAH_CLOCKS): s_memtime ticks per wave slot and phase
 };
 #ifdef ARAH_CLOCKS
@@ -1358,7 +1358,8 @@ constexpr size_t kLdsCanonSolve =
 template <bool SPLIT>
 __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const int* __restrict__ list,
                                                              const int* count, int* queue_head, CanonOut outp,
-                                                             unsigned long long* ctr, unsigned long long* clk_out) {
+                                                             unsigned long long* ctr, unsigned long long* ctr_canon,
+                                                             unsigned long long* clk_out) {
     const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     KernelClk clk;
@@ -1561,7 +1562,10 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
         __syncthreads();   // logits rows / alive flags are rewritten by the next pass
         clk.mark(11);
     }
-    if (owner && lane == 0) count_add(ctr, n_eval);
+    if (owner && lane == 0) {
+        count_add(ctr, n_eval);
+        count_add(ctr_canon, n_eval);
+    }
 #ifdef ARAH_CLOCKS
     if (lane == 0)
         for (int i = 0; i < 16; ++i) atomicAdd(&clk_out[wave * 16 + i], (unsigned long long)clk.acc[i]);
@@ -2454,6 +2458,7 @@ int setup_attributes() {
 
 // optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
 hipEvent_t g_shade_ev0 = nullptr, g_shade_ev1 = nullptr, g_density_ev0 = nullptr, g_density_ev1 = nullptr;
+hipEvent_t g_canon_ev0 = nullptr, g_canon_ev1 = nullptr;
 
 KnnData knn_of(const FrameDev& fd) {
     return KnnData{fd.knn.sorted4, fd.knn.spheres, reinterpret_cast<const GridInfo*>(fd.knn.grid), fd.knn.cells};
@@ -2580,7 +2585,7 @@ ColSegs one_seg(int len) {
 // =============================================================================================
 extern "C" {
 
-const char* arah_dominant_kernel(void) { return "k_density"; }   // largest single launch of the default path
+const char* arah_dominant_kernel(void) { return "k_canon_solve"; }   // largest single launch of the default path (loop C)
 
 int arah_set_shade_events(void* start_event, void* stop_event) {
     g_shade_ev0 = reinterpret_cast<hipEvent_t>(start_event);
@@ -2591,6 +2596,12 @@ int arah_set_shade_events(void* start_event, void* stop_event) {
 int arah_set_density_events(void* start_event, void* stop_event) {
     g_density_ev0 = reinterpret_cast<hipEvent_t>(start_event);
     g_density_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
+    return ARAH_OK;
+}
+
+int arah_set_canon_events(void* start_event, void* stop_event) {
+    g_canon_ev0 = reinterpret_cast<hipEvent_t>(start_event);
+    g_canon_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
     return ARAH_OK;
 }
 
@@ -2939,9 +2950,11 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
     if (tgt)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
                            (const int*)&cnt[0], tgt, outp.T);
+    if (g_canon_ev0) hipEventRecord(g_canon_ev0, s);
     LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
                   kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
-                  &w.ctr->n_skin_fwd, w.ctr->clk);
+                  &w.ctr->n_skin_fwd, &w.ctr->n_canon, w.ctr->clk);
+    if (g_canon_ev1) hipEventRecord(g_canon_ev1, s);
     return check_launch();
 }
 
@@ -3130,7 +3143,7 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
         if (g_density_ev0) hipEventRecord(g_density_ev0, s);
         LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
                       (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd,
-                      &w.ctr->r0);
+                      &w.ctr->n_density);
         if (g_density_ev1) hipEventRecord(g_density_ev1, s);
         slist = w.listB;
         scount = &w.counts[1];

@@ -83,7 +83,7 @@ class ArahTrainGrads(C.Structure):
 class ArahCounters(C.Structure):
     _fields_ = [("n_sdf_fwd", C.c_uint64), ("n_sdf_grad", C.c_uint64), ("n_skin_fwd", C.c_uint64),
                 ("n_skin_jac", C.c_uint64), ("n_col", C.c_uint64), ("n_knn", C.c_uint64),
-                ("n_density", C.c_uint64), ("reserved", C.c_uint64)]
+                ("n_density", C.c_uint64), ("n_canon", C.c_uint64)]
 
 
 COUNTER_BYTES = C.sizeof(ArahCounters)
@@ -93,7 +93,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "ar
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
            "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_dominant_kernel", "arah_set_shade_events",
-           "arah_set_density_events"]
+           "arah_set_density_events", "arah_set_canon_events"]
 
 _lib = None
 
@@ -240,7 +240,7 @@ class Workspace:
             _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream(self.device)),
                    "arah_counters_read")
         return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn",
-                                                   "n_density")}
+                                                   "n_density", "n_canon")}
 
 
 class Frame:
@@ -623,6 +623,16 @@ def set_shade_events(start=None, stop=None):
     a = C.c_void_p(start.cuda_event) if start is not None else None
     b = C.c_void_p(stop.cuda_event) if stop is not None else None
     _check(lib.arah_set_shade_events(a, b), "arah_set_shade_events")
+
+
+def set_canon_events(start=None, stop=None):
+    lib = load_library()
+    for ev in (start, stop):
+        if ev is not None:
+            ev.record()
+    a = C.c_void_p(start.cuda_event) if start is not None else None
+    b = C.c_void_p(stop.cuda_event) if stop is not None else None
+    _check(lib.arah_set_canon_events(a, b), "arah_set_canon_events")
 
 
 def set_density_events(start=None, stop=None):

@@ -11,11 +11,14 @@ i -> rank i mod N): no data-path collective, weak scaling, value = al
 / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      largest single launch of the default path (k_density: the SDF MLP forward on every valid sample):
-                algorithmic MFMA flops per launch / HIP-event duration.  Peak: the default GEMM engine carries each
-                fp32 operand as two f16 and spends three v_mfma_f32_16x16x32_f16 per product, so its ceiling in
-                algorithmic fp32 flops is the dense f16 MFMA peak / 3 = 833 TFLOP/s; the exact engine
-                (ARAH_PRECISION=fp32) is priced against the fp32 MFMA peak, 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  roofline      largest single launch of the default path: k_canon_solve, loop C (every Broyden iteration of every
+                valid sample in one resident kernel).  Algorithmic MFMA flops = skinning-MLP evaluations x 105 472
+                / HIP-event duration of the launch.  Peak: the default GEMM engine carries each fp32 operand as two
+                f16 and spends three v_mfma_f32_16x16x32_f16 per product, so its ceiling in algorithmic fp32 flops is
+                the dense f16 MFMA peak / 3 = 833 TFLOP/s; the exact engine (ARAH_PRECISION=fp32) is priced against
+                the fp32 MFMA peak, 157.3 TFLOP/s (MI355X_MICROARCH.md).
+  roofline_k_density  the same for the second largest launch (round 1's dominant kernel): the SDF MLP forward on
+                every valid sample.
   exact_fp32_engine  the same frames with v_mfma_f32_16x16x4_f32 everywhere.
   cpu_baseline  the oracle (a torch-CPU restatement of the reference, pinned against it) on a bounded
                 sample of the same frame's rays, on the host cores of this box; rank 0, N == 1 only.
@@ -35,6 +38,7 @@ if ROOT not in sys.path:
 F_SDF = 657408          # 2*(3*256 + 5*256^2 + 256)
 F_SDF_GRAD = 657408
 F_COL = {"no_view_dir": 794112, "idr": 821760}
+F_SKIN = 105472         # 2*(3*128 + 3*128^2 + 128*25), one skinning-MLP evaluation
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # three f16 MFMAs per fp32 product
@@ -170,6 +174,8 @@ class GpuRuntime:
         self.tracer = model.idhr_network.ray_tracer
         self.ev0 = torch.cuda.Event(enable_timing=True)
         self.ev1 = torch.cuda.Event(enable_timing=True)
+        self.cv0 = torch.cuda.Event(enable_timing=True)   # around loop C's solver (k_canon_solve)
+        self.cv1 = torch.cuda.Event(enable_timing=True)
 
     def make_inputs(self, size, frame_idx):
         return self.scene.make_inputs(size, size, frame_idx=frame_idx, device=self.dev)
@@ -183,9 +189,13 @@ class GpuRuntime:
     def set_events(self, full_shading, on):
         setter = self.hip.set_shade_events if full_shading else self.hip.set_density_events
         setter(self.ev0, self.ev1) if on else setter(None, None)
+        self.hip.set_canon_events(self.cv0, self.cv1) if on else self.hip.set_canon_events(None, None)
 
     def event_ms(self):
         return self.ev0.elapsed_time(self.ev1)
+
+    def canon_ms(self):
+        return self.cv0.elapsed_time(self.cv1)
 
     def split_engine(self):
         return self.hip.default_precision() == self.hip.PRECISION_SPLIT_F16
@@ -243,6 +253,8 @@ def run(args, rt):
 
     n_rays_max = max(int(i["ray_dirs"].shape[1]) for i in warm_inputs + timed_inputs)
 
+    canon_ms = {}
+
     def timed_pass(full_shading, precision="split"):
         """K timed steps (barrier + sync on both sides), then the same K steps again with HIP events
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
@@ -261,13 +273,15 @@ def run(args, rt):
         dt = time.perf_counter() - t0
         ctr = ws.counters()
         rt.set_events(full_shading, True)
-        ms = []
+        ms, cms = [], []
         for inp in timed_inputs:
             rt.render(inp)
             rt.device_sync()
             ms.append(rt.event_ms())
+            cms.append(rt.canon_ms())
         rt.set_events(full_shading, False)
         os.environ["ARAH_PRECISION"] = default_engine
+        canon_ms[(full_shading, precision)] = cms
         return dt, ctr, ms
 
     default_engine = os.environ.get("ARAH_PRECISION", "split")
@@ -291,10 +305,16 @@ def run(args, rt):
         mode = cfg["model"]["renderer_kwargs"]["mode"]
 
         def path_flops(c):
-            return (F_SDF * c["n_sdf_fwd"] + F_SDF_GRAD * c["n_sdf_grad"] + 105472 * (c["n_skin_fwd"] + 3 * c["n_skin_jac"]) +
+            return (F_SDF * c["n_sdf_fwd"] + F_SDF_GRAD * c["n_sdf_grad"] + F_SKIN * (c["n_skin_fwd"] + 3 * c["n_skin_jac"]) +
                     F_COL[mode] * c["n_col"] + 55120 * c["n_knn"])
 
-        # dominant kernel of the default path: k_density = the SDF MLP forward on every valid sample
+        # largest launch of the default path: k_canon_solve = loop C, every Broyden iteration of every valid sample in one
+        # resident kernel (skinning MLP 3 -> 128 x4 -> 25 on the split engine + softmax tree + LBS blend + update)
+        cms = canon_ms[(False, default_engine)]
+        canon_avg_ms = sum(cms) / max(len(cms), 1)
+        canon_evals = counters["n_canon"] / max(len(cms), 1)
+        canon_achieved = canon_evals * F_SKIN / (canon_avg_ms * 1e-3) / 1e12
+        # second largest: k_density = the SDF MLP forward on every valid sample
         n_launch = max(len(dens_ms), 1)
         dens_samples = counters["n_density"] / n_launch           # == number of valid (converged) samples
         dens_avg_ms = sum(dens_ms) / n_launch
@@ -303,6 +323,7 @@ def run(args, rt):
         total_flops = path_flops(counters)
         tf = {True: "true", False: "false"}
         dens_traffic, traffic_src = pmc_traffic("k_density<%s>" % tf[split])
+        canon_traffic, canon_src = pmc_traffic("k_canon_solve<%s>" % tf[split])
         shade_traffic, _ = pmc_traffic("k_shade<%s, %s>" % (tf[mode == "idr"], tf[split]))
         peak_fwd = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         # k_shade: forward trunk on the default engine, reverse sweep and colour MLP on the exact engine
@@ -322,13 +343,22 @@ def run(args, rt):
                                    (args.size, args.size, args.n_steps, near, far),
                        "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
                        "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world},
-            "roofline": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
-                         "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
-                         "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_live": False,
-                         "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples, "flops_per_sample": F_SDF,
-                         "peak_note": ("algorithmic fp32 flops against dense f16 MFMA peak / 3 (three f16 MFMAs per "
-                                       "fp32 product); executed f16 MFMA rate = 3 x achieved" if split else
+            "roofline": {"bound": "mfma", "kernel": "k_canon_solve", "achieved": canon_achieved, "peak": peak_fwd,
+                         "unit": "TFLOP/s", "frac": canon_achieved / peak_fwd, "traffic": canon_traffic,
+                         "traffic_unit": "bytes/launch", "traffic_source": canon_src, "traffic_live": False,
+                         "avg_launch_ms": canon_avg_ms, "evaluations_per_launch": canon_evals,
+                         "flops_per_evaluation": F_SKIN,
+                         "peak_note": ("algorithmic fp32 MFMA flops of the skinning MLP against dense f16 MFMA peak / 3 (three "
+                                       "f16 MFMAs per fp32 product); the kernel's Softplus epilogues, softmax tree, LBS blend "
+                                       "and Broyden update are vector-ALU work on top (DESIGN.md section 7)" if split else
                                        "dense fp32 MFMA peak")},
+            "roofline_k_density": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
+                                   "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
+                                   "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_live": False,
+                                   "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples,
+                                   "flops_per_sample": F_SDF,
+                                   "note": "second largest launch (the dominant one of round 1): SDF MLP forward on every "
+                                           "valid sample"},
             "work": {"per_ray": {k: v / max(n_rays_local, 1) for k, v in counters.items()},
                      "algorithmic_mflop_per_ray": total_flops / max(n_rays_local, 1) / 1e6,
                      "whole_path_tflops_rank0": total_flops / elapsed / 1e12},

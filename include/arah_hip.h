@@ -170,7 +170,7 @@ typedef struct ArahFrame {
 typedef struct ArahCounters {
     uint64_t n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn;
     uint64_t n_density;   /* samples seen by the density pre-pass of lazy shading (a subset of n_sdf_fwd) */
-    uint64_t reserved;
+    uint64_t n_canon;     /* skinning-MLP evaluations of loop C (k_canon_solve; a subset of n_skin_fwd) */
 } ArahCounters;
 
 /* ---- frame preparation ------------------------------------------------------------------ */
@@ -310,6 +310,8 @@ const char* arah_dominant_kernel(void);
 int arah_set_shade_events(void* start_event, void* stop_event);
 /* same for the density pre-pass (k_density) of lazy shading */
 int arah_set_density_events(void* start_event, void* stop_event);
+/* same for loop C's resident solver (k_canon_solve), the largest launch of the default path */
+int arah_set_canon_events(void* start_event, void* stop_event);
 
 #ifdef __cplusplus
 }

@@ -63,7 +63,7 @@ class _StubWorkspace:
         self.n = 0
 
     def counters(self):
-        keys = ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn", "n_density")
+        keys = ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn", "n_density", "n_canon")
         return {k: 100 * self.n for k in keys}
 
 
@@ -103,6 +103,9 @@ class _StubRuntime:
 
     def event_ms(self):
         return 1.0
+
+    def canon_ms(self):
+        return 2.0
 
     def split_engine(self):
         return False
