@@ -50,8 +50,11 @@ __device__ __forceinline__ void zero_acc(f32x4& a) { a = f32x4{0.f, 0.f, 0.f, 0.
 // wrong, run to run) -- tools/ubench/trunk_repro.hip bisects it down to exactly this: the same layer compiled to
 // scalar v_fma_f32 is bit-reproducible.  The empty asm pins each value in its own VGPR, which keeps the SLP
 // vectoriser away from the chain; the arithmetic (an explicit fmaf chain) is unchanged.
+// -DARAH_ALLOW_PACK removes the fence (diagnostic build: the packed listing under profiles/ and trunk_repro come from it).
 __device__ __forceinline__ void no_pack(f32x4& v) {
+#ifndef ARAH_ALLOW_PACK
     asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#endif
 }
 
 // Weight fragments are addressed as (wave-uniform 64-bit base) + (per-lane 32-bit byte offset): the base stays in

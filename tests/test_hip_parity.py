@@ -522,23 +522,26 @@ def test_split_engine_matches_exact_fp32_engine(scene):
 
 @gpu
 @pytest.mark.parametrize("engine", ["split", "fp32"])
-def test_render_is_reproducible_under_load(scene, engine):
-    """Full-size frame, three renders with the same inputs: bit-identical, on both GPU engines.  (The first
-    split-engine build was not: a K = 3 input layer that hipcc had packed into v_pk_fma_f32 + op_sel corrupted whole
-    16-point groups when two workgroups shared a CU -- see no_pack() in csrc/mlp.hpp.)"""
+@pytest.mark.parametrize("name", ["zju377_mono", "h36m"])
+def test_render_is_reproducible_under_load(scene, engine, name):
+    """Full-size frames (three poses, both colour modes), three renders each with the same inputs: bit-identical, on
+    both GPU engines.  (The first split-engine build was not: a K = 3 input layer that hipcc had packed into
+    v_pk_fma_f32 + op_sel corrupted whole 16-point groups when two workgroups shared a CU -- see no_pack() in
+    csrc/mlp.hpp and profiles/r02_no_pack_*.txt.)"""
     from arah_release_amd import hip
     dev = torch.device("cuda:0")
     prec = hip.PRECISION_SPLIT_F16 if engine == "split" else hip.PRECISION_FP32
-    frame, inputs, cfg = _frame_for(scene, "zju377_mono", 512, 11, prec, dev)
     ws = hip.Workspace(dev)
-    samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
     pose = torch.eye(4, device=dev)[:3].contiguous()
-    cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
-    ref = hip.render(frame, ws, samp, cam, d, nf, pose)
-    for _ in range(2):
-        again = hip.render(frame, ws, samp, cam, d, nf, pose)
-        for a, b in zip(ref, again):
-            assert torch.equal(a, b)
+    for frame_idx in (11, 3, 7):
+        frame, inputs, cfg = _frame_for(scene, name, 512, frame_idx, prec, dev)
+        samp = hip.Sampling(dev, 64, 16, 16, cfg["model"]["cano_view_dirs"], False)
+        cam, d, nf = inputs["cam_loc"], inputs["ray_dirs"][0], inputs["body_bounds_intersections"][0]
+        ref = hip.render(frame, ws, samp, cam, d, nf, pose)
+        for _ in range(2):
+            again = hip.render(frame, ws, samp, cam, d, nf, pose)
+            for a, b in zip(ref, again):
+                assert torch.equal(a, b)
 
 
 @gpu
