@@ -2264,6 +2264,7 @@ __global__ void k_points_cam(FrameDev fr, int n, RaySet rs, const float* dists, 
 
 }  // namespace
 #include "train.hpp"
+#include "meshquery.hpp"
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -3277,6 +3278,28 @@ int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int
     if (n_rows == 0) return ARAH_OK;
     hipLaunchKernelGGL(k_gram_skinny, dim3(arah_gram_skinny_blocks(n_rows)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a, lda, m, b, ldb, n, n_rows, partial);
+    return check_launch();
+}
+
+// ---- mesh queries of the training data path ------------------------------------------------------------------
+size_t arah_mesh_query_scratch_bytes(void) { return 256; }
+
+int arah_mesh_query(const float* verts, int32_t n_verts, const int32_t* faces, int32_t n_faces, const void* pts,
+                    int32_t pts_are_f64, int32_t n_pts, double* d2, int32_t* face, double* closest, double* bary,
+                    uint8_t* inside, void* scratch, void* stream) {
+    if (!verts || !faces || n_verts < 1 || n_faces < 1 || n_pts < 0 || !scratch) return ARAH_E_BADARG;
+    if (n_pts == 0) return ARAH_OK;
+    if (!pts || !d2 || !face || !closest || !bary || !inside) return ARAH_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    MeshBox* box = reinterpret_cast<MeshBox*>(scratch);
+    hipLaunchKernelGGL(k_mesh_box, dim3(1), dim3(256), 0, s, verts, faces, n_faces, 512.0, box);
+    const int g = (n_pts + kMeshThreads - 1) / kMeshThreads;
+    if (pts_are_f64)
+        hipLaunchKernelGGL(k_mesh_query<double>, dim3(g), dim3(kMeshThreads), 0, s, verts, faces, n_faces, (const MeshBox*)box,
+                           reinterpret_cast<const double*>(pts), n_pts, d2, face, closest, bary, inside);
+    else
+        hipLaunchKernelGGL(k_mesh_query<float>, dim3(g), dim3(kMeshThreads), 0, s, verts, faces, n_faces, (const MeshBox*)box,
+                           reinterpret_cast<const float*>(pts), n_pts, d2, face, closest, bary, inside);
     return check_launch();
 }
 

@@ -190,3 +190,91 @@ def _rotvec_to_matrix(rv):
     scale = torch.where(small, 0.5 - a2 / 48 + a2 * a2 / 3840, torch.sin(angle / 2) / angle.clamp_min(1e-30))
     q = torch.cat([rv * scale.unsqueeze(1), torch.cos(angle / 2).unsqueeze(1)], dim=1)
     return smpl.quaternion_to_rotation_matrix_xyzw(q)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training-only samplers (data/zju_mocap.py:455-543) on the device: regularisation points off the canonical
+# SMPL surface, skinning supervision points on it, points inside it
+# ---------------------------------------------------------------------------------------------------------------------
+def sample_surface(verts, faces, count, generator=None):
+    """``trimesh.Trimesh.sample(count, return_index=True)`` (trimesh 3.9, not in the reference tree; restated from
+    trimesh/sample.py sample_surface): faces drawn proportionally to area by a search in the cumulative areas, the point is
+    origin + r1 e1 + r2 e2 with (r1, r2) uniform in the unit square, reflected (|r - 1|) when r1 + r2 > 1.
+    verts (V,3), faces (F,3) integer -> points (count,3), face index (count,)."""
+    dev = verts.device
+    tri = verts[faces.long()]
+    e1, e2 = tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]
+    area = torch.linalg.cross(e1, e2).norm(dim=-1) * 0.5
+    cum = torch.cumsum(area, 0)
+    pick = torch.rand(count, device=dev, generator=generator) * cum[-1]
+    fi = torch.searchsorted(cum, pick).clamp(max=faces.shape[0] - 1)
+    r = torch.rand(count, 2, device=dev, generator=generator)
+    flip = r.sum(1) > 1.0
+    r = torch.where(flip[:, None], (r - 1.0).abs(), r)
+    return tri[fi, 0] + r[:, :1] * e1[fi] + r[:, 1:] * e2[fi], fi
+
+
+def _choose(n_have, n_want, dev, generator):
+    """np.random.choice(n_have, size=n_want, replace=n_have < n_want) (zju_mocap.py:472-475)."""
+    if n_have >= n_want:
+        return torch.randperm(n_have, device=dev, generator=generator)[:n_want]
+    return torch.randint(0, n_have, (n_want,), device=dev, generator=generator)
+
+
+def training_samples(minimal_shape_v, faces, skinning_weights, coord_min, coord_max, center, sample_reg_surface=False,
+                     sample_inside=False, off_surface_thr=0.2, inside_thr=0.001, generator=None):
+    """The per-item point sets of the training losses (zju_mocap.py:455-543), from the canonical (Vitruvian-pose) SMPL mesh:
+
+      points_uniform   (1024,3) normalised: uniform in [-1,1]^3, outside the mesh and farther than the threshold from it
+                       (the reference compares the SQUARED distance igl returns with ``off_surface_thr``; kept);
+      points_skinning / sampled_weights: 1024 surface samples with barycentrically interpolated skinning weights
+                       (sample_reg_surface) or the 24 part centroids with one-hot weights;
+      points_inside    (1024,3) normalised (sample_inside): surface samples displaced by N(0, 0.5 m) that fall inside the
+                       mesh, not nearer than ``inside_thr`` (squared) to it and not on a hand part, plus the 22 part centroids.
+
+    Containment, closest face and barycentric weights come from one device call per point set (hip.mesh_query: the
+    reference's libmesh test restated exactly; igl's closest-point query).  Random draws: a torch generator stands in for
+    numpy's global state.  minimal_shape_v (6890,3) float32 on the GPU, faces (13776,3) int32, skinning_weights (6890,24)."""
+    from . import hip
+    dev = minimal_shape_v.device
+    v = minimal_shape_v.float().contiguous()
+    f = faces.to(torch.int32).contiguous()
+    cmin, cmax, cen = coord_min.reshape(()), coord_max.reshape(()), center.reshape(1, 3)
+    span = cmax - cmin
+    normalize = lambda p: (((p - cen) - cmin + span * 0.05) / span / 1.1 - 0.5) * 2.0
+    unnormalize = lambda p: (p / 2.0 + 0.5) * 1.1 * span + cmin - span * 0.05 + cen
+    part_idx = skinning_weights.argmax(-1)
+    onehot = torch.nn.functional.one_hot(part_idx, 24).float()
+    centroids = (onehot.t() @ v) / onehot.sum(0).clamp(min=1.0)[:, None]           # per-part mean vertex (:457-459,503-506)
+
+    def interpolated_weights(face, bary):
+        vid = f[face.long()].long()
+        return (skinning_weights[vid] * bary.float()[..., None]).sum(1)            # :485-486
+
+    out = {}
+    uniform = torch.rand(4096, 3, device=dev, generator=generator) * 2.0 - 1.0     # :464 / :491
+    query = unnormalize(uniform)
+    if sample_reg_surface:
+        pts_skin, _ = sample_surface(v, f, 1024, generator)                         # :468
+        d2, face, _, bary, inside = hip.mesh_query(v, f, torch.cat([query, pts_skin], 0))
+        keep = (~inside[:4096]) & (d2[:4096] > off_surface_thr)                    # :471
+        out["points_skinning"] = pts_skin
+        out["sampled_weights"] = interpolated_weights(face[4096:], bary[4096:])
+    else:
+        d2, _, _, _, inside = hip.mesh_query(v, f, query)
+        keep = (~inside) & (d2 > off_surface_thr)                                  # :495
+        out["points_skinning"] = centroids
+        out["sampled_weights"] = torch.eye(24, device=dev)
+    cand = uniform[keep]
+    if cand.shape[0] == 0:
+        raise ValueError("no regularisation point survives the off-surface threshold")   # numpy's choice raises here too
+    out["points_uniform"] = cand[_choose(cand.shape[0], 1024, dev, generator)]
+    if sample_inside:
+        pts, _ = sample_surface(v, f, 4096, generator)                              # :517
+        pts = pts + torch.randn(pts.shape, device=dev, generator=generator) * 0.5
+        d2, face, _, bary, inside = hip.mesh_query(v, f, pts)
+        part = interpolated_weights(face, bary).argmax(-1)                          # :528-529
+        ok = inside & (part != 22) & (part != 23) & (d2 >= inside_thr)             # :521,530
+        pts = torch.cat([pts[ok], centroids[:22]], 0)                               # :532-535 (22 body parts, no hands)
+        out["points_inside"] = normalize(pts[_choose(pts.shape[0], 1024, dev, generator)])
+    return out

@@ -92,7 +92,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "ar
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_dominant_kernel", "arah_set_shade_events",
+           "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events", "arah_set_canon_events"]
 
 _lib = None
@@ -112,6 +112,7 @@ def load_library():
     lib.arah_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.arah_dominant_kernel.restype = C.c_char_p
     lib.arah_shade_train_slab_bytes.restype = C.c_size_t
+    lib.arah_mesh_query_scratch_bytes.restype = C.c_size_t
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the symbol is missing
     _lib = lib
@@ -593,6 +594,29 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
                                          C.c_size_t(ws.train_slab.numel()), _ptr(buf), C.c_size_t(buf.numel()),
                                          _stream()), "arah_shade_train_backward")
     return st
+
+
+def mesh_query(verts, faces, pts):
+    """Closest point of a triangle mesh and containment for every query point (training samplers, zju_mocap.py:461-543).
+    verts (V,3) float32, faces (F,3) int32, pts (P,3) float32 or float64 on one GPU ->
+    d2 (P,) float64, face (P,) int32, closest (P,3) float64, bary (P,3) float64, inside (P,) bool."""
+    lib = load_library()
+    dev = _same_device(verts, faces, pts)
+    if verts.dtype != torch.float32 or faces.dtype != torch.int32 or pts.dtype not in (torch.float32, torch.float64):
+        raise ValueError("verts float32, faces int32, pts float32 / float64 required")
+    verts, faces, pts = verts.contiguous(), faces.contiguous(), pts.contiguous()
+    P = pts.shape[0]
+    d2 = torch.empty(P, dtype=torch.float64, device=dev)
+    face = torch.empty(P, dtype=torch.int32, device=dev)
+    closest = torch.empty(P, 3, dtype=torch.float64, device=dev)
+    bary = torch.empty(P, 3, dtype=torch.float64, device=dev)
+    inside = torch.empty(P, dtype=torch.uint8, device=dev)
+    with _on_device(dev):
+        scratch = torch.empty(lib.arah_mesh_query_scratch_bytes(), dtype=torch.uint8, device=dev)
+        _check(lib.arah_mesh_query(_ptr(verts), C.c_int32(verts.shape[0]), _ptr(faces), C.c_int32(faces.shape[0]), _ptr(pts),
+                                   C.c_int32(1 if pts.dtype == torch.float64 else 0), C.c_int32(P), _ptr(d2), _ptr(face),
+                                   _ptr(closest), _ptr(bary), _ptr(inside), _ptr(scratch), _stream()), "arah_mesh_query")
+    return d2, face, closest, bary, inside.bool()
 
 
 def gram_skinny(a, b):

@@ -272,6 +272,17 @@ int32_t arah_gram_skinny_blocks(int32_t n_rows);
 int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int32_t ldb, int32_t n, int32_t n_rows,
                      float* partial, void* stream);
 
+/* Mesh queries of the training data path (zju_mocap.py:461-543): for every query point the closest point of the triangle
+ * mesh -- squared distance, face (lowest index on ties), the point, barycentric weights of the face's three vertices
+ * (igl.point_mesh_squared_distance + igl.barycentric_coordinates_tri) -- and containment exactly as
+ * im2mesh/utils/libmesh/inside_mesh.py:4-100 decides it (z-ray crossing parity in both directions, hash resolution 512,
+ * double precision).  verts [V,3] f32, faces [F,3] i32, pts [P,3] f32 or f64 -> d2 [P] f64, face [P] i32,
+ * closest [P,3] f64, bary [P,3] f64, inside [P] u8.  scratch: arah_mesh_query_scratch_bytes() device bytes. */
+size_t arah_mesh_query_scratch_bytes(void);
+int arah_mesh_query(const float* verts, int32_t n_verts, const int32_t* faces, int32_t n_faces, const void* pts,
+                    int32_t pts_are_f64, int32_t n_pts, double* d2, int32_t* face, double* closest, double* bary,
+                    uint8_t* inside, void* scratch, void* stream);
+
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* rays: cam_loc [n_cams,3], ray r belongs to camera r / rays_per_cam; dirs [N,3]; near_far [N,2].
  * root_find_all: 0 = joint root find on the non-diverged rays (eval), 1 = on every ray (training, RT:249).

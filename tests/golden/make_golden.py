@@ -302,7 +302,55 @@ def make_f9():
     save("f9_callers.npz", **out)
 
 
+def test_mesh():
+    """A closed, body-sized triangle mesh for the mesh-query fixtures: zero level of a union of capsules (torso, head,
+    two arms, two legs) on a 56^3 lattice, triangulated by the build's own marching cubes (CPU tensors)."""
+    from arah_release_amd import meshing
+    n = 56
+    lin = torch.linspace(-1.0, 1.0, n)
+    X, Y, Z = torch.meshgrid(lin, lin, lin, indexing="ij")
+    P = torch.stack([X, Y, Z], -1).reshape(-1, 3)
+
+    def capsule(a, b, r):
+        a, b = torch.tensor(a), torch.tensor(b)
+        ab = b - a
+        t = ((P - a) @ ab / (ab @ ab)).clamp(0, 1)
+        return (P - a - t[:, None] * ab).norm(dim=-1) - r
+
+    parts = [capsule((0, -0.1, 0), (0, 0.45, 0), 0.2), capsule((0, 0.62, 0), (0, 0.7, 0), 0.12),
+             capsule((-0.22, 0.4, 0), (-0.75, 0.42, 0.05), 0.07), capsule((0.22, 0.4, 0), (0.75, 0.38, -0.05), 0.07),
+             capsule((-0.1, -0.2, 0), (-0.18, -0.9, 0.03), 0.09), capsule((0.1, -0.2, 0), (0.2, -0.9, -0.02), 0.09)]
+    sdf = torch.stack(parts, 0).min(0).values.reshape(n, n, n)
+    tri = meshing.marching_cubes(sdf, level=0.0).float()                         # (F,3,3) soup, shared corners bit-equal
+    verts, inv = torch.unique(tri.reshape(-1, 3), dim=0, return_inverse=True)
+    return verts.numpy().astype(np.float32), inv.reshape(-1, 3).numpy().astype(np.int32)
+
+
+def make_f10():
+    """F10: containment of query points in a closed mesh by the reference's OWN im2mesh/utils/libmesh/inside_mesh.py
+    (check_mesh_contains, zju_mocap.py:466,493,520), its Cython triangle hash replaced by a brute-force candidate filter
+    (ref_shim._BruteTriangleHash: the hash is only a pre-selection).  The mesh object is a stand-in for trimesh.Trimesh
+    (float64 ``vertices``, ``faces``)."""
+    import types
+    from im2mesh.utils.libmesh.inside_mesh import check_mesh_contains
+    verts, faces = test_mesh()
+    rng = np.random.RandomState(7)
+    uniform = rng.rand(4096, 3) * 2.0 - 1.0                                   # zju_mocap.py:464
+    fa = rng.randint(0, len(faces), 2048)
+    w = rng.dirichlet(np.ones(3), 2048)
+    surf = (verts[faces[fa]].astype(np.float64) * w[..., None]).sum(1)
+    near = surf + rng.normal(scale=0.02, size=surf.shape)                     # both sides of the surface, 2 cm
+    far = surf + rng.normal(scale=0.5, size=surf.shape)                       # zju_mocap.py:518
+    pts = np.concatenate([uniform, near, far, verts[:64].astype(np.float64)], 0)
+    mesh = types.SimpleNamespace(vertices=verts.astype(np.float64), faces=faces.astype(np.int64))
+    contains = check_mesh_contains(mesh, pts)
+    np.savez_compressed(os.path.join(HERE, "f10_mesh_contains.npz"), verts=verts, faces=faces, points=pts, contains=contains)
+    print("wrote f10_mesh_contains.npz: %d verts, %d faces, %d points, %d inside" % (len(verts), len(faces), len(pts), int(contains.sum())))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f10":
+        return make_f10()
     if len(sys.argv) > 1 and sys.argv[1] == "f9":
         return make_f9()
     if len(sys.argv) > 1 and sys.argv[1] == "f1d4":

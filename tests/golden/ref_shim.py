@@ -71,6 +71,30 @@ def _knn_points(p1, p2, K=1, **kwargs):
     return _KNN(dists=dists, idx=idx, knn=None)
 
 
+class _BruteTriangleHash:
+    """Stand-in for the reference's Cython triangle hash (im2mesh/utils/libmesh/triangle_hash.pyx, not built here).  The
+    hash only PRE-SELECTS candidate (point, triangle) pairs -- every triangle registered in the grid cell of the point;
+    each candidate then goes through inside_mesh.py's own strict 2-D containment test -- so any superset of the pairs
+    that pass that test gives the same answer.  Here: every triangle whose 2-D bounding box contains the point."""
+
+    def __init__(self, triangles, resolution):
+        import numpy as np
+        t = np.asarray(triangles, np.float64)
+        self.lo, self.hi = t.min(1), t.max(1)
+
+    def query(self, points):
+        import numpy as np
+        pts = np.asarray(points, np.float64)
+        pi, ti = [], []
+        for c0 in range(0, len(pts), 512):
+            p = pts[c0:c0 + 512]
+            m = ((p[:, None, :] >= self.lo[None]) & (p[:, None, :] <= self.hi[None])).all(-1)
+            a, b = np.nonzero(m)
+            pi.append(a + c0)
+            ti.append(b)
+        return np.concatenate(pi), np.concatenate(ti)
+
+
 def install():
     """Make ``import im2mesh`` resolve to the reference tree. Returns the im2mesh package."""
     if not os.path.isdir(os.path.join(REF_ROOT, "im2mesh")):
@@ -87,6 +111,7 @@ def install():
             parent, child = name.rsplit(".", 1)
             setattr(sys.modules[parent], child, sys.modules[name])
     sys.modules["pytorch3d.ops"].knn_points = _knn_points
+    sys.modules["im2mesh.utils.libmesh.triangle_hash"].TriangleHash = _BruteTriangleHash
     # kornia 0.5.10 conversions used by LightningModel.compose_inputs (lightning_model.py:477,539): third-party, restated
     # from kornia's documented formulas (the same restatement the build uses: these two functions pin nothing)
     import enum
