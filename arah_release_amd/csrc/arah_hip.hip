@@ -1991,7 +1991,8 @@ __device__ __forceinline__ float volsdf_density(float sdf, float inv_beta) {
 
 // ------------------------------------------------------------------------------------------
 // loop D, pass 1 (exact lazy shading): SDF value -> density for every valid sample.  A sample whose
-// density is exactly +0 (outside the surface by more than ~104 beta: exp underflows in fp32) has
+// density is exactly +0 (outside the surface by more than 16.6 beta: exp(-s / beta) < 2^-24, so 1 - exp(.) rounds to 1 and
+// 0.5 - 0.5 * 1 is 0) has
 // alpha = 1 - exp(-0 * delta) = 0 and weight 0 whatever its colour, and it scales the transmittance by
 // (1 - 0 + 1e-7) independently of its colour (IDR:387-394).  Its normal and colour are therefore dead
 // values: only samples with density > 0 go on to pass 2 (k_shade).  The composited image is

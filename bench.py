@@ -125,6 +125,10 @@ def main():
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
+    ap.add_argument("--beta", type=float, default=None,
+                    help="override the VolSDF beta of the synthetic subject (|deviation_decoder.variance|, default 1e-3 = the "
+                         "reference's initial value): the share of samples with density > 0, hence what exact lazy shading "
+                         "saves, depends on it")
     ap.add_argument("--passes", default="all", choices=["all", "default"],
                     help="'default': only the product's default path (profiling runs); 'all' adds the full-shading, "
                          "exact-engine and strict passes over the same frames")
@@ -152,6 +156,9 @@ def main():
 
     near = far = args.n_steps // 4
     model, cfg = config.build_synthetic_model(args.config, args.n_steps, near, far, device=dev)
+    if args.beta is not None:
+        with torch.no_grad():
+            model.deviation_decoder.variance.fill_(args.beta)
     rt = GpuRuntime(world, rank, dev, dist if world > 1 else None, model, cfg, synthetic.SyntheticScene(0), hip)
     line = run(args, rt)
     if rank == 0:
@@ -336,7 +343,7 @@ def run(args, rt):
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32 (operands as hi+lo f16 pairs on the f16 MFMA pipe, fp32 accumulate)" if split else "f32",
-            "data": "synthetic",
+            "data": "synthetic" if getattr(args, "beta", None) is None else "synthetic, VolSDF beta overridden to %g" % args.beta,
             "precision": engine,
             "config": {"workload": WORKLOAD_NAMES.get(args.config, args.config) + " test.py inference, %dx%d, %d samples/ray (near %d / far %d), "
                                    "synthetic capsule body + fitted SIREN, one frame per step" %
