@@ -8,6 +8,7 @@ agreement >= 99.5 %, depth/points within 1e-4..2e-4 on agreeing rays, PSNR >= 45
 """
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -70,6 +71,26 @@ def test_microbenchmarks_compile(name, tmp_path):
     src = os.path.join(REPO, "tools", "ubench", name + ".hip")
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-c", src, "-o",
                     str(tmp_path / (name + ".o"))], check=True, capture_output=True)
+
+
+def test_device_code_has_no_packed_fp32(tmp_path):
+    """The library is built without packed-fp32 instruction selection (__graft_entry__.NO_PACKED_FP32): on the MI355X
+    v_pk_fma_f32 with op_sel on a VGPR source goes wrong next to another workgroup's f16 MFMAs (tools/ubench/trunk_repro.hip,
+    profiles/r02_trunk_repro.txt), and hipcc emits that form on its own.  Disassemble the shipped code object and look."""
+    import shutil
+    import __graft_entry__
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not found")
+    __graft_entry__.build()
+    lib = shutil.copy(os.path.join(REPO, "arah_release_amd", "libarah_hip.so"), tmp_path / "lib.so")
+    subprocess.run([objdump, "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    cos = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(cos) == 1, cos
+    dis = subprocess.run([objdump, "-d", str(tmp_path / cos[0])], check=True, capture_output=True, text=True).stdout
+    assert dis.count("v_mfma_f32_16x16x32_f16") > 100 and dis.count("v_fma_mixlo_f16") > 10     # it is the product's code
+    for op in ("v_pk_fma_f32", "v_pk_mul_f32", "v_pk_add_f32"):
+        assert op not in dis, op
 
 
 def test_product_has_no_cpu_fallback():

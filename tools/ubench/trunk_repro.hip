@@ -102,7 +102,44 @@ __device__ __forceinline__ void trunk_dbg(const SdfNet& net, const float* xin, f
             const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
             for (int n = 0; n < NT; ++n) {
                 f32x4 v, h, d;
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
+                if (FL & (16384 | 32768 | 65536)) {
+                    // one operand-selection form at a time, written out; the other two products on aligned pairs
+                    //   16384: v_pk_mul_f32  src0 = coordinate pair {x0, x1}, op_sel_hi:[0,1]    (both lanes read x0)
+                    //   32768: v_pk_fma_f32  src1 = coordinate pair {x0, x1}, op_sel:[0,1,0]     (both lanes read x1)
+                    //   65536: v_pk_fma_f32  src1 = pair {x2, unrelated},     op_sel_hi:[1,0,1]  (both lanes read x2)
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    for (int p = 0; p < 2; ++p) {
+                        f32x2 wa = {w[2 * p][0], w[2 * p + 1][0]}, wb = {w[2 * p][1], w[2 * p + 1][1]},
+                              wc = {w[2 * p][2], w[2 * p + 1][2]};
+                        f32x2 xa = {x[n][0], x[n][0]}, xb = {x[n][1], x[n][1]}, xc = {x[n][2], x[n][2]}, t;
+                        f32x2 x01 = {x[n][0], x[n][1]}, x2j = {x[n][2], x[n][3]};
+                        if (FL & 16384) asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x01), "v"(wa));
+                        else asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(wa), "v"(xa));
+                        if (FL & 32768) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0]" : "+v"(t) : "v"(wb), "v"(x01));
+                        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(wb), "v"(xb));
+                        if (FL & 65536) asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(t) : "v"(wc), "v"(x2j));
+                        else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(wc), "v"(xc));
+                        v[2 * p] = t.x;
+                        v[2 * p + 1] = t.y;
+                    }
+                } else if (FL & 8192) {   // the K = 3 chain as explicit packed FMAs on ALIGNED register pairs: no op_sel anywhere
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    for (int p = 0; p < 2; ++p) {
+                        f32x2 wa = {w[2 * p][0], w[2 * p + 1][0]}, wb = {w[2 * p][1], w[2 * p + 1][1]},
+                              wc = {w[2 * p][2], w[2 * p + 1][2]};
+                        f32x2 xa = {x[n][0], x[n][0]}, xb = {x[n][1], x[n][1]}, xc = {x[n][2], x[n][2]}, t;
+                        asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(t) : "v"(wa), "v"(xa));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(wb), "v"(xb));
+                        asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(t) : "v"(wc), "v"(xc));
+                        v[2 * p] = t.x;
+                        v[2 * p + 1] = t.y;
+                    }
+                } else {
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[n][2], fmaf(w[r][1], x[n][1], w[r][0] * x[n][0]));
+                }
+                if (FL & 1024) asm volatile("s_nop 7\n\ts_nop 7");        // 16 idle cycles between the packed chain and the sine
+                if (FL & 2048) asm volatile("s_nop 0");
+                if (FL & 4096) __builtin_amdgcn_sched_barrier(0);
                 if (FL & 512) {
                     for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(v[r]));   // K=3 chain unpacked, sine free to pack
                 }
@@ -833,6 +870,14 @@ int main(int argc, char** argv) {
             }
         }
     }
+    run_dbg<8192>("K=3 chain as explicit v_pk_mul/fma_f32 on aligned pairs, no op_sel", net, dX, n, dO, lds);
+    run_dbg<16384>("explicit packed chain, ONLY v_pk_mul_f32 op_sel_hi:[0,1] on the coordinate pair", net, dX, n, dO, lds);
+    run_dbg<32768>("explicit packed chain, ONLY v_pk_fma_f32 op_sel:[0,1,0] on the coordinate pair", net, dX, n, dO, lds);
+    run_dbg<65536>("explicit packed chain, ONLY v_pk_fma_f32 op_sel_hi:[1,0,1] on {x2, unrelated}", net, dX, n, dO, lds);
+    run_dbg<114688>("explicit packed chain, all three operand-selection forms", net, dX, n, dO, lds);
+    run_dbg<1024>("packed chain, then 16 idle cycles (s_nop 7 x2) before the sine", net, dX, n, dO, lds);
+    run_dbg<2048>("packed chain, then s_nop 0 before the sine", net, dX, n, dO, lds);
+    run_dbg<4096>("packed chain, then a scheduling barrier only", net, dX, n, dO, lds);
     run_dbg<4>("one-channel head", net, dX, n, dO, lds);
     run_dbg<512>("K=3 chain fenced, product sine", net, dX, n, dO, lds);
     run_dbg<256>("layer-1 sine re-written inline (same math)", net, dX, n, dO, lds);
