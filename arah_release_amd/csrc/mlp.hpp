@@ -501,13 +501,30 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         if constexpr (TAP::on) stream_rows(act, ld, 256, tap.h[k], tap.row0, tap.rows, wave * 64 + lane);   // h_k: read only
         if (SPLIT) gemm_acc_split<8, kSdfMT, NT, GRAD>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);   // GRAD kernels: 2 waves/SIMD
         else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
+        // forward-only kernels: the epilogue's per-channel constants travel (L2 latency) while the workgroup gathers at the
+        // barrier (the gradient kernels sit at the VGPR cap and load them afterwards)
+        f32x4 fwm[kSdfMT], pwm[kSdfMT];
+        if constexpr (!GRAD) {
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m) {
+                const int ch0 = (mt0 + m) * 16 + 4 * g;
+                fwm[m] = *reinterpret_cast<const f32x4*>((SPLIT ? net.fws : net.fw) + k * 256 + ch0);
+                pwm[m] = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+            }
+        }
         ARAH_SYNC();   // everyone is done reading the layer input
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
-            const f32x4 fw = *reinterpret_cast<const f32x4*>((SPLIT ? net.fws : net.fw) + k * 256 + ch0);
-            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
-            const f32x4 f = GRAD ? *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0) : zero4;
+            f32x4 fw, pw, f = zero4;
+            if constexpr (GRAD) {
+                fw = *reinterpret_cast<const f32x4*>((SPLIT ? net.fws : net.fw) + k * 256 + ch0);
+                pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+                f = *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0);
+            } else {
+                fw = fwm[m];
+                pw = pwm[m];
+            }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 f32x4 h, d;
@@ -699,11 +716,12 @@ __device__ __forceinline__ void skin_mlp(const SkinNet& net, const float* xin, f
         if (SPLIT) gemm_acc_split<4, 1, NT>(net.wps[k - 1], wave, act, ld, 256, acc, lane);
         else gemm_acc<8, 1, NT>(net.wp[k - 1], wave, act, ld, acc, lane);
         clk.mark(1 + 2 * k);
-        ARAH_SYNC();
+        // the epilogue's constants travel (L2 latency) while the workgroup gathers at the barrier
         const int ch0 = wave * 16 + 4 * g;
         f32x4 b = *reinterpret_cast<const f32x4*>(net.bias + k * 128 + ch0);
         const float S = SPLIT ? net.scales[k] : 1.0f;
         const float inv = SPLIT ? net.scales[4 + k - 1] * S : 1.0f;   // accumulator -> S (W h): S is a power of two
+        ARAH_SYNC();
         const float c1 = 144.269504088896341f / S, c2 = 6.93147180559945e-3f * S;
         if (SPLIT) b = b * S;
 #pragma unroll
