@@ -125,6 +125,9 @@ def main():
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="frames in flight in the timed region (renderer.render_sequence: frame k on HIP stream k mod N, "
+                         "own scratch each); 1 = strictly one frame after the other")
     ap.add_argument("--beta", type=float, default=None,
                     help="override the VolSDF beta of the synthetic subject (|deviation_decoder.variance|, default 1e-3 = the "
                          "reference's initial value): the share of samples with density > 0, hence what exact lazy shading "
@@ -189,6 +192,28 @@ class GpuRuntime:
 
     def render(self, inputs):
         return self.model(inputs, eval=True)
+
+    def render_many(self, frames, n_streams):
+        """The timed region: independent frames, n_streams of them in flight (renderer.render_sequence)."""
+        from arah_release_amd import renderer
+        return renderer.render_sequence(self.model, frames, n_streams=n_streams, eval=True)
+
+    def prepare(self, n_rays, n_steps):
+        """Size every scratch that exists (one per stream that has rendered) before anything is timed or counted."""
+        self.tracer.workspace(self.dev)
+        for ws in self.tracer.workspaces():
+            ws.ensure(n_rays, n_steps)
+
+    def reset_counters(self):
+        for ws in self.tracer.workspaces():
+            ws.reset_counters()
+
+    def counters(self):
+        tot = {}
+        for ws in self.tracer.workspaces():
+            for k, v in ws.counters().items():
+                tot[k] = tot.get(k, 0) + v
+        return tot
 
     def device_sync(self):
         torch.cuda.synchronize()
@@ -262,23 +287,22 @@ def run(args, rt):
 
     canon_ms = {}
 
-    def timed_pass(full_shading, precision="split"):
+    def timed_pass(full_shading, precision="split", n_streams=None):
         """K timed steps (barrier + sync on both sides), then the same K steps again with HIP events
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
         tracer.full_shading = full_shading
         os.environ["ARAH_PRECISION"] = precision
-        ws = tracer.workspace(rt.dev)
-        ws.ensure(n_rays_max, args.n_steps)   # sized for the largest frame before anything is timed or counted
-        for inp in warm_inputs:
-            rt.render(inp)
+        n_streams = args.streams if n_streams is None else n_streams
+        rt.render_many(warm_inputs, n_streams)
         sync()
-        ws.reset_counters()
+        rt.prepare(n_rays_max, args.n_steps)   # every scratch sized for the largest frame before anything is timed or counted
+        rt.reset_counters()
+        sync()
         t0 = time.perf_counter()
-        for inp in timed_inputs:
-            rt.render(inp)
+        rt.render_many(timed_inputs, n_streams)
         sync()
         dt = time.perf_counter() - t0
-        ctr = ws.counters()
+        ctr = rt.counters()
         rt.set_events(full_shading, True)
         ms, cms = [], []
         for inp in timed_inputs:
@@ -295,6 +319,9 @@ def run(args, rt):
     split = rt.split_engine()
     with torch.no_grad():
         elapsed, counters, dens_ms = timed_pass(False, default_engine)          # the product's default path
+        elapsed_one = None
+        if args.streams > 1:                                    # the same frames strictly one after the other
+            elapsed_one, _, _ = timed_pass(False, default_engine, n_streams=1)
         elapsed_full = elapsed_exact = elapsed_strict = None
         if args.passes == "all":
             elapsed_full, counters_full, shade_ms = timed_pass(True, default_engine)  # shade every valid sample, like the reference
@@ -304,6 +331,7 @@ def run(args, rt):
         tracer.full_shading = False
 
     total_rays, t_max = aggregate(n_rays_local, elapsed, dist)
+    t_max_one = aggregate(n_rays_local, elapsed_one, dist)[1] if elapsed_one else None
     t_max_full = aggregate(n_rays_local, elapsed_full, dist)[1] if elapsed_full else None
     t_max_exact = aggregate(n_rays_local, elapsed_exact, dist)[1] if elapsed_exact else None
     t_max_strict = aggregate(n_rays_local, elapsed_strict, dist)[1] if elapsed_strict else None
@@ -349,7 +377,8 @@ def run(args, rt):
                                    "synthetic capsule body + fitted SIREN, one frame per step" %
                                    (args.size, args.size, args.n_steps, near, far),
                        "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
-                       "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world},
+                       "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world,
+                       "frames_in_flight_per_gpu": args.streams},
             "roofline": {"bound": "mfma", "kernel": "k_canon_solve", "achieved": canon_achieved, "peak": peak_fwd,
                          "unit": "TFLOP/s", "frac": canon_achieved / peak_fwd, "traffic": canon_traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": canon_src, "traffic_live": False,
@@ -370,6 +399,11 @@ def run(args, rt):
                      "algorithmic_mflop_per_ray": total_flops / max(n_rays_local, 1) / 1e6,
                      "whole_path_tflops_rank0": total_flops / elapsed / 1e12},
         }
+        if t_max_one:
+            line["one_frame_at_a_time"] = {"note": "same frames, same path, a single HIP stream (no frame in flight while "
+                                                   "another one renders): the latency figure",
+                                           "value": total_rays / t_max_one, "unit": "rays/s",
+                                           "ms_per_step": 1e3 * t_max_one / max(args.steps, 1)}
         if t_max_full:
             # dominant kernel of the shade-everything path: k_shade (forward trunk on the default engine, reverse sweep
             # and colour MLP on the exact engine)

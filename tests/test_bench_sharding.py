@@ -75,6 +75,9 @@ class _StubTracer:
     def workspace(self, dev):
         return self.ws
 
+    def workspaces(self):
+        return [self.ws]
+
 
 class _StubRuntime:
     """Same surface as bench.GpuRuntime; a 'render' costs 2 ms per frame on rank 0 and 4 ms on rank 1, a frame has
@@ -94,6 +97,19 @@ class _StubRuntime:
         time.sleep(0.002 * (self.rank + 1))
         self.tracer.ws.n += 1
         self.rendered.append(inputs["frame"])
+
+    def render_many(self, frames, n_streams):
+        for f in frames:
+            self.render(f)
+
+    def prepare(self, n_rays, n_steps):
+        pass
+
+    def reset_counters(self):
+        self.tracer.ws.reset_counters()
+
+    def counters(self):
+        return self.tracer.ws.counters()
 
     def device_sync(self):
         pass
@@ -117,7 +133,7 @@ def _run_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     args = argparse.Namespace(gpus=world, steps=3, warmup=1, size=64, n_steps=64, config="zju377_mono",
-                              cpu_sample_rays=16, no_cpu_baseline=True, no_train=True, passes="default")
+                              cpu_sample_rays=16, no_cpu_baseline=True, no_train=True, passes="default", streams=1, beta=None)
     rt = _StubRuntime(world, rank)
     line = bench.run(args, rt)
     out[rank] = (line, list(rt.rendered))
