@@ -9,7 +9,7 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
 if [ -z "$SKIP_TESTS" ]; then
-timeout 900 python -m pytest tests -m gpu -x -q > $OUT/tests.log 2>&1
+timeout 900 python -m pytest tests -m gpu -x -q --timeout=240 > $OUT/tests.log 2>&1
 echo "pytest rc=$?" >> $OUT/tests.log
 tail -5 $OUT/tests.log
 timeout 600 python bench.py --steps 8 --warmup 2 > $OUT/bench_default.json 2> $OUT/bench_default.err
@@ -22,13 +22,15 @@ try:
           "density frac", d["roofline_k_density"]["frac"], "dens_ms", d["roofline_k_density"]["avg_launch_ms"])
     for k in ("full_shading", "exact_fp32_engine", "strict"):
         if k in d: print(k, d[k]["value"], d[k]["ms_per_step"])
+    print("one frame at a time", d.get("one_frame_at_a_time"))
+    print("training", d.get("training"))
     print("psnr", d.get("psnr_vs_oracle_db"), "mask", d.get("mask_agreement"), "work", d["work"]["per_ray"])
 except Exception as e:
     print("bench parse failed", e)
 PY
 fi
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o kt -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --passes default > $OUT/bench_prof.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o kt -- python $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/bench_prof.json 2> $OUT/prof.err
 cd $ROOT
 DB=$(find $OUT/prof -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB > $OUT/kernel_stats.txt && head -30 $OUT/kernel_stats.txt
@@ -37,7 +39,7 @@ if [ "$2" = "pmc" ]; then
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
     N=$(echo $C | cut -d' ' -f1)
-    timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-train --passes default > $OUT/pmc_$N.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/pmc_$N.log 2>&1
   done
   cd $ROOT
   F=$(find $OUT/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find $OUT/pmc_WRITE_SIZE -name "*.db" | head -1)
