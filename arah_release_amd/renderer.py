@@ -409,9 +409,9 @@ def render_sequence(model, frames, n_streams=3, **forward_kwargs):
     frames = list(frames)
     if not frames:
         return []
-    dev = next(t.device for t in _walk_tensors(frames[0]) if t.is_cuda)
+    dev = next((t.device for t in _walk_tensors(frames[0]) if t.is_cuda), None)
     n_streams = max(1, int(n_streams))
-    if n_streams == 1:
+    if n_streams == 1 or dev is None:   # (host-resident inputs: the model raises for want of a GPU, as it always does)
         with torch.no_grad():
             return [model(f, **forward_kwargs) for f in frames]
     cache = model.__dict__.setdefault("_sequence_streams", {})
