@@ -115,6 +115,8 @@ class BodyRayTracing(nn.Module):
             device = torch.device("cuda", torch.cuda.current_device())
         key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         if key not in self._ws:
+            if len(self._ws) >= 8:   # streams come and go: keep the eight most recent scratches (each is ~1 GB at 512 x 512 x 64;
+                self._ws.pop(next(iter(self._ws)))   # a dropped one returns to the pool of the stream it was allocated on)
             self._ws[key] = hip.Workspace(device)
         return self._ws[key]
 
