@@ -369,11 +369,22 @@ struct SdfNet {
 constexpr int kSdfLd = 260;   // 256 + 4
 constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
 
-// sin(pi w), cos(pi w) for w in half-revolutions, branch-free (the epilogue must stay straight-line code so
-// that the compiler can pack it into v_pk_* and interleave it): q = rint(w), r = w - q in [-1/2, 1/2] exactly,
-// sin(pi w) = (-1)^q r S(r^2), cos(pi w) = (-1)^q C(r^2); S, C minimax fits (|err| 3.4e-9 / 2.2e-10 before
-// rounding, ~1.5 ulp evaluated in fp32).  |w| >= 2^23 gives r = 0 (sin 0, cos 1): such arguments carry no
-// fractional information in fp32 any more.
+// sin(pi w), cos(pi w) for w in half-revolutions.  Default: the hardware sine / cosine of the reduced argument,
+// v_sin_f32(v_fract_f32(w / 2)) = sin(2 pi frac(w / 2)) -- measured on the MI355X against a double-precision sine over
+// |w| < 600 (tools/ubench/hw_sin_accuracy.hip, profiles/r02_hw_sin_accuracy.txt): max |error| 1.24e-7, rms 3.46e-8,
+// i.e. the rounding of the fp32 argument and result and nothing else; four VALU operations instead of eleven.
+// -DARAH_POLY_SINE: round 1's branch-free polynomial (q = rint(w), r = w - q in [-1/2, 1/2] exactly,
+// sin(pi w) = (-1)^q r S(r^2), cos(pi w) = (-1)^q C(r^2) with minimax S, C; max |error| 1.71e-7, rms 3.67e-8).
+#ifndef ARAH_POLY_SINE
+__device__ __forceinline__ float sinpi_amp(float w, float amp) {
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(0.5f * w)) * amp;
+}
+__device__ __forceinline__ void sincospi_amp(float w, float amp, float& s, float& c) {
+    const float t = __builtin_amdgcn_fractf(0.5f * w);
+    s = __builtin_amdgcn_sinf(t) * amp;
+    c = __builtin_amdgcn_cosf(t);
+}
+#else
 __device__ __forceinline__ float sinpi_amp(float w, float amp) {
     const float q = rintf(w);
     const float r = w - q;
@@ -403,6 +414,7 @@ __device__ __forceinline__ void sincospi_amp(float w, float amp, float& s, float
     s = __uint_as_float(__float_as_uint(p * r) ^ sgn);
     c = __uint_as_float(__float_as_uint(pc) ^ sgn);
 }
+#endif
 
 // FiLM-SIREN activation of 4 channels: h = amp sin(z), z = 30 (f (v + b) + phi) = pi (fw v + pw);
 // GRAD: d = dh/dv / amp = 30 f cos(z)

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-bash tools/gpu_round.sh r2c pmc 2>&1 | grep -v amdgpu.ids | head -24
-python tools/phase_clocks.py run 3 2>&1 | grep -v amdgpu.ids > gpurun_out/r2c/phase_clocks.txt
+timeout 60 tools/ubench/bin/hw_sin_accuracy | tee gpurun_out/hw_sin_accuracy.txt
+timeout 600 python -m pytest tests -m gpu -q -x --timeout=120 2>&1 | tail -4
+python tools/ab.py tools/ubench/bin/libarah_prev.so arah_release_amd/libarah_hip.so 2 2>&1 | grep -v amdgpu.ids
