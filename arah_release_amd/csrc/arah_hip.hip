@@ -226,7 +226,7 @@ __global__ void k_fold_film(const float* __restrict__ freq, const float* __restr
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 6 * 256) return;
     const int k = i >> 8;
-    const double c = 30.0 / 3.14159265358979323846;
+    const double c = kFilmScale;   // revolutions (hardware sine) or half-revolutions (-DARAH_POLY_SINE), see mlp.hpp
     const double f = freq[i];
     fw[i] = (float)(f * c);
     pw[i] = (float)((f * (double)bias[i] + (double)phase[i]) * c);

@@ -360,8 +360,8 @@ struct SdfNet {
     const float* freq;     // [6][256]
     const float* phase;    // [6][256]
     const float* b6;       // [1]
-    const float* fw;       // [6][256]  30 f / pi                 (z = pi (fw v + pw), v = W h)
-    const float* pw;       // [6][256]  30 (f b + phi) / pi
+    const float* fw;       // [6][256]  f kFilmScale             (z = 2 pi (fw v + pw) by default, v = W h)
+    const float* pw;       // [6][256]  (f b + phi) kFilmScale
     const float* fws;      // [6][256]  fw / (weight scale * kActScale) of the split layers (row 0 = fw)
     const f16x8* wps[5];   // split-packed 256x256
 };
@@ -369,22 +369,25 @@ struct SdfNet {
 constexpr int kSdfLd = 260;   // 256 + 4
 constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
 
-// sin(pi w), cos(pi w) for w in half-revolutions.  Default: the hardware sine / cosine of the reduced argument,
-// v_sin_f32(v_fract_f32(w / 2)) = sin(2 pi frac(w / 2)) -- measured on the MI355X against a double-precision sine over
-// |w| < 600 (tools/ubench/hw_sin_accuracy.hip, profiles/r02_hw_sin_accuracy.txt): max |error| 1.24e-7, rms 3.46e-8,
-// i.e. the rounding of the fp32 argument and result and nothing else; four VALU operations instead of eleven.
-// -DARAH_POLY_SINE: round 1's branch-free polynomial (q = rint(w), r = w - q in [-1/2, 1/2] exactly,
+// FiLM-SIREN argument z = 30 (f (v + b) + phi) = kFilmTurn (fw v + pw): the folded constants fw, pw (k_fold_film) carry z
+// in the unit the sine below wants.  Default: REVOLUTIONS, z = 2 pi w, and the hardware sine / cosine of the reduced
+// argument, v_sin_f32(v_fract_f32(w)) = sin(2 pi frac(w)) -- measured on the MI355X against a double-precision sine over
+// 600 half-revolutions (tools/ubench/hw_sin_accuracy.hip, profiles/r02_hw_sin_accuracy.txt): max |error| 1.24e-7, rms
+// 3.46e-8, i.e. the rounding of the fp32 argument and result and nothing else; three VALU operations instead of eleven.
+// -DARAH_POLY_SINE: round 1's branch-free polynomial on HALF-revolutions (q = rint(w), r = w - q in [-1/2, 1/2] exactly,
 // sin(pi w) = (-1)^q r S(r^2), cos(pi w) = (-1)^q C(r^2) with minimax S, C; max |error| 1.71e-7, rms 3.67e-8).
 #ifndef ARAH_POLY_SINE
+constexpr double kFilmScale = 30.0 / 6.28318530717958647692;   // fw = f kFilmScale, pw = (f b + phi) kFilmScale
 __device__ __forceinline__ float sinpi_amp(float w, float amp) {
-    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(0.5f * w)) * amp;
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(w)) * amp;
 }
 __device__ __forceinline__ void sincospi_amp(float w, float amp, float& s, float& c) {
-    const float t = __builtin_amdgcn_fractf(0.5f * w);
+    const float t = __builtin_amdgcn_fractf(w);
     s = __builtin_amdgcn_sinf(t) * amp;
     c = __builtin_amdgcn_cosf(t);
 }
 #else
+constexpr double kFilmScale = 30.0 / 3.14159265358979323846;
 __device__ __forceinline__ float sinpi_amp(float w, float amp) {
     const float q = rintf(w);
     const float r = w - q;

@@ -1,4 +1,5 @@
-// Accuracy of the hardware sine (v_sin_f32: sin(2 pi x), preceded by v_fract_f32) against a double-precision sine, next to
+// Accuracy of the hardware sine (v_sin_f32: sin(2 pi x), preceded by v_fract_f32; the product feeds it revolutions
+// directly, here x = w / 2 for a w in half-revolutions so that both candidates see the same argument) against a double-precision sine, next to
 // the product's polynomial (film_sine in csrc/mlp.hpp: half-revolutions, rint, degree-4 minimax in r^2).  The SDF trunk
 // feeds sin(30 (f (W x + b) + phi)) through six layers into a root finder with a 1e-5 m threshold: what matters is the
 // absolute error of one activation in [-1, 1].

@@ -730,7 +730,7 @@ int main(int argc, char** argv) {
     net.w0 = dev(w0);
     net.w6 = dev(w6);
     std::vector<float> fw(6 * 256), pw(6 * 256), fws(6 * 256), fr(6 * 256, 1.0f), b6(4, 0.01f);
-    const float c = 30.0f / 3.14159265f, wscale = exp2f(14.0f - ceilf(log2f(wmax)));
+    const float c = (float)kFilmScale, wscale = exp2f(14.0f - ceilf(log2f(wmax)));
     for (int i = 0; i < 6 * 256; ++i) { fw[i] = c; pw[i] = rnd() * 0.02f * c; fws[i] = i < 256 ? c : c / (wscale * kActScale); }
     net.fw = dev(fw); net.pw = dev(pw); net.fws = dev(fws); net.freq = dev(fr); net.phase = net.freq; net.bias = net.freq; net.b6 = dev(b6);
     float* p32; f16x8* ps;
