@@ -405,7 +405,7 @@ def render_sequence(model, frames, n_streams=3, **forward_kwargs):
     in flight: frame k runs on HIP stream k mod n_streams with its own scratch, so that the latency-bound stretches of one
     frame (the tails of sphere tracing and of the joint root find: a few hundred live rays, ~60 us of kernel latency per
     step) run under the other frames' wide kernels.  Per-frame results are bit-identical to one-at-a-time rendering
-    (tests/test_hip_parity.py::test_zz_render_sequence.py); 56 -> 49 ms per 512x512 frame on one
+    (tests/test_zz_render_sequence.py); 56 -> 49 ms per 512x512 frame on one
     MI355X.  frames: iterable of input dicts (resident on one GPU); returns the list of output dicts, usable on the
     caller's current stream.  The caller's stream is synchronised once at the start (see below).  model(inputs, **forward_kwargs) is called under torch.no_grad()."""
     frames = list(frames)
