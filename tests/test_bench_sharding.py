@@ -163,3 +163,20 @@ def test_bench_run_two_ranks_gloo():
     assert abs(line0["value"] - rays / t) < 1e-6 * line0["value"]
     assert 3 * 0.004 <= t < 3 * 0.004 + 0.2          # the slower rank (4 ms per frame) sets the time
     assert "workload" in line0["config"] and "model" not in line0["config"]
+
+
+def test_pipelined_extra_adds_its_object_and_leaves_the_line_alone():
+    """The frames-in-flight pass of bench.py (N = 1, after everything else): same frames as the timed region, its own
+    object, `value` untouched."""
+    import argparse
+    args = argparse.Namespace(steps=3, warmup=1, size=64, n_steps=64, pipelined_streams=3)
+    rt = _StubRuntime(1, 0)
+    line = {"value": 123.0, "ms_per_step": 4.0}
+    out = bench.pipelined_extra(args, rt, dict(line), limit_s=30.0)
+    assert out["value"] == 123.0 and out["ms_per_step"] == 4.0
+    fi = out["frames_in_flight"]
+    assert fi["streams"] == 3 and fi["unit"] == "rays/s"
+    rays = sum(1000 + f for f in (1, 2, 3))                      # frames 1..3 are the timed ones of rank 0 of 1
+    assert abs(fi["value"] - rays / (fi["ms_per_step"] * 3 / 1e3)) < 1e-6 * fi["value"]
+    # warm-up + one round of the streams, then the timed frames
+    assert rt.rendered == [0, 1, 2, 3, 1, 2, 3]
