@@ -22,12 +22,8 @@ hyperlayers.py:270-285,497-510) or only export folded weight tensors.
 The torch ``forward`` of the per-sample networks is kept because the training
 path differentiates through them with autograd.
 """
-import math
-
-import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 # SMPL kinematic tree (parent of each of the 24 joints); data, same table as
 # reference siren_modules.py:204-205.

@@ -108,7 +108,7 @@ def test_rasterize_against_oracle():
 
 @gpu
 def test_sdf_grid_matches_point_queries(scene):
-    from arah_release_amd import hip, renderer
+    from arah_release_amd import hip
     dev = torch.device("cuda:0")
     model, cfg = get_model("zju377_mono", dev)
     inputs = scene.make_inputs(32, 32, frame_idx=1, device=dev)
@@ -131,7 +131,7 @@ def test_gen_cano_mesh_branch(scene, name):
     """MetaAvatarRender.forward(inputs, gen_cano_mesh=True, eval=True) as lightning_model.py:320 calls it: the three
     normal maps, composed from the build's own pieces checked one by one (mesh on the SDF's zero set, rasteriser vs
     the oracle) -- plus what can be said without pytorch3d / skimage: silhouettes, orientation, unit normals."""
-    from arah_release_amd import meshing, training
+    from arah_release_amd import meshing
     dev = torch.device("cuda:0")
     model, cfg = get_model(name, dev)
     # the reference rasterises the posed mesh at 512 x 512 whatever the frame size (models/__init__.py:226-233): the
