@@ -278,3 +278,75 @@ def training_samples(minimal_shape_v, faces, skinning_weights, coord_min, coord_
         pts = torch.cat([pts[ok], centroids[:22]], 0)                               # :532-535 (22 body parts, no hands)
         out["points_inside"] = normalize(pts[_choose(pts.shape[0], 1024, dev, generator)])
     return out
+
+
+def training_rays(image, mask, mask_erode, bounds, K, R, T, num_fg_samples=1024, num_bg_samples=1024, generator=None):
+    """Pixel / ray sampling of a TRAINING item (zju_mocap.py:330-400, sampling == 'default') on the device of its inputs.
+
+    image (H,W,3) float in [0,1] (undistorted, resized), mask / mask_erode (H,W) integer (the eroded mask is 1 on the body,
+    0 on the background, 100 on the rim the reference leaves out); bounds (2,3) posed-body box, K (3,3) of the resized image,
+    R (3,3), T (3,).  As the reference: num_fg + 1024 pixels with mask_erode == 1 and num_bg + 1024 pixels of the projected
+    box with mask_erode == 0 are drawn without replacement, rays through them are intersected with the box, and num_fg /
+    num_bg of those that hit it are kept (the 1024 spare ones absorb rays that graze the box, near > far).  Background
+    pixels are black.  -> dict with the 'inputs*' entries of the item (leading batch dimension 1)."""
+    dev = image.device
+    H, W = mask.shape
+    K_inv = torch.linalg.inv(K)
+    cam_loc = -R.t() @ T
+    fg_sample, bg_sample = mask_erode == 1, mask_erode == 0
+
+    def pick(flat_idx, want):
+        if flat_idx.shape[0] < want:   # np.random.choice(replace=False) raises here as well
+            raise ValueError("Cannot take a larger sample than population when 'replace=False'")
+        return flat_idx[torch.randperm(flat_idx.shape[0], device=dev, generator=generator)[:want]]
+
+    fg = pick(torch.nonzero(fg_sample.reshape(-1)).reshape(-1), num_fg_samples + 1024)
+    box = bound_2d_mask(bounds, K, torch.cat([R, T.reshape(3, 1)], dim=1), H, W)
+    bg = pick(torch.nonzero((box & bg_sample).reshape(-1)).reshape(-1), num_bg_samples + 1024)
+    idx = torch.cat([fg, bg])
+    ys, xs = torch.div(idx, W, rounding_mode="floor"), idx % W
+    pixels = image[ys, xs].clone()
+    pixels[fg.shape[0]:] = 0.0
+    m = mask[ys, xs] != 0
+    me = mask_erode[ys, xs] != 0
+    homo = torch.stack([xs.float(), ys.float(), torch.ones_like(xs, dtype=torch.float32)], dim=-1)
+    uv = homo @ K_inv.t()
+    rays_cam = uv / (uv.norm(dim=-1, keepdim=True) + 1e-12)
+    rays = uv @ R
+    rays = rays / (rays.norm(dim=-1, keepdim=True) + 1e-12)
+    near, far, ok = near_far(bounds, cam_loc.expand_as(rays), rays)
+    n_fg = fg.shape[0]
+    keep_fg = pick(torch.nonzero(ok[:n_fg]).reshape(-1), num_fg_samples)
+    keep_bg = pick(torch.nonzero(ok[n_fg:]).reshape(-1), num_bg_samples) + n_fg
+    keep = torch.cat([keep_fg, keep_bg])
+    b = lambda t: t[keep].unsqueeze(0)
+    return {"inputs": b(pixels), "inputs.mask": b(m), "inputs.mask_erode": b(me), "inputs.uv": b(uv),
+            "inputs.ray_dirs": b(rays), "inputs.ray_dirs_cam": b(rays_cam),
+            "inputs.body_bounds_intersections": torch.stack([near[keep], far[keep]], dim=-1).unsqueeze(0)}
+
+
+def training_item(model, camera, body, faces, image, mask, mask_erode, img_size, orig_img_size, box_margin=0.05,
+                  num_fg_samples=1024, num_bg_samples=1024, sample_reg_surface=False, sample_inside=False,
+                  off_surface_thr=0.2, inside_thr=0.001, device="cuda", generator=None, **ids):
+    """A whole training item (ZJUMOCAPDataset.__getitem__, mode 'train', zju_mocap.py:226-600) on the device: the frame
+    composition of `frame_item`, the pixel / ray sample of `training_rays` in place of the full box, and the point sets of
+    `training_samples`.  image / mask / mask_erode: already undistorted and resized (cv2 is not part of this build)."""
+    item = frame_item(model, camera, body, img_size, orig_img_size, box_margin=box_margin, device=device, **ids)
+    f32 = lambda a: torch.as_tensor(np.asarray(a, np.float32), device=device)
+    verts = item["image.smpl_vertices"][0]
+    bounds = torch.stack([verts.min(dim=0)[0] - box_margin, verts.max(dim=0)[0] + box_margin])
+    rays = training_rays(torch.as_tensor(image, dtype=torch.float32, device=device), torch.as_tensor(mask, device=device),
+                         torch.as_tensor(mask_erode, device=device), bounds, item["image.K"][0], item["image.R"][0],
+                         item["image.T"][0], num_fg_samples, num_bg_samples, generator)
+    item.update(rays)
+    item.pop("inputs.image_mask", None)
+    item["inputs.novel_seq"] = torch.tensor([False])
+    pts = training_samples(item["image.minimal_shape"][0], torch.as_tensor(np.asarray(faces), device=device),
+                           f32(body.lbs_weights), item["image.coord_min"][0], item["image.coord_max"][0],
+                           item["image.center"][0], sample_reg_surface, sample_inside, off_surface_thr, inside_thr, generator)
+    item["image.points_uniform"] = pts["points_uniform"].unsqueeze(0)
+    item["image.points_skinning"] = pts["points_skinning"].unsqueeze(0)
+    item["image.sampled_weights"] = pts["sampled_weights"].unsqueeze(0)
+    if "points_inside" in pts:
+        item["image.points_inside"] = pts["points_inside"].unsqueeze(0)
+    return item

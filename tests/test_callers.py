@@ -253,3 +253,97 @@ def test_dataset_item_renders_on_the_device(body):
     n = inp["ray_dirs"].shape[1]
     assert tuple(out["rgb_values"].shape) == (1, n, 3) and bool(torch.isfinite(out["rgb_values"]).all())
     assert 0 < int(out["network_body_mask"].sum()) <= n
+
+
+def test_training_rays_sampling_properties():
+    """zju_mocap.py:330-400 on tensors: counts, every kept ray hits the box, foreground pixels come from the eroded body
+    mask with their colours, background pixels from the projected box outside it and black, rays through the pixels."""
+    from arah_release_amd import data
+    H = W = 256
+    K = torch.tensor([[300.0, 0, 128], [0, 300.0, 128], [0, 0, 1]])
+    R, T = torch.eye(3), torch.tensor([0.0, 0.0, 3.0])
+    bounds = torch.tensor([[-0.45, -0.95, -0.25], [0.45, 0.95, 0.25]])
+    yy, xx = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+    body = ((xx - 128).abs() < 26) & ((yy - 128).abs() < 70)
+    rim = ((xx - 128).abs() < 29) & ((yy - 128).abs() < 73) & ~body
+    me = torch.zeros(H, W, dtype=torch.int64)
+    me[body], me[rim] = 1, 100
+    mask = (body | rim).long()
+    img = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(0))
+    out = data.training_rays(img, mask, me, bounds, K, R, T, num_fg_samples=1024, num_bg_samples=512,
+                             generator=torch.Generator().manual_seed(1))
+    n = 1024 + 512
+    assert tuple(out["inputs"].shape) == (1, n, 3) and tuple(out["inputs.body_bounds_intersections"].shape) == (1, n, 2)
+    nf = out["inputs.body_bounds_intersections"][0]
+    assert bool((nf[:, 0] < nf[:, 1]).all())
+    assert bool(out["inputs.mask_erode"][0, :1024].all()) and not bool(out["inputs.mask_erode"][0, 1024:].any())
+    assert float(out["inputs"][0, 1024:].abs().max()) == 0.0
+    # the pixel behind every ray: uv = K^-1 (x, y, 1)
+    px = (out["inputs.uv"][0] @ K.t())
+    xs, ys = px[:, 0].round().long(), px[:, 1].round().long()
+    assert bool(body[ys[:1024], xs[:1024]].all())
+    torch.testing.assert_close(out["inputs"][0, :1024], img[ys[:1024], xs[:1024]])
+    box = data.bound_2d_mask(bounds, K, torch.cat([R, T.reshape(3, 1)], dim=1), H, W)
+    assert bool((box[ys[1024:], xs[1024:]] & (me[ys[1024:], xs[1024:]] == 0)).all())
+    assert len(set(zip(xs[:1024].tolist(), ys[:1024].tolist()))) == 1024           # without replacement
+    d = out["inputs.ray_dirs"][0]
+    torch.testing.assert_close(d.norm(dim=-1), torch.ones(n))
+    torch.testing.assert_close(out["inputs.ray_dirs_cam"][0], d)                      # R = identity
+    # too few foreground pixels: the reference's np.random.choice raises, so does this
+    with pytest.raises(ValueError):
+        data.training_rays(img, mask, me, bounds, K, R, T, num_fg_samples=20000, num_bg_samples=16)
+
+
+@pytest.mark.gpu
+def test_training_item_through_a_training_step(body, monkeypatch):
+    """data.training_item -> LightningModel.training_step on cuda:0: the dataset side of a training step (frame
+    composition, pixel / ray sample, regularisation point sets) feeds the model's loss and every group of parameters gets a
+    gradient.  The synthetic body has no triangle mesh, so the three point sets come from a stand-in with the sampler's
+    shapes (the sampler itself: tests/test_mesh_query.py)."""
+    from arah_release_amd import config, data
+    g = golden("f9_callers.npz")
+    dev = torch.device("cuda:0")
+    md = {k[3:]: g[k] for k in g.files if k.startswith("md.")}
+    cam = {k[4:]: g[k] for k in g.files if k.startswith("cam.")}
+    H = W = 256
+
+    def fake_samples(v, f, w, cmin, cmax, cen, reg, inside, *a, **k):
+        gen = torch.Generator(device=v.device).manual_seed(0)
+        out = {"points_uniform": torch.rand(1024, 3, device=v.device, generator=gen) * 2 - 1,
+               "points_skinning": v[:1024].clone(), "sampled_weights": w[:1024].clone()}
+        if inside:
+            out["points_inside"] = (torch.rand(1024, 3, device=v.device, generator=gen) - 0.5) * 0.2
+        return out
+
+    monkeypatch.setattr(data, "training_samples", fake_samples)
+    item0 = data.frame_item(md, cam, body, H, 64, device=dev, frame_idx=5, data_idx=1)    # the fixture's K is for 64 x 64
+    mask = item0["inputs.image_mask"][0]
+    # "segmentation": the box's pixels whose ray passes within 15 cm of a posed vertex are the body
+    d, o = item0["inputs.ray_dirs"][0], item0["image.cam_loc"][0]
+    v = item0["image.smpl_vertices"][0][::8]
+    t = ((v[None] - o) * d[:, None]).sum(-1)
+    dist = ((o + t[..., None] * d[:, None]) - v[None]).norm(dim=-1).min(dim=1)[0]
+    me = torch.zeros(H, W, dtype=torch.int64, device=dev)
+    me[mask] = (dist < 0.15).long()
+    image = torch.rand(H, W, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    n_fg = int((me == 1).sum()) - 1024
+    assert n_fg > 256, n_fg
+    item = data.training_item(md, cam, body, torch.zeros(4, 3, dtype=torch.int32), image, (me > 0).long(), me, H, 64, device=dev,
+                              num_fg_samples=256, num_bg_samples=256, sample_reg_surface=True, sample_inside=True,
+                              frame_idx=5, data_idx=1, generator=torch.Generator(device=dev).manual_seed(4))
+    assert tuple(item["inputs.ray_dirs"].shape) == (1, 512, 3) and tuple(item["image.points_uniform"].shape) == (1, 1024, 3)
+    assert "inputs.image_mask" not in item and not bool(item["inputs.novel_seq"][0])
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=4)
+    lm.model.load_state_dict(config.synthetic_state_dict(cfg), strict=False)
+    lm = lm.to(dev).train()
+    lm.model.frames = []
+    loss = lm.training_step(item)
+    assert torch.isfinite(loss)
+    loss.backward()
+    groups = {"sdf_decoder": 0, "skinning_model": 0, "color_decoder": 0, "deviation_decoder": 0}
+    for name, p in lm.model.named_parameters():
+        for k in groups:
+            if name.startswith(k) and p.grad is not None and float(p.grad.abs().sum()) > 0:
+                groups[k] += 1
+    assert all(vv > 0 for vv in groups.values()), groups

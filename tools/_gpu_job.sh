@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2
+timeout 150 python -m pytest tests/test_callers.py -m gpu -q -x --timeout=100 2>&1 | grep -v amdgpu.ids | tail -25
