@@ -218,12 +218,7 @@ class LightningModel(nn.Module):
 
     def configure_optimizers(self):
         from . import training
-        opt = training.configure_optimizers(self.model, self.cfg)
-        if self.model.train_cameras:
-            opt.add_param_group({"params": list(self.model.camera_parameters()), "lr": 1e-4})     # lightning_model.py:431-437
-        if self.model.train_smpl:
-            opt.add_param_group({"params": list(self.model.smpl_parameters()), "lr": 1e-4})       # :440-446
-        return opt
+        return training.configure_optimizers(self.model, self.cfg)
 
     def compose_inputs(self, data, eval):
         """lightning_model.py:463-634, tensor for tensor; everything stays on the device `data` lives on."""

@@ -362,8 +362,9 @@ def build_loss(cfg, perceptual_loss_fn=None):
 
 
 def configure_optimizers(model, cfg):
-    """Adam with the reference's parameter groups and learning rates (lightning_model.py:403-461)."""
-    t = cfg["training"]
+    """Adam with the reference's parameter groups, in the reference's ORDER (an optimiser state dict addresses groups by
+    position) and with its learning rates (lightning_model.py:403-461)."""
+    t, m = cfg["training"], cfg["model"]
     lr = t["lr"]
     groups = [{"params": model.sdf_decoder.net.layers.parameters(), "lr": lr},
               {"params": model.sdf_decoder.pose_encoder.parameters(), "lr": lr * t["pose_net_factor"]},
@@ -371,8 +372,12 @@ def configure_optimizers(model, cfg):
               {"params": model.deviation_decoder.parameters(), "lr": 1e-4}]
     if t["train_skinning_net"]:
         groups.append({"params": model.skinning_model.parameters(), "lr": t["skinning_lr"]})
-    if hasattr(model, "latent"):
-        groups.append({"params": model.latent.parameters(), "lr": 1e-4, "weight_decay": 0.05})
+    if m.get("train_cameras"):
+        groups.append({"params": model.camera_parameters(), "lr": 1e-4})                      # :434-440
+    if m.get("train_smpl"):
+        groups.append({"params": model.smpl_parameters(), "lr": 1e-4})                        # :442-448
+    if m.get("color_pose_encoder") in ("hybrid", "latent") or m.get("geo_pose_encoder") in ("latent",):
+        groups.append({"params": model.latent.parameters(), "lr": 1e-4, "weight_decay": 0.05})   # :450-457
     return torch.optim.Adam(params=groups)
 
 

@@ -348,7 +348,46 @@ def make_f10():
     print("wrote f10_mesh_contains.npz: %d verts, %d faces, %d points, %d inside" % (len(verts), len(faces), len(pts), int(contains.sum())))
 
 
+def make_f11():
+    """F11: the optimiser LightningModel.configure_optimizers builds (lightning_model.py:403-461): per parameter group
+    its learning rate, weight decay, number of tensors and number of elements, in order -- plain ZJUMOCAP-313, and with
+    optimised SMPL parameters and cameras (registered as in make_f9: the constructor needs the SMPL files)."""
+    import json
+    import torch.nn as nn
+    from im2mesh.metaavatar_render import lightning_model as ref_lm
+    cfg = ref_config.load_config(REF_CFG["zju313"], "configs/default.yaml")
+    sd = my_config.synthetic_state_dict(my_config.builtin_config("zju313"))
+    fake = "/tmp/arah_fake_ckpt_f11.ckpt"
+    torch.save({"state_dict": {"model.latent.weight": sd["latent.weight"]}}, fake)
+    out = {}
+    for tag, flags in (("plain", (False, False)), ("smpl_cameras", (True, True))):
+        cfg["model"]["train_smpl"], cfg["model"]["train_cameras"] = False, False
+        model = ref_render_config.get_model(cfg, mode="test", checkpoint_path=fake)
+        if flags[0]:
+            model.train_smpl = model.train_cameras = True
+            pd = {"%s_%d" % (k, fr): nn.Parameter(torch.zeros(n)) for fr in (4, 5)
+                  for k, n in (("root_orient", 3), ("pose_body", 63), ("pose_hand", 6), ("trans", 3))}
+            model.body_poses = nn.ParameterDict(pd)
+            model.register_parameter("betas", nn.Parameter(torch.zeros(1, 10)))
+            model.register_parameter("cam_rots", nn.Parameter(torch.zeros(2, 4)))
+            model.register_parameter("cam_trans", nn.Parameter(torch.zeros(2, 3)))
+        cfg["model"]["train_smpl"], cfg["model"]["train_cameras"] = flags
+        lm = ref_lm.LightningModel.__new__(ref_lm.LightningModel)
+        nn.Module.__init__(lm)
+        lm.model, lm.cfg = model, cfg
+        opt = lm.configure_optimizers()
+        out[tag] = [{"lr": g["lr"], "weight_decay": g["weight_decay"], "tensors": len(g["params"]),
+                     "elements": int(sum(p.numel() for p in g["params"]))} for g in opt.param_groups]
+        out[tag + "_adam"] = {k: (list(v) if isinstance(v, tuple) else v) for k, v in opt.defaults.items()
+                              if k in ("lr", "betas", "eps", "weight_decay", "amsgrad")}
+    with open(os.path.join(HERE, "f11_optimizer_groups.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote f11_optimizer_groups.json", {k: len(v) for k, v in out.items()})
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f11":
+        return make_f11()
     if len(sys.argv) > 1 and sys.argv[1] == "f10":
         return make_f10()
     if len(sys.argv) > 1 and sys.argv[1] == "f9":

@@ -197,7 +197,7 @@ def test_train_smpl_construction_from_a_dataset(tmp_path, scene, body):
     assert m.frames == [10, 11, 12] and m.latent.num_embeddings == 3
     assert set(m.body_poses.keys()) == {"%s_%d" % (k, f) for k in ("root_orient", "pose_body", "pose_hand", "trans") for f in (10, 11, 12)}
     assert float(m.body_poses["root_orient_10"].detach().abs().max()) == pytest.approx(1e-8)       # zero rotation got its nudge
-    assert float(m.body_poses["trans_12"][2]) == 5.0 and tuple(m.betas.shape) == (1, 10)
+    assert float(m.body_poses["trans_12"].detach()[2]) == 5.0 and tuple(m.betas.shape) == (1, 10)
     np.testing.assert_allclose(m.cam_rots[1].detach().numpy(), Rotation.from_rotvec([0, 0.3, 0]).as_quat(), atol=1e-6)
     assert len(list(m.smpl_parameters())) == 13 and len(list(m.camera_parameters())) == 2
     n_all = len(list(m.parameters()))
@@ -347,3 +347,37 @@ def test_training_item_through_a_training_step(body, monkeypatch):
             if name.startswith(k) and p.grad is not None and float(p.grad.abs().sum()) > 0:
                 groups[k] += 1
     assert all(vv > 0 for vv in groups.values()), groups
+
+
+def test_optimizer_groups_against_reference(body):
+    """LightningModel.configure_optimizers: the reference's parameter groups in the reference's order (fixture F11: learning
+    rate, weight decay, number of tensors and elements per group; Adam defaults) -- an optimiser state dict of the reference
+    addresses groups by position."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from arah_release_amd import config, renderer
+    ref = json.load(open(os.path.join(GOLDEN, "f11_optimizer_groups.json")))
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=4)
+    m = lm.model
+
+    def groups(opt):
+        return [{"lr": g["lr"], "weight_decay": g["weight_decay"], "tensors": len(g["params"]),
+                 "elements": int(sum(p.numel() for p in g["params"]))} for g in opt.param_groups]
+
+    opt = lm.configure_optimizers()
+    assert groups(opt) == ref["plain"]
+    for k, v in ref["plain_adam"].items():
+        got = opt.defaults[k]
+        assert (list(got) if isinstance(got, tuple) else got) == v, k
+    # optimised SMPL parameters and cameras: two frames, two cameras (as the fixture registered them)
+    kw = dict(frames=[4, 5], betas=np.zeros((1, 10), np.float32), body_model=body, cam_rots=np.zeros((2, 4), np.float32),
+              cam_trans=np.zeros((2, 3), np.float32), n_data_points=4)
+    for key, n in (("root_orient", 3), ("pose_body", 63), ("pose_hand", 6), ("trans", 3)):
+        kw[key] = [np.zeros(n, np.float32), np.zeros(n, np.float32)]
+    lm.model = renderer.MetaAvatarRender(m.sdf_decoder, m.skinning_model, m.color_decoder, m.deviation_decoder,
+                                         train_cameras=True, train_smpl=True, train_latent_code=True,
+                                         train_geo_latent_code=True, **kw)
+    cfg["model"].update(train_smpl=True, train_cameras=True)
+    assert groups(lm.configure_optimizers()) == ref["smpl_cameras"]
