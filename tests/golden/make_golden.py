@@ -385,7 +385,23 @@ def make_f11():
     print("wrote f11_optimizer_groups.json", {k: len(v) for k, v in out.items()})
 
 
+def make_f12():
+    """F12: what the reference's load_config makes of its own YAML files (recursive inherit_from + configs/default.yaml,
+    im2mesh/config.py:12-56) for the three configurations the build restates in builtin_config: the merged 'model',
+    'training' and 'data' sections as plain JSON."""
+    import json
+    out = {}
+    for name, path in REF_CFG.items():
+        cfg = ref_config.load_config(path, "configs/default.yaml")
+        out[name] = {sec: cfg.get(sec, {}) for sec in ("method", "model", "training", "data")}
+    with open(os.path.join(HERE, "f12_merged_configs.json"), "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote f12_merged_configs.json", list(out))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f12":
+        return make_f12()
     if len(sys.argv) > 1 and sys.argv[1] == "f11":
         return make_f11()
     if len(sys.argv) > 1 and sys.argv[1] == "f10":
