@@ -399,7 +399,47 @@ def make_f12():
     print("wrote f12_merged_configs.json", list(out))
 
 
+def make_f13():
+    """F13: the reference's IDHRLoss (renderer/loss.py) on random model outputs -- every term in isolation from the forward
+    pass: three pixel-loss types, the boundary value 100 of the body mask, empty hit / off-surface masks, more than 2048
+    rays (the patch tail is ignored by every term but the perceptual one, whose weight is 0: LPIPS is not available)."""
+    from im2mesh.metaavatar_render.renderer.loss import IDHRLoss
+    g = torch.Generator().manual_seed(77)
+    cases = {}
+    for ci, (kind, n_rays, empty_hit, empty_off, boundary) in enumerate((("l1", 2048, False, False, False),
+                                                                           ("mse", 2048, False, False, True),
+                                                                           ("smoothed_l1", 2100, False, False, True),
+                                                                           ("l1", 512, True, False, False),
+                                                                           ("l1", 512, False, True, False))):
+        crit = IDHRLoss(1.0, 0.0, 0.1, 0.5, 0.3, 0.2, 1e-3, 10.0, rgb_loss_type=kind, perceptual_loss_fn=None)
+        hit = torch.rand(1, n_rays, generator=g) > (2.0 if empty_hit else 0.4)
+        body = (torch.rand(1, n_rays, generator=g) > 0.5).long()
+        if boundary:
+            body[0, ::7] = 100
+        off = torch.rand(1, n_rays, generator=g) > (2.0 if empty_off else 0.6)
+        out = {"rgb_values": torch.rand(1, n_rays, 3, generator=g), "network_body_mask": hit, "body_mask": body,
+               "off_surface_mask": off, "sdf_output": torch.rand(1, min(n_rays, 2048), 1, generator=g),   # the mask term indexes it with a 2048-ray mask
+               "grad_theta": torch.randn(1500, 3, generator=g), "off_surface_sdf": torch.rand(1, 1024, 1, generator=g) * 0.1,
+               "inside_sdf": torch.randn(1024, 1, generator=g) * 1e-3,
+               "sdf_params": [torch.randn(1, 1000 + 10 * k, generator=g) * 0.01 for k in range(3)],
+               "pred_weights": torch.softmax(torch.randn(1, 1024, 24, generator=g), -1),
+               "surface_normals": None}          # read by the reference's forward, used by no term
+        gt = {"rgb": torch.rand(1, n_rays, 3, generator=g), "sampled_weights": torch.softmax(torch.randn(1, 1024, 24, generator=g), -1)}
+        with torch.no_grad():
+            res = crit(out, gt)
+        rec = {"kind": np.array(kind), "n_sdf_params": np.array(3)}
+        rec.update({"out." + k: v.numpy() for k, v in out.items() if torch.is_tensor(v)})
+        rec.update({"out.sdf_params_%d" % k: v.numpy() for k, v in enumerate(out["sdf_params"])})
+        rec.update({"gt." + k: v.numpy() for k, v in gt.items()})
+        rec.update({"res." + k: np.asarray(v.detach().numpy(), np.float64) for k, v in res.items()})
+        cases.update({"c%d.%s" % (ci, k): v for k, v in rec.items()})
+    np.savez_compressed(os.path.join(HERE, "f13_idhr_loss.npz"), **cases)
+    print("wrote f13_idhr_loss.npz", sorted({k.split(".", 1)[1] for k in cases if k.startswith("c0.res.")}))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f13":
+        return make_f13()
     if len(sys.argv) > 1 and sys.argv[1] == "f12":
         return make_f12()
     if len(sys.argv) > 1 and sys.argv[1] == "f11":
