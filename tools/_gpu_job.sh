@@ -1,9 +1,11 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/r2g
-timeout 200 python bench.py --size 1024 --n-steps 128 --config h36m --steps 3 --warmup 1 --no-cpu-baseline --passes default --no-train > gpurun_out/r2g/bench_config5.json 2>/dev/null
-timeout 120 python bench.py --size 256 --n-steps 32 --steps 8 --warmup 2 --no-cpu-baseline --passes default --no-train > gpurun_out/r2g/bench_config1.json 2>/dev/null
-python - <<PY
-import json
-for c in ("5","1"):
-    d=json.load(open("gpurun_out/r2g/bench_config%s.json" % c)); print(c, d["value"], d["ms_per_step"], d.get("frames_in_flight",{}).get("value"), d.get("frames_in_flight",{}).get("ms_per_step"))
-PY
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/r2h; mkdir -p $OUT
+timeout 120 python tools/train_bench.py --steps 8 --warmup 2 2>/dev/null | cut -c1-220
+cd /tmp
+timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prof -o kt -- python $GRAFT_REPO_ROOT/tools/train_bench.py --steps 5 --warmup 2 > $OUT/train.json 2> $OUT/prof.err
+cd $GRAFT_REPO_ROOT
+DB=$(find $OUT/prof -name "*.db" | head -1)
+python tools/rocpd_stats.py $DB > $OUT/train_kernel_stats.txt
+head -12 $OUT/train_kernel_stats.txt | cut -c1-130; tail -1 $OUT/train_kernel_stats.txt
+rm -rf $OUT/prof
