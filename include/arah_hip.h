@@ -29,6 +29,10 @@
  *   arah_rasterize          pytorch3d MeshRasterizer (pix_to_face) as used at metaavatar_render/models/__init__.py:232-276
  *   arah_shade_train_*      get_rbg_value_vol_sdf with self.training: per-sample forward and backward
  *                           renderer/implicit_differentiable_renderer.py:291-361, diff_operators.py:39-50
+ *   arah_gram_skinny        the matmul backward of autograd for the 1- / 3-row heads and the K = 3 first layer
+ *                           (weight gradients summed over ~1e5 samples)
+ *   arah_mesh_query         check_mesh_contains + igl.point_mesh_squared_distance + igl.barycentric_coordinates_tri
+ *                           im2mesh/utils/libmesh/inside_mesh.py:4-160, im2mesh/data/zju_mocap.py:466-529
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless its name starts with "h_"; the caller owns all
