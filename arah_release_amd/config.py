@@ -331,10 +331,37 @@ class LightningModel(nn.Module):
         return self.render_image(data, gen_cano_mesh=False)
 
     def test_step(self, data, data_idx=None):
+        """lightning_model.py:306-338: the frame's image and the three normal maps of the canonical mesh, channels first
+        (keys rgb_pred / normal_pred / normal_front / normal_back, as test_epoch_end takes them)."""
         if not isinstance(data, dict) or "inputs.ray_dirs" not in data:   # already-composed model inputs
             with torch.no_grad():
                 return self.model(data, gen_cano_mesh=False, eval=True)
-        return self.render_image(data, gen_cano_mesh=True)                # lightning_model.py:320
+        out = self.render_image(data, gen_cano_mesh=True)                 # lightning_model.py:320
+        return {"rgb_pred": out["image"].squeeze(0).permute(2, 0, 1),
+                "normal_pred": out["output_normal"].squeeze(0).permute(2, 0, 1),
+                "normal_front": out["normal_cano_front"].squeeze(0).permute(2, 0, 1),
+                "normal_back": out["normal_cano_back"].squeeze(0).permute(2, 0, 1)}
+
+    def test_epoch_end(self, test_step_outputs, first_index=0, index_stride=1, clear=True):
+        """lightning_model.py:351-401 without the Lightning all_gather: writes rgb_ / normal_ / front_ / back_%06d.png into
+        <out_dir>/vis (PNG through PIL; the reference's imageio and its vis.mp4 are not part of this build).  A rank of a
+        frame-sharded run passes first_index = rank, index_stride = world size and clear = (rank == 0)."""
+        import shutil
+        import numpy as np
+        from PIL import Image
+        vis_dir = os.path.join(self.cfg["training"]["out_dir"], "vis")
+        if clear and os.path.exists(vis_dir):
+            shutil.rmtree(vis_dir)
+        os.makedirs(vis_dir, exist_ok=True)
+        written = []
+        for k, out in enumerate(test_step_outputs):
+            idx = first_index + k * index_stride
+            for name, key in (("rgb", "rgb_pred"), ("normal", "normal_pred"), ("front", "normal_front"), ("back", "normal_back")):
+                img = (out[key].permute(1, 2, 0).detach().cpu().numpy() * 255.0).astype(np.uint8)   # the reference's cast
+                path = os.path.join(vis_dir, "%s_%06d.png" % (name, idx))
+                Image.fromarray(img).save(path)
+                written.append(path)
+        return written
 
 
 class _Method:

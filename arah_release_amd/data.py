@@ -350,3 +350,51 @@ def training_item(model, camera, body, faces, image, mask, mask_erode, img_size,
     if "points_inside" in pts:
         item["image.points_inside"] = pts["points_inside"].unsqueeze(0)
     return item
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the out-of-distribution-pose test dataset (reference ZJUMOCAPODPDataset, data/zju_mocap_odp.py:20-120) and its factory
+# ---------------------------------------------------------------------------------------------------------------------
+class SequenceDataset:
+    """<dataset_folder>/<subject>/cam_params.json + <dataset_folder>/<subject>/<pose_dir>/*.npz, enumerated camera-major
+    like the reference (``.cameras``, ``.cam_names``, ``.data`` -- what get_model(cfg, dataset=...) reads); ``item(idx,
+    device)`` composes the frame on the device instead of in a numpy worker."""
+
+    def __init__(self, dataset_folder, subjects, pose_dir, body, img_size=(512, 512), orig_img_size=(1024, 1024),
+                 sampling_rate=1, start_frame=0, end_frame=-1, views=(), box_margin=0.05):
+        if len(subjects) != 1:
+            raise AssertionError("one subject per dataset, like the reference (zju_mocap_odp.py:81)")
+        self.body, self.img_size, self.orig_img_size, self.box_margin = body, tuple(img_size), tuple(orig_img_size), box_margin
+        subject_dir = os.path.join(dataset_folder, subjects[0])
+        self.cameras = load_cam_params(os.path.join(subject_dir, "cam_params.json"))
+        self.cam_names = list(views) if len(views) else list(self.cameras["all_cam_names"])
+        for c in self.cam_names:
+            if c not in self.cameras:
+                raise KeyError("camera %r is not in %s" % (c, os.path.join(subject_dir, "cam_params.json")))
+        frames, files = list_sequence(subject_dir, pose_dir, start_frame, end_frame, sampling_rate)
+        if not files:
+            raise FileNotFoundError("no *.npz under %s" % os.path.join(subject_dir, pose_dir))
+        self.data = [{"subject": subjects[0], "gender": "neutral", "cam_idx": ci, "cam_name": c, "frame_idx": f, "data_idx": d,
+                      "model_file": mf} for ci, c in enumerate(self.cam_names) for d, (f, mf) in enumerate(zip(frames, files))]
+
+    def __len__(self):
+        return len(self.data)
+
+    def item(self, idx, device):
+        d = self.data[idx]
+        return frame_item(load_model_npz(d["model_file"]), self.cameras[d["cam_name"]], self.body, self.img_size,
+                          self.orig_img_size, box_margin=self.box_margin, device=device, cam_idx=d["cam_idx"],
+                          frame_idx=d["frame_idx"], data_idx=d["data_idx"], gender=d["gender"])
+
+
+def get_dataset(mode, cfg, body):
+    """im2mesh.config.get_dataset for dataset type 'zju_mocap_odp' (reference im2mesh/config.py:78-262): split, views and
+    frame range of `mode` from cfg['data'], 1024 -> 512 images."""
+    d = cfg["data"]
+    if d["dataset"] != "zju_mocap_odp":
+        raise ValueError('Invalid dataset "%s" (this build reads the pose-sequence format zju_mocap_odp)' % d["dataset"])
+    if mode not in ("train", "val", "test"):
+        raise ValueError("Invalid mode %r" % mode)
+    return SequenceDataset(d["path"], d[mode + "_split"], d["pose_dir"], body, img_size=(512, 512), orig_img_size=(1024, 1024),
+                           sampling_rate=d[mode + "_subsampling_rate"], start_frame=d[mode + "_start_frame"],
+                           end_frame=d[mode + "_end_frame"], views=d[mode + "_views"], box_margin=d["box_margin"])

@@ -381,3 +381,141 @@ def test_optimizer_groups_against_reference(body):
                                          train_geo_latent_code=True, **kw)
     cfg["model"].update(train_smpl=True, train_cameras=True)
     assert groups(lm.configure_optimizers()) == ref["smpl_cameras"]
+
+
+def test_test_epoch_end_writes_the_references_files(tmp_path):
+    """lightning_model.py:351-401: rgb_ / normal_ / front_ / back_%06d.png under <out_dir>/vis, uint8 by truncation of
+    value * 255, an existing vis directory replaced; a frame-sharded rank writes its own indices."""
+    from PIL import Image
+    from arah_release_amd import config
+    cfg = config.builtin_config("zju313")
+    cfg["training"]["out_dir"] = str(tmp_path / "run")
+    lm = config.get_model(cfg, mode="test", n_data_points=2)
+    g = torch.Generator().manual_seed(0)
+    outs = [{k: torch.rand(3, 8, 6, generator=g) for k in ("rgb_pred", "normal_pred", "normal_front", "normal_back")} for _ in range(3)]
+    os.makedirs(tmp_path / "run" / "vis")
+    (tmp_path / "run" / "vis" / "stale.png").write_bytes(b"x")
+    files = lm.test_epoch_end(outs)
+    assert len(files) == 12 and not (tmp_path / "run" / "vis" / "stale.png").exists()
+    assert sorted(os.listdir(tmp_path / "run" / "vis"))[:3] == ["back_000000.png", "back_000001.png", "back_000002.png"]
+    img = np.asarray(Image.open(tmp_path / "run" / "vis" / "rgb_000001.png"))
+    want = (outs[1]["rgb_pred"].permute(1, 2, 0).numpy() * 255.0).astype(np.uint8)
+    assert img.shape == (8, 6, 3)
+    np.testing.assert_array_equal(img, want)
+    # rank 1 of 2: frames 1, 3, 5 -- and it must not wipe rank 0's files
+    lm.test_epoch_end(outs, first_index=1, index_stride=2, clear=False)
+    names = set(os.listdir(tmp_path / "run" / "vis"))
+    assert {"rgb_000003.png", "rgb_000005.png", "rgb_000000.png", "rgb_000002.png"} <= names
+
+
+@pytest.mark.gpu
+def test_test_step_on_a_dataset_item(body):
+    """LightningModel.test_step(item) as the reference's trainer.test calls it (lightning_model.py:306-338): the image and
+    the three normal maps of the canonical mesh, channels first."""
+    from arah_release_amd import config, data
+    g = golden("f9_callers.npz")
+    dev = torch.device("cuda:0")
+    md = {k[3:]: g[k] for k in g.files if k.startswith("md.")}
+    cam = {k[4:]: g[k] for k in g.files if k.startswith("cam.")}
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=4)
+    lm.model.load_state_dict(config.synthetic_state_dict(cfg), strict=False)
+    lm = lm.to(dev).eval()
+    lm.model.frames = []
+    item = data.frame_item(md, cam, body, 512, 64, device=dev, frame_idx=5, data_idx=1)   # the fixture's K is for 64 x 64
+    out = lm.test_step(item)
+    assert set(out) == {"rgb_pred", "normal_pred", "normal_front", "normal_back"}
+    for k, v in out.items():
+        assert tuple(v.shape) == (3, 512, 512) and bool(torch.isfinite(v).all()), k
+        assert 0.0 <= float(v.min()) and float(v.max()) <= 1.0 + 1e-6
+    mask = item["inputs.image_mask"][0]
+    assert float(out["rgb_pred"][:, ~mask].abs().max()) == 0.0           # outside the projected box nothing is written
+    assert float(out["rgb_pred"].sum()) > 0.0
+
+
+def _write_sequence(root, scene, n_frames=4):
+    """<root>/data/odp/CoreView_000/{cam_params.json, seq/*.npz} in the reference's formats."""
+    sub = os.path.join(root, "data", "odp", "CoreView_000")
+    os.makedirs(os.path.join(sub, "seq"))
+    rng = np.random.RandomState(0)
+    for f in range(n_frames):
+        fr = scene.frame(f)
+        np.savez(os.path.join(sub, "seq", "%06d.npz" % f), minimal_shape=scene.verts_cano, betas=np.zeros((1, 10), np.float32),
+                 Jtr_posed=fr["joints_posed"], bone_transforms=fr["bone_transforms"], trans=np.array([0.0, 0.0, 3.0], np.float32),
+                 root_orient=rng.randn(3).astype(np.float32) * 0.1, pose_body=rng.randn(63).astype(np.float32) * 0.1,
+                 pose_hand=np.zeros(6, np.float32))
+    K = [[1228.8, 0, 512], [0, 1228.8, 512], [0, 0, 1]]
+    cams = {"all_cam_names": ["1", "2"], "1": {"K": K, "D": [0] * 5, "R": np.eye(3).tolist(), "T": [[0], [0], [0.2]]},
+            "2": {"K": K, "D": [0] * 5, "R": np.eye(3).tolist(), "T": [[0.1], [0], [0.3]]}}
+    with open(os.path.join(sub, "cam_params.json"), "w") as f:
+        json.dump(cams, f)
+    return sub
+
+
+def test_sequence_dataset_and_cli_surface(tmp_path, scene, body):
+    """The test dataset of test.py (ZJUMOCAPODPDataset: camera-major enumeration, frame slicing, the fields get_model reads)
+    and the command line of arah_release_amd.test_sequence: test.py's arguments and its overrides of the configuration."""
+    from arah_release_amd import data, test_sequence
+    _write_sequence(str(tmp_path), scene)
+    cfg = {"data": {"dataset": "zju_mocap", "path": "elsewhere", "pose_dir": "x", "box_margin": 0.05, "test_split": ["CoreView_000"],
+                    "test_views": ["9"], "test_subsampling_rate": 1, "test_start_frame": 0, "test_end_frame": 0}}
+    args = test_sequence.build_parser().parse_args(["cfg.yaml", "--pose-dir", "seq", "--test-views", "2,1", "--subsampling-rate", "2",
+                                                   "--start-frame", "1"])
+    cfg = test_sequence.apply_overrides(cfg, args)
+    assert cfg["data"]["dataset"] == "zju_mocap_odp" and cfg["data"]["path"] == "data/odp" and cfg["data"]["test_views"] == ["2", "1"]
+    cfg["data"]["path"] = os.path.join(str(tmp_path), "data", "odp")
+    ds = data.get_dataset("test", cfg, body)
+    assert ds.cam_names == ["2", "1"] and len(ds) == 4
+    assert [(d["cam_idx"], d["frame_idx"], d["data_idx"]) for d in ds.data] == [(0, 1, 0), (0, 3, 1), (1, 1, 0), (1, 3, 1)]
+    item = ds.item(2, "cpu")
+    assert tuple(item["inputs.image_mask"].shape) == (1, 512, 512) and int(item["inputs.cam_idx"]) == 1
+    np.testing.assert_allclose(item["image.K"][0, 0, 0].item(), 1228.8 / 1024 * 512, rtol=1e-6)     # 1024 -> 512 images
+    with pytest.raises(KeyError):
+        cfg["data"]["test_views"] = ["5"]
+        data.get_dataset("test", cfg, body)
+    cfg["data"]["test_views"] = []
+    assert data.get_dataset("test", cfg, body).cam_names == ["1", "2"]
+    cfg["data"]["pose_dir"] = "missing"
+    with pytest.raises(FileNotFoundError):
+        data.get_dataset("test", cfg, body)
+    cfg["data"]["dataset"] = "zju_mocap"
+    with pytest.raises(ValueError):
+        data.get_dataset("test", cfg, body)
+
+
+@pytest.mark.gpu
+def test_test_sequence_end_to_end(tmp_path, scene, body):
+    """python -m arah_release_amd.test_sequence on a synthetic subject written in the reference's on-disk formats: the
+    checkpoint under <out_dir>/checkpoints/last.ckpt, two cameras x two frames, four PNGs per frame under <out_dir>/vis."""
+    import yaml
+    from PIL import Image
+    from arah_release_amd import config, test_sequence
+    _write_sequence(str(tmp_path), scene, n_frames=3)
+    cfg = config.builtin_config("zju313")
+    cfg["training"]["out_dir"] = str(tmp_path / "out")
+    cfg["data"] = {"dataset": "zju_mocap", "path": "unused", "pose_dir": "unused", "box_margin": 0.05,
+                   "test_split": ["CoreView_000"], "test_views": [], "test_subsampling_rate": 1, "test_start_frame": 0,
+                   "test_end_frame": 0}
+    os.makedirs(tmp_path / "out" / "checkpoints")
+    sd = {"model." + k: v for k, v in config.synthetic_state_dict(cfg).items()}
+    sd["model.latent.weight"] = torch.zeros(4, cfg["model"]["latent_dim"])
+    torch.save({"state_dict": sd}, tmp_path / "out" / "checkpoints" / "last.ckpt")
+    (tmp_path / "cfg.yaml").write_text(yaml.safe_dump(cfg))
+    with pytest.raises(FileNotFoundError):
+        bad = dict(cfg, training=dict(cfg["training"], out_dir=str(tmp_path / "nowhere")))
+        (tmp_path / "bad.yaml").write_text(yaml.safe_dump(bad))
+        test_sequence.main([str(tmp_path / "bad.yaml"), "--default-config", str(tmp_path / "bad.yaml")], body=body)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)             # test.py overrides cfg['data']['path'] with the relative 'data/odp'
+    try:
+        test_sequence.main([str(tmp_path / "cfg.yaml"), "--default-config", str(tmp_path / "cfg.yaml"), "--pose-dir", "seq",
+                            "--test-views", "1,2", "--subsampling-rate", "2"], body=body)
+    finally:
+        os.chdir(cwd)
+    vis = tmp_path / "out" / "vis"
+    names = sorted(os.listdir(vis))
+    assert len(names) == 16 and names[0] == "back_000000.png" and "rgb_000003.png" in names      # 2 cameras x frames 0, 2
+    rgb = np.asarray(Image.open(vis / "rgb_000001.png"))
+    front = np.asarray(Image.open(vis / "front_000001.png"))
+    assert rgb.shape == (512, 512, 3) and rgb.max() > 0
+    assert front.shape == (512, 512, 3) and len(np.unique(front.reshape(-1, 3), axis=0)) > 100
