@@ -360,11 +360,18 @@ class SequenceDataset:
     like the reference (``.cameras``, ``.cam_names``, ``.data`` -- what get_model(cfg, dataset=...) reads); ``item(idx,
     device)`` composes the frame on the device instead of in a numpy worker."""
 
-    def __init__(self, dataset_folder, subjects, pose_dir, body, img_size=(512, 512), orig_img_size=(1024, 1024),
-                 sampling_rate=1, start_frame=0, end_frame=-1, views=(), box_margin=0.05):
+    def __init__(self, dataset_folder, subjects, pose_dir, body=None, mode="test", orig_img_size=(1024, 1024), img_size=(512, 512),
+                 num_fg_samples=1024, num_bg_samples=1024, sampling_rate=1, start_frame=0, end_frame=-1, views=(),
+                 box_margin=0.05, body_models="body_models/misc"):
+        """The reference's keyword arguments (zju_mocap_odp.py:24-38; mode / num_*_samples are accepted and unused, as
+        there); body: smpl.BodyModel, default the neutral SMPL model under `body_models` like the reference (:40-58)."""
         if len(subjects) != 1:
             raise AssertionError("one subject per dataset, like the reference (zju_mocap_odp.py:81)")
-        self.body, self.img_size, self.orig_img_size, self.box_margin = body, tuple(img_size), tuple(orig_img_size), box_margin
+        if body is None:
+            body = smpl.BodyModel.from_files("neutral", body_models)
+        as2 = lambda v: (int(v), int(v)) if np.isscalar(v) else tuple(v)
+        self.mode = mode
+        self.body, self.img_size, self.orig_img_size, self.box_margin = body, as2(img_size), as2(orig_img_size), box_margin
         subject_dir = os.path.join(dataset_folder, subjects[0])
         self.cameras = load_cam_params(os.path.join(subject_dir, "cam_params.json"))
         self.cam_names = list(views) if len(views) else list(self.cameras["all_cam_names"])
@@ -379,6 +386,11 @@ class SequenceDataset:
 
     def __len__(self):
         return len(self.data)
+
+    def __getitem__(self, idx):
+        """Host-resident item WITH the leading batch dimension of 1 (use DataLoader(batch_size=None)); `item(idx, device)`
+        composes the same dict directly on the GPU."""
+        return self.item(idx, "cpu")
 
     def item(self, idx, device):
         d = self.data[idx]
@@ -395,6 +407,6 @@ def get_dataset(mode, cfg, body):
         raise ValueError('Invalid dataset "%s" (this build reads the pose-sequence format zju_mocap_odp)' % d["dataset"])
     if mode not in ("train", "val", "test"):
         raise ValueError("Invalid mode %r" % mode)
-    return SequenceDataset(d["path"], d[mode + "_split"], d["pose_dir"], body, img_size=(512, 512), orig_img_size=(1024, 1024),
+    return SequenceDataset(d["path"], d[mode + "_split"], d["pose_dir"], body=body, mode=mode, img_size=(512, 512), orig_img_size=(1024, 1024),
                            sampling_rate=d[mode + "_subsampling_rate"], start_frame=d[mode + "_start_frame"],
                            end_frame=d[mode + "_end_frame"], views=d[mode + "_views"], box_margin=d["box_margin"])

@@ -22,6 +22,15 @@ def test_import_paths_and_signatures():
         ["self", "deviation_network", "rendering_network", "skinning_model", "ray_tracer", "cano_view_dirs",
          "train_skinning_net", "render_last_pt", "low_vram"]
     assert set(decoder_dict) >= {"hyper_bvp", "deformer_mlp"}
+    # the harness and the test dataset under the reference's names (lightning_model.py:101, data/zju_mocap_odp.py:20-38)
+    from im2mesh import data
+    from im2mesh.metaavatar_render.lightning_model import LightningModel
+    for name in ("compose_inputs", "training_step", "validation_step", "test_step", "test_epoch_end", "configure_optimizers"):
+        assert callable(getattr(LightningModel, name)), name
+    assert list(inspect.signature(LightningModel.compose_inputs).parameters) == ["self", "data", "eval"]
+    ref_kwargs = ["dataset_folder", "subjects", "pose_dir", "mode", "orig_img_size", "img_size", "num_fg_samples",
+                  "num_bg_samples", "sampling_rate", "start_frame", "end_frame", "views", "box_margin"]
+    assert set(ref_kwargs) <= set(inspect.signature(data.ZJUMOCAPODPDataset.__init__).parameters)
 
 
 def test_state_dict_names_and_checkpoint_roundtrip(tmp_path):
