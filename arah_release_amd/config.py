@@ -327,8 +327,52 @@ class LightningModel(nn.Module):
         out["image"] = img
         return out
 
-    def validation_step(self, data, data_idx=None):
-        return self.render_image(data, gen_cano_mesh=False)
+    @staticmethod
+    def normals_from_points(points_img):
+        """Normal map from the camera-space surface points of a frame (H,W,3; zeros where the ray missed), by the
+        reference's finite differences dz/dy, dz/dx (lightning_model.py:184-203): NaNs -- from 0 / 0 on the background and
+        at the silhouette -- become -1 before the map to [0, 1]."""
+        zs, xs, ys = points_img[:, :, 2], points_img[:, :, 0], points_img[:, :, 1]
+        zy = (zs[1:, :] - zs[:-1, :]) / (ys[1:, :] - ys[:-1, :])
+        zx = (zs[:, 1:] - zs[:, :-1]) / (xs[:, 1:] - xs[:, :-1])
+        nrm = torch.zeros_like(points_img)
+        nrm[:-1, :, 1] = -zy
+        nrm[:, :-1, 0] = -zx
+        nrm[:, :, 2] = 1
+        nrm = nrm / torch.linalg.norm(nrm, dim=-1, keepdim=True)
+        nrm[nrm.isnan()] = -1
+        return ((nrm + 1) / 2.0).clip(0.0, 1.0)
+
+    def validation_step(self, data, data_idx=None, ssim_fn=None, lpips_fn=None):
+        """lightning_model.py:160-230: predicted image, normal map (the canonical-mesh one when the model produced it, else
+        finite differences of the surface points), ground-truth image, PSNR (im2mesh/utils/eval.py:6-9).  SSIM and LPIPS
+        come from skimage / lpips in the reference: pass callables (pred HxWx3, gt HxWx3, box mask) to have them filled."""
+        import numpy as np
+        out = self.render_image(data, gen_cano_mesh=False)
+        mask = data.get("inputs.image_mask")
+        n = int(mask.sum())
+        pred_pixels = out["image"].squeeze(0)
+        if "output_normal" in out:
+            pred_normals = out["output_normal"].squeeze(0)
+        else:
+            pts = torch.zeros(*mask.shape, 3, device=mask.device)
+            pts.masked_scatter_(mask.unsqueeze(-1), out["points_cam"].reshape(-1, 3)[:n])
+            pred_normals = self.normals_from_points(pts.squeeze(0))
+        image = data.get("inputs")
+        gt_pixels = torch.zeros(*mask.shape, 3, device=mask.device)
+        gt_pixels.masked_scatter_(mask.unsqueeze(-1), image.reshape(-1, 3)[:n])
+        gt_pixels = gt_pixels.squeeze(0)
+        pred_img = out["rgb_values"].reshape(-1, 3).detach().cpu().numpy()
+        gt_img = image.reshape(-1, 3).detach().cpu().numpy()
+        res = {"psnr": -10 * np.log(np.mean((pred_img - gt_img) ** 2)) / np.log(10)}
+        box = mask.squeeze(0).detach().cpu().numpy()
+        if ssim_fn is not None:
+            res["ssim"] = ssim_fn(pred_pixels.detach().cpu().numpy(), gt_pixels.detach().cpu().numpy(), box)
+        if lpips_fn is not None:
+            res["lpips"] = lpips_fn(pred_pixels.detach().cpu().numpy(), gt_pixels.detach().cpu().numpy(), box)
+        res.update({"rgb_pred": pred_pixels.permute(2, 0, 1), "normal_pred": pred_normals.permute(2, 0, 1),
+                    "rgb_gt": gt_pixels.permute(2, 0, 1)})
+        return res
 
     def test_step(self, data, data_idx=None):
         """lightning_model.py:306-338: the frame's image and the three normal maps of the canonical mesh, channels first

@@ -437,7 +437,49 @@ def make_f13():
     print("wrote f13_idhr_loss.npz", sorted({k.split(".", 1)[1] for k in cases if k.startswith("c0.res.")}))
 
 
+def make_f14():
+    """F14: the reference's LightningModel.validation_step (lightning_model.py:160-230) around a stub model: scatter of the
+    rendered pixels into the image, the normal map it derives from the camera-space surface points by finite differences
+    (incl. its NaN handling at the silhouette), the ground-truth image and PSNR.  SSIM and LPIPS (skimage, lpips: absent)
+    are replaced by constants."""
+    import torch.nn as nn
+    from im2mesh.metaavatar_render import lightning_model as ref_lm
+    ref_lm.ssim_metric = lambda *a, **k: 0.5
+    ref_lm.lpips_metric = lambda *a, **k: 0.25
+    g = torch.Generator().manual_seed(14)
+    H, W = 24, 20
+    mask = torch.zeros(1, H, W, dtype=torch.bool)
+    mask[0, 3:21, 4:17] = True
+    mask[0, 10, 9] = False
+    n = int(mask.sum())
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    depth = 3.0 + 0.2 * torch.sin(xx / 3.0) * torch.cos(yy / 4.0)
+    pts_img = torch.stack([(xx - 10) / 40.0 * depth, (yy - 12) / 40.0 * depth, depth], -1)
+    hit = torch.rand(H, W, generator=g) > 0.25                      # rays that missed the body: points_cam == 0
+    pts = (pts_img * hit[..., None])[mask[0]]
+    outputs = {"rgb_values": torch.rand(1, n, 3, generator=g), "points_cam": pts.unsqueeze(0)}
+
+    class Stub(nn.Module):
+        def forward(self, inputs, gen_cano_mesh=False, eval=True):
+            return dict(outputs)
+
+    lm = ref_lm.LightningModel.__new__(ref_lm.LightningModel)
+    nn.Module.__init__(lm)
+    lm.model, lm.cfg, lm.loss_fn_vgg = Stub(), {}, None
+    object.__setattr__(lm, "device", torch.device("cpu"))
+    lm.compose_inputs = lambda batch, eval: {}
+    batch = {"inputs.img_height": torch.tensor([H]), "inputs.img_width": torch.tensor([W]), "inputs.image_mask": mask,
+             "inputs": torch.rand(1, n, 3, generator=g)}
+    res = lm.validation_step(batch, 0)
+    save("f14_validation_step.npz", H=H, W=W, image_mask=mask, rgb_values=outputs["rgb_values"], points_cam=outputs["points_cam"],
+         inputs=batch["inputs"], psnr=np.float64(res["psnr"]), ssim=np.float64(res["ssim"]), lpips=np.float64(res["lpips"]),
+         rgb_pred=res["rgb_pred"], normal_pred=res["normal_pred"], rgb_gt=res["rgb_gt"])
+    print("psnr", res["psnr"], "nan->-1 pixels", int((res["normal_pred"] == 0).all(0).sum()))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f14":
+        return make_f14()
     if len(sys.argv) > 1 and sys.argv[1] == "f13":
         return make_f13()
     if len(sys.argv) > 1 and sys.argv[1] == "f12":

@@ -519,3 +519,32 @@ def test_test_sequence_end_to_end(tmp_path, scene, body):
     front = np.asarray(Image.open(vis / "front_000001.png"))
     assert rgb.shape == (512, 512, 3) and rgb.max() > 0
     assert front.shape == (512, 512, 3) and len(np.unique(front.reshape(-1, 3), axis=0)) > 100
+
+
+def test_validation_step_against_reference():
+    """LightningModel.validation_step around a stub model against the reference's own (fixture F14): image scatter, normal
+    map from the surface points incl. the NaN handling, ground-truth image, PSNR; SSIM / LPIPS through caller-supplied
+    callables."""
+    from arah_release_amd import config
+    g = golden("f14_validation_step.npz")
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=2)
+    outputs = {"rgb_values": T(g["rgb_values"]), "points_cam": T(g["points_cam"])}
+
+    class Stub(torch.nn.Module):
+        def forward(self, inputs, gen_cano_mesh=False, eval=True):
+            return dict(outputs)
+
+    lm.model = Stub()
+    mask = torch.from_numpy(g["image_mask"])
+    lm.compose_inputs = lambda data, eval: {"image_mask": mask}
+    batch = {"inputs.image_mask": mask, "inputs": T(g["inputs"]), "inputs.img_height": torch.tensor([int(g["H"])]),
+             "inputs.img_width": torch.tensor([int(g["W"])])}
+    res = lm.validation_step(batch, 0, ssim_fn=lambda a, b, m: 0.5, lpips_fn=lambda a, b, m: 0.25)
+    assert set(res) == {"psnr", "ssim", "lpips", "rgb_pred", "normal_pred", "rgb_gt"}
+    np.testing.assert_allclose(res["psnr"], float(g["psnr"]), rtol=1e-6)
+    assert res["ssim"] == float(g["ssim"]) and res["lpips"] == float(g["lpips"])
+    for k in ("rgb_pred", "rgb_gt"):
+        np.testing.assert_array_equal(res[k].numpy(), g[k])
+    np.testing.assert_allclose(res["normal_pred"].numpy(), g["normal_pred"], rtol=0, atol=1e-6)
+    assert "ssim" not in lm.validation_step(batch, 0)

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-timeout 250 python -m pytest tests/test_callers.py -m gpu -q -x --timeout=120 2>&1 | grep -v amdgpu.ids | tail -25
+timeout 400 python -m pytest tests -m gpu -q -x --timeout=150 2>&1 | tail -3
