@@ -364,7 +364,8 @@ class LightningModel(nn.Module):
         gt_pixels = gt_pixels.squeeze(0)
         pred_img = out["rgb_values"].reshape(-1, 3).detach().cpu().numpy()
         gt_img = image.reshape(-1, 3).detach().cpu().numpy()
-        res = {"psnr": -10 * np.log(np.mean((pred_img - gt_img) ** 2)) / np.log(10)}
+        with np.errstate(divide="ignore"):   # identical images: the reference's formula gives inf (with numpy's warning)
+            res = {"psnr": -10 * np.log(np.mean((pred_img - gt_img) ** 2)) / np.log(10)}
         box = mask.squeeze(0).detach().cpu().numpy()
         if ssim_fn is not None:
             res["ssim"] = ssim_fn(pred_pixels.detach().cpu().numpy(), gt_pixels.detach().cpu().numpy(), box)

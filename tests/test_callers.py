@@ -548,3 +548,33 @@ def test_validation_step_against_reference():
         np.testing.assert_array_equal(res[k].numpy(), g[k])
     np.testing.assert_allclose(res["normal_pred"].numpy(), g["normal_pred"], rtol=0, atol=1e-6)
     assert "ssim" not in lm.validation_step(batch, 0)
+
+
+@pytest.mark.gpu
+def test_validation_step_on_a_dataset_item(body):
+    """validation_step on the device with the real model: keys and shapes of the reference's eval dict, PSNR against a
+    ground truth that IS the prediction (infinite) and against black."""
+    from arah_release_amd import config, data
+    g = golden("f9_callers.npz")
+    dev = torch.device("cuda:0")
+    md = {k[3:]: g[k] for k in g.files if k.startswith("md.")}
+    cam = {k[4:]: g[k] for k in g.files if k.startswith("cam.")}
+    cfg = config.builtin_config("zju313")
+    lm = config.get_model(cfg, mode="test", n_data_points=4)
+    lm.model.load_state_dict(config.synthetic_state_dict(cfg), strict=False)
+    lm = lm.to(dev).eval()
+    lm.model.frames = []
+    item = data.frame_item(md, cam, body, 128, 64, device=dev, frame_idx=5, data_idx=1)
+    res = lm.validation_step(item)                                       # frame_item's 'inputs' are black pixels
+    assert set(res) == {"psnr", "rgb_pred", "normal_pred", "rgb_gt"}
+    for k in ("rgb_pred", "normal_pred", "rgb_gt"):
+        assert tuple(res[k].shape) == (3, 128, 128) and bool(torch.isfinite(res[k]).all()), k
+    assert float(res["rgb_gt"].abs().max()) == 0.0 and np.isfinite(res["psnr"]) and res["psnr"] > 0
+    mask = item["inputs.image_mask"][0]
+    item["inputs"] = res["rgb_pred"].permute(1, 2, 0)[mask].unsqueeze(0).clone()
+    again = lm.validation_step(item)
+    assert again["psnr"] == float("inf") and torch.equal(again["rgb_gt"], again["rgb_pred"])
+    # the normal map: unit-length where defined, (0, 0, 0) where the finite differences were NaN
+    n = again["normal_pred"].permute(1, 2, 0) * 2 - 1
+    defined = (again["normal_pred"] != 0).any(0)
+    assert float((n[defined].norm(dim=-1) - 1).abs().max()) < 1e-3
