@@ -410,3 +410,66 @@ def get_dataset(mode, cfg, body):
     return SequenceDataset(d["path"], d[mode + "_split"], d["pose_dir"], body=body, mode=mode, img_size=(512, 512), orig_img_size=(1024, 1024),
                            sampling_rate=d[mode + "_subsampling_rate"], start_frame=d[mode + "_start_frame"],
                            end_frame=d[mode + "_end_frame"], views=d[mode + "_views"], box_margin=d["box_margin"])
+
+
+class TrainingDataset:
+    """The training dataset (reference ZJUMOCAPDataset, data/zju_mocap.py:20-150): <subject>/models/*.npz,
+    <subject>/<camera>/*.jpg (images) and *.png (masks), <subject>/cam_params.json, enumerated camera-major.  ``item(idx,
+    device)`` reads the image pair (PIL), prepares it on the device (imageops: undistort, resize, mask rim), samples pixels /
+    rays and the regularisation point sets (training_item)."""
+
+    def __init__(self, dataset_folder, subjects=("CoreView_313",), mode="train", img_size=(512, 512), num_fg_samples=1024,
+                 num_bg_samples=1024, sampling_rate=1, start_frame=0, end_frame=-1, views=(), off_surface_thr=0.2,
+                 inside_thr=0.001, box_margin=0.05, sampling="default", sample_reg_surface=False, sample_inside=False,
+                 erode_mask=True, body=None, faces=None, body_models="body_models/misc"):
+        if len(subjects) != 1:
+            raise AssertionError("one subject per dataset, like the reference (zju_mocap.py:95)")
+        if sampling != "default":
+            raise ValueError("Sampling strategy {} is not supported!".format(sampling))          # zju_mocap.py:401
+        self.mode, self.sampling = mode, sampling
+        self.img_size = (int(img_size), int(img_size)) if np.isscalar(img_size) else tuple(img_size)
+        self.num_fg_samples, self.num_bg_samples = num_fg_samples, num_bg_samples
+        self.off_surface_thr, self.inside_thr, self.box_margin = off_surface_thr, inside_thr, box_margin
+        self.sample_reg_surface, self.sample_inside, self.erode_mask = sample_reg_surface, sample_inside, erode_mask
+        self.body = body if body is not None else smpl.BodyModel.from_files("neutral", body_models)
+        self.faces = faces if faces is not None else np.load(os.path.join(body_models, "faces.npz"))["faces"]
+        subject_dir = os.path.join(dataset_folder, subjects[0])
+        self.cameras = load_cam_params(os.path.join(subject_dir, "cam_params.json"))
+        self.cam_names = list(views) if len(views) else list(self.cameras["all_cam_names"])
+        sl = slice(start_frame, end_frame if end_frame > 0 else None, sampling_rate)
+        model_files = sorted(glob.glob(os.path.join(subject_dir, "models/*.npz")))[sl]
+        self.data = []
+        for ci, cam in enumerate(self.cam_names):
+            cam_dir = os.path.join(subject_dir, cam)
+            all_imgs = sorted(glob.glob(os.path.join(cam_dir, "*.jpg")))
+            frames = list(range(len(all_imgs)))[sl]
+            imgs, masks = all_imgs[sl], sorted(glob.glob(os.path.join(cam_dir, "*.png")))[sl]
+            if not (len(model_files) == len(imgs) == len(masks)):
+                raise AssertionError("camera %s: %d images, %d masks for %d model files" % (cam, len(imgs), len(masks),
+                                                                                             len(model_files)))
+            for d_idx, (f_idx, img, msk, mf) in enumerate(zip(frames, imgs, masks, model_files)):
+                self.data.append({"subject": subjects[0], "gender": "neutral", "cam_idx": ci, "cam_name": cam, "frame_idx": f_idx,
+                                  "data_idx": d_idx, "img_file": img, "mask_file": msk, "model_file": mf})
+
+    def __len__(self):
+        return len(self.data)
+
+    def item(self, idx, device, generator=None):
+        from PIL import Image
+        from . import imageops
+        d = self.data[idx]
+        cam = self.cameras[d["cam_name"]]
+        image = torch.as_tensor(np.array(Image.open(d["img_file"]).convert("RGB")), device=device).float()
+        mask = torch.as_tensor(np.array(Image.open(d["mask_file"]).convert("L")), device=device)
+        orig = (image.shape[0], image.shape[1])
+        K, D = torch.as_tensor(np.asarray(cam["K"], np.float32)), np.asarray(cam["D"], np.float64).ravel()
+        rim = imageops.rim_mask(mask, self.erode_mask or self.mode in ("val", "test"))                  # zju_mocap.py:246
+        image, mask, rim = imageops.undistort(image, K, D), imageops.undistort(mask, K, D), imageops.undistort(rim, K, D)
+        image = imageops.resize_linear(image, self.img_size) / 255.0                                     # :254-259
+        mask, rim = imageops.resize_nearest(mask, self.img_size), imageops.resize_nearest(rim, self.img_size)
+        return training_item(load_model_npz(d["model_file"]), cam, self.body, self.faces, image, mask, rim, self.img_size, orig,
+                             box_margin=self.box_margin, num_fg_samples=self.num_fg_samples,
+                             num_bg_samples=self.num_bg_samples, sample_reg_surface=self.sample_reg_surface,
+                             sample_inside=self.sample_inside, off_surface_thr=self.off_surface_thr,
+                             inside_thr=self.inside_thr, device=device, generator=generator, cam_idx=d["cam_idx"],
+                             frame_idx=d["frame_idx"], data_idx=d["data_idx"], gender=d["gender"])
