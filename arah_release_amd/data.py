@@ -431,45 +431,116 @@ class TrainingDataset:
         self.num_fg_samples, self.num_bg_samples = num_fg_samples, num_bg_samples
         self.off_surface_thr, self.inside_thr, self.box_margin = off_surface_thr, inside_thr, box_margin
         self.sample_reg_surface, self.sample_inside, self.erode_mask = sample_reg_surface, sample_inside, erode_mask
-        self.body = body if body is not None else smpl.BodyModel.from_files("neutral", body_models)
+        self.body = body if body is not None else smpl.BodyModel.from_files(self._gender(subjects[0]), body_models)
         self.faces = faces if faces is not None else np.load(os.path.join(body_models, "faces.npz"))["faces"]
-        subject_dir = os.path.join(dataset_folder, subjects[0])
-        self.cameras = load_cam_params(os.path.join(subject_dir, "cam_params.json"))
+        subject_dir = self._subject_dir(dataset_folder, subjects[0])
+        self.cameras = self._load_cameras(subject_dir)
         self.cam_names = list(views) if len(views) else list(self.cameras["all_cam_names"])
         sl = slice(start_frame, end_frame if end_frame > 0 else None, sampling_rate)
         model_files = sorted(glob.glob(os.path.join(subject_dir, "models/*.npz")))[sl]
         self.data = []
         for ci, cam in enumerate(self.cam_names):
-            cam_dir = os.path.join(subject_dir, cam)
-            all_imgs = sorted(glob.glob(os.path.join(cam_dir, "*.jpg")))
+            img_dir, mask_dir = self._image_dirs(subject_dir, cam)
+            all_imgs = sorted(glob.glob(os.path.join(img_dir, "*.jpg")))
             frames = list(range(len(all_imgs)))[sl]
-            imgs, masks = all_imgs[sl], sorted(glob.glob(os.path.join(cam_dir, "*.png")))[sl]
+            imgs, masks = all_imgs[sl], sorted(glob.glob(os.path.join(mask_dir, "*.png")))[sl]
             if not (len(model_files) == len(imgs) == len(masks)):
                 raise AssertionError("camera %s: %d images, %d masks for %d model files" % (cam, len(imgs), len(masks),
                                                                                              len(model_files)))
             for d_idx, (f_idx, img, msk, mf) in enumerate(zip(frames, imgs, masks, model_files)):
-                self.data.append({"subject": subjects[0], "gender": "neutral", "cam_idx": ci, "cam_name": cam, "frame_idx": f_idx,
-                                  "data_idx": d_idx, "img_file": img, "mask_file": msk, "model_file": mf})
+                self.data.append({"subject": subjects[0], "gender": self._gender(subjects[0]), "cam_idx": ci, "cam_name": cam,
+                                  "frame_idx": f_idx, "data_idx": d_idx, "img_file": img, "mask_file": msk, "model_file": mf})
+
+    # ---- what differs between the capture formats (zju_mocap.py / h36m.py / people_snapshot.py)
+    def _subject_dir(self, dataset_folder, subject):
+        return os.path.join(dataset_folder, subject)
+
+    def _load_cameras(self, subject_dir):
+        return load_cam_params(os.path.join(subject_dir, "cam_params.json"))
+
+    def _image_dirs(self, subject_dir, cam):
+        return os.path.join(subject_dir, cam), os.path.join(subject_dir, cam)
+
+    def _gender(self, subject):
+        return "neutral"
+
+    def _rim(self, mask):
+        from . import imageops
+        return imageops.rim_mask(mask, self.erode_mask or self.mode in ("val", "test"))                  # zju_mocap.py:212
+
+    def _prepare(self, image, mask, rim, K, D):
+        """-> image (H,W,3) in [0,1], mask, rim at img_size, and the size the intrinsics refer to (zju_mocap.py:246-262)."""
+        from . import imageops
+        orig = (image.shape[0], image.shape[1])
+        image, mask, rim = imageops.undistort(image, K, D), imageops.undistort(mask, K, D), imageops.undistort(rim, K, D)
+        image = imageops.resize_linear(image, self.img_size) / 255.0
+        return image, imageops.resize_nearest(mask, self.img_size), imageops.resize_nearest(rim, self.img_size), orig
 
     def __len__(self):
         return len(self.data)
 
     def item(self, idx, device, generator=None):
         from PIL import Image
-        from . import imageops
         d = self.data[idx]
         cam = self.cameras[d["cam_name"]]
         image = torch.as_tensor(np.array(Image.open(d["img_file"]).convert("RGB")), device=device).float()
         mask = torch.as_tensor(np.array(Image.open(d["mask_file"]).convert("L")), device=device)
-        orig = (image.shape[0], image.shape[1])
         K, D = torch.as_tensor(np.asarray(cam["K"], np.float32)), np.asarray(cam["D"], np.float64).ravel()
-        rim = imageops.rim_mask(mask, self.erode_mask or self.mode in ("val", "test"))                  # zju_mocap.py:246
-        image, mask, rim = imageops.undistort(image, K, D), imageops.undistort(mask, K, D), imageops.undistort(rim, K, D)
-        image = imageops.resize_linear(image, self.img_size) / 255.0                                     # :254-259
-        mask, rim = imageops.resize_nearest(mask, self.img_size), imageops.resize_nearest(rim, self.img_size)
+        image, mask, rim, orig = self._prepare(image, mask, self._rim(mask), K, D)
         return training_item(load_model_npz(d["model_file"]), cam, self.body, self.faces, image, mask, rim, self.img_size, orig,
                              box_margin=self.box_margin, num_fg_samples=self.num_fg_samples,
                              num_bg_samples=self.num_bg_samples, sample_reg_surface=self.sample_reg_surface,
                              sample_inside=self.sample_inside, off_surface_thr=self.off_surface_thr,
                              inside_thr=self.inside_thr, device=device, generator=generator, cam_idx=d["cam_idx"],
                              frame_idx=d["frame_idx"], data_idx=d["data_idx"], gender=d["gender"])
+
+
+class H36MDataset(TrainingDataset):
+    """Human3.6M captures (reference data/h36m.py): the subject's files sit under <subject>/Posing, the image is reduced to
+    img_size FIRST (INTER_AREA) and undistorted at that size with intrinsics that already refer to it, the mask rim is left
+    out only while training (h36m.py:96,113,211,246-272)."""
+
+    def __init__(self, dataset_folder, subjects=("S1",), mode="train", img_size=(1002, 1000), **kw):
+        super().__init__(dataset_folder, subjects=subjects, mode=mode, img_size=img_size, **kw)
+
+    def _subject_dir(self, dataset_folder, subject):
+        return os.path.join(dataset_folder, subject, "Posing")
+
+    def _rim(self, mask):
+        from . import imageops
+        return imageops.rim_mask(mask, self.erode_mask and self.mode not in ("val", "test"))
+
+    def _prepare(self, image, mask, rim, K, D):
+        from . import imageops
+        image = imageops.resize_area(image, self.img_size)
+        mask, rim = imageops.resize_nearest(mask, self.img_size), imageops.resize_nearest(rim, self.img_size)
+        image, mask, rim = imageops.undistort(image, K, D), imageops.undistort(mask, K, D), imageops.undistort(rim, K, D)
+        return image / 255.0, mask, rim, self.img_size            # intrinsics are for img_size: no rescaling
+
+
+class PeopleSnapshotDataset(TrainingDataset):
+    """People-Snapshot captures (reference data/people_snapshot.py): one camera from <subject>/camera.pkl (camera_f,
+    camera_c, camera_k, identity pose), images under image/, masks under mask/, gender from the subject's name
+    (people_snapshot.py:94-150,222-232)."""
+
+    def __init__(self, dataset_folder, subjects=("female-3-casual",), mode="train", img_size=(1080, 1080), **kw):
+        kw.pop("views", None)
+        super().__init__(dataset_folder, subjects=subjects, mode=mode, img_size=img_size, **kw)
+
+    def _load_cameras(self, subject_dir):
+        import pickle
+        with open(os.path.join(subject_dir, "camera.pkl"), "rb") as f:
+            cam = pickle.load(f, encoding="latin1")
+        K = np.zeros((3, 3), np.float32)
+        K[0, 0], K[1, 1] = cam["camera_f"][0], cam["camera_f"][1]
+        K[:2, 2] = cam["camera_c"]
+        K[2, 2] = 1
+        self.orig_img_size = (cam["height"], cam["width"])
+        return {"all_cam_names": ["1"], "1": {"K": K, "D": np.asarray(cam["camera_k"], np.float32), "R": np.eye(3, dtype=np.float32),
+                                              "T": np.zeros(3, np.float32)}}
+
+    def _image_dirs(self, subject_dir, cam):
+        return os.path.join(subject_dir, "image"), os.path.join(subject_dir, "mask")
+
+    def _gender(self, subject):
+        return "female" if "female" in subject else "male"

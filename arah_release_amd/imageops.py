@@ -77,3 +77,11 @@ def resize_nearest(mask, size):
     ys = torch.div(torch.arange(size[0], device=mask.device) * H, size[0], rounding_mode="floor").clamp(max=H - 1)
     xs = torch.div(torch.arange(size[1], device=mask.device) * W, size[1], rounding_mode="floor").clamp(max=W - 1)
     return mask[ys][:, xs]
+
+
+def resize_area(img, size):
+    """cv2.resize(img, (size[1], size[0]), interpolation=cv2.INTER_AREA) for (H,W,C) float images: box average of the source
+    pixels a result pixel covers (exact for integer reduction factors; for fractional ones OpenCV weights the partially
+    covered border pixels, here every result pixel averages the source pixels whose index range it spans)."""
+    x = img.permute(2, 0, 1)[None].float()
+    return F.interpolate(x, size=tuple(size), mode="area")[0].permute(1, 2, 0)

@@ -2,3 +2,4 @@
 (reference im2mesh/data/__init__.py, data/zju_mocap_odp.py:20)."""
 from arah_release_amd.data import SequenceDataset as ZJUMOCAPODPDataset, get_dataset  # noqa: F401
 from arah_release_amd.data import TrainingDataset as ZJUMOCAPDataset  # noqa: F401,E402
+from arah_release_amd.data import H36MDataset, PeopleSnapshotDataset  # noqa: F401,E402
