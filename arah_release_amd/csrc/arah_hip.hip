@@ -45,6 +45,7 @@ struct KnnPtrs {
 struct FrameDev {
     SdfNet sdf;
     SkinNet skin;
+    SkinWave skw;
     ColNet col;
     KnnPtrs knn;
     const float* verts4;
@@ -97,6 +98,8 @@ FrameDev to_dev(const ArahFrame& f) {
     d.skin.bias = f.skin_bias;
     for (int i = 0; i < 4; ++i) d.skin.wps[i] = reinterpret_cast<const f16x8*>(f.skin_wps[i]);
     d.skin.scales = f.skin_scales;
+    d.skw.wpr = reinterpret_cast<const f16x8*>(f.skin_wpr);
+    d.skw.consts = f.skin_wconsts;
     d.col.w0p = f.col_w0p;
     d.col.w1p = f.col_w1p;
     d.col.w2p = f.col_w2p;
@@ -119,7 +122,7 @@ FrameDev to_dev(const ArahFrame& f) {
 }
 
 struct Counters {
-    unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, n_density, n_canon;
+    unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, n_density, n_canon, n_split_nonfinite;
     unsigned long long clk[8 * 16];   // instrumented builds (-DARAH_CLOCKS): s_memtime ticks per wave slot and phase
 };
 #ifdef ARAH_CLOCKS
@@ -200,6 +203,9 @@ __device__ __forceinline__ float split_weight_scale(unsigned amax_bits) {
 
 // split-engine A operand of one 256x256 layer: dst[((mt*8 + kc)*2 + s)*64 + lane] holds 8 halves (s = 0 hi, 1 lo)
 // of scale * src[mt*16 + (lane&15)][kc*32 + 8 (lane>>4) .. +7]
+// PERM (the point-owning-wave kernels, SkinWave in mlp.hpp): element e of lane group g in chunk kc is the channel an
+// accumulator of the previous layer holds there, (2 kc + (e >> 2)) * 16 + 4 g + (e & 3).
+template <bool PERM = false>
 __global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ src, int M, int ld, int m_tiles,
                              int KC32, const unsigned* amax) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -210,7 +216,8 @@ __global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ 
     f16x8 hi, lo;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-        const float w = row < M ? src[(size_t)row * ld + kc * 32 + (lane >> 4) * 8 + e] * scale : 0.f;
+        const int col = PERM ? (2 * kc + (e >> 2)) * 16 + 4 * (lane >> 4) + (e & 3) : kc * 32 + (lane >> 4) * 8 + e;
+        const float w = row < M ? src[(size_t)row * ld + col] * scale : 0.f;
         const _Float16 h = (_Float16)w;
         hi[e] = h;
         lo[e] = (_Float16)(w - (float)h);
@@ -281,6 +288,22 @@ __global__ void k_skin_scales(const unsigned* amax, float* scales) {
     }
     scales[k] = S;
     scales[4 + k] = 1.0f / (split_weight_scale(amax[4 + k]) * S);
+}
+
+// constants of the point-owning-wave kernels (SkinWave::consts, layout kCw* in mlp.hpp); amax[4..7] = |W| of layers 1..4
+__global__ void k_skin_wave_consts(SkinRaw net, const float* __restrict__ w4b, const unsigned* amax, float* __restrict__ c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 128) {
+        c[kCwW0 + i * 4 + 0] = net.w[0][i * 3 + 0] * kZUnit;
+        c[kCwW0 + i * 4 + 1] = net.w[0][i * 3 + 1] * kZUnit;
+        c[kCwW0 + i * 4 + 2] = net.w[0][i * 3 + 2] * kZUnit;
+        c[kCwW0 + i * 4 + 3] = net.b[0][i] * kZUnit;
+#pragma unroll
+        for (int k = 1; k < 4; ++k) c[kCwBz + (k - 1) * 128 + i] = net.b[k][i] * kZUnit;
+    }
+    if (i < 32) c[kCwB4 + i] = i < 25 ? w4b[i] : 0.f;
+    if (i < 3) c[kCwInv + i] = 1.0f / split_weight_scale(amax[4 + i]);
+    if (i == 3) c[kCwInv + 3] = (float)(0.6931471805599453 / 100.0) / split_weight_scale(amax[7]);
 }
 
 // the per-frame scalars stay on the device: trans(3), center(3), coord_min, coord_max, |variance| -> scal[9]
@@ -1588,6 +1611,8 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
 #endif
 }
 
+#include "canon_wave.hpp"
+
 // explicit targets (arah_broyden3_lbs): file them where k_canon_solve expects them, in row 3 of the start transform
 __global__ void k_canon_seed(const int* list, const int* count, const float* tgt, float* T0) {
     const int n = *count;
@@ -2389,6 +2414,20 @@ inline int env_int(const char* name, int dflt) {
     return e ? atoi(e) : dflt;
 }
 
+// compute units of the current device (grid of the resident one-workgroup-per-CU kernels)
+inline int num_cus() {
+    constexpr int kMaxDevices = 64;
+    static int cus[kMaxDevices] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
+    if (cus[dev] == 0) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        cus[dev] = v;
+    }
+    return cus[dev];
+}
+
 // dynamic LDS sizes (bytes)
 constexpr size_t kLdsSdfFwd = (64 * 4 * 2 + 64) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsSdfGrad = kLdsSdfFwd + (size_t)64 * kSdfLd * 4;
@@ -2455,6 +2494,8 @@ int setup_attributes() {
     allow_lds(k_skin_jac, kLdsSkin);
     allow_lds(k_canon_solve<false>, kLdsCanonSolve);
     allow_lds(k_canon_solve<true>, kLdsSplitSolo);
+    allow_lds(k_canon_wave<true>, kLdsCanonWave);
+    allow_lds(k_canon_wave<false>, kLdsCanonWave);
     allow_lds(k_joint_iter<true, false>, kLdsJoint);
     allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<false, false>, kLdsJoint);
@@ -2518,7 +2559,7 @@ RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
 struct FrameLayout {
     size_t sdf_w0, sdf_wp[5], sdf_wpT[5], sdf_w6, sdf_b6, sdf_bias, sdf_freq, sdf_phase;
     size_t sdf_wps[5], sdf_fw, sdf_pw, sdf_fws, sdf_amax;
-    size_t skin_w0, skin_wp[3], skin_w4p, skin_bias, skin_wps[4], skin_scales, skin_amax;
+    size_t skin_w0, skin_wp[3], skin_w4p, skin_bias, skin_wps[4], skin_scales, skin_amax, skin_wpr, skin_wconsts;
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
     size_t col_w0pT, col_w1pT, col_w2pT, col_w3apT, col_w3bpT, col_w4pT;   // transposed packings (training backward)
     size_t verts4, knn_spheres, knn_grid, knn_cells, scalars;
@@ -2556,6 +2597,8 @@ FrameLayout frame_layout(int col_mode) {
     L.skin_wps[3] = take(32 * 128);
     L.skin_scales = take(64);
     L.skin_amax = take(64);
+    L.skin_wpr = take(kCwWeightBytes / 4);
+    L.skin_wconsts = take(1024);
     L.col_w0p = take((size_t)256 * kin_pad);
     L.col_w1p = take(256 * 256);
     L.col_w2p = take(128 * 256);
@@ -2662,7 +2705,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         if (hipMemsetAsync(amax, 0, 64 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
         for (int i = 0; i < 5; ++i) {
             hipLaunchKernelGGL(k_absmax, dim3(16), dim3(256), 0, s, nets->sdf_w[i + 1], 256 * 256, amax + i);
-            hipLaunchKernelGGL(k_pack_split, dim3(16 * 8 * 64 / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_pack_split<false>, dim3(16 * 8 * 64 / 256), dim3(256), 0, s,
                                reinterpret_cast<f16x8*>(base + L.sdf_wps[i]), nets->sdf_w[i + 1], 256, 256, 16, 8,
                                (const unsigned*)(amax + i));
         }
@@ -2688,11 +2731,16 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         for (int i = 0; i < 4; ++i) {
             const int M = i < 3 ? 128 : 25, mt = i < 3 ? 8 : 2;
             hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, s, nets->skin_w[i + 1], M * 128, amax + 4 + i);
-            hipLaunchKernelGGL(k_pack_split, dim3((mt * 4 * 64 + 255) / 256), dim3(256), 0, s,
+            hipLaunchKernelGGL(k_pack_split<false>, dim3((mt * 4 * 64 + 255) / 256), dim3(256), 0, s,
                                reinterpret_cast<f16x8*>(base + L.skin_wps[i]), nets->skin_w[i + 1], M, 128, mt, 4,
+                               (const unsigned*)(amax + 4 + i));
+            hipLaunchKernelGGL(k_pack_split<true>, dim3((mt * 4 * 64 + 255) / 256), dim3(256), 0, s,
+                               reinterpret_cast<f16x8*>(base + L.skin_wpr + (size_t)i * kCwLayerBytes), nets->skin_w[i + 1], M, 128, mt, 4,
                                (const unsigned*)(amax + 4 + i));
         }
         hipLaunchKernelGGL(k_skin_scales, dim3(1), dim3(64), 0, s, (const unsigned*)amax, P(L.skin_scales));
+        hipLaunchKernelGGL(k_skin_wave_consts, dim3(1), dim3(128), 0, s, raw, nets->skin_b[4], (const unsigned*)amax,
+                           P(L.skin_wconsts));
     }
     // ---- colour MLP: permute input columns to [feat(256), x(3), n(3), view(27)], fold the pose tail
     {
@@ -2762,6 +2810,8 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->skin_bias = P(L.skin_bias);
     for (int i = 0; i < 4; ++i) out->skin_wps[i] = base + L.skin_wps[i];
     out->skin_scales = P(L.skin_scales);
+    out->skin_wpr = base + L.skin_wpr;
+    out->skin_wconsts = P(L.skin_wconsts);
     out->col_w0p = P(L.col_w0p);
     out->col_w1p = P(L.col_w1p);
     out->col_w2p = P(L.col_w2p);
@@ -2968,10 +3018,33 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
     if (tgt)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
                            (const int*)&cnt[0], tgt, outp.T);
+    // ARAH_CANON_KERNEL: wave (default: point-owning waves, hi fragments in LDS), wave_l2 (all fragments from L2),
+    // tile (round 2's channel-sliced tiles).  The exact engine always runs the tile kernel.
+    static const int mode = [] {
+        const char* e = getenv("ARAH_CANON_KERNEL");
+        if (e && !strcmp(e, "tile")) return 0;
+        if (e && !strcmp(e, "wave_l2")) return 2;
+        return 1;
+    }();
     if (g_canon_ev0) hipEventRecord(g_canon_ev0, s);
-    LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
-                  kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
-                  &w.ctr->n_skin_fwd, &w.ctr->n_canon, w.ctr->clk);
+    if (fd.split && mode != 0) {
+        long long gw = (max_pts + kCwWaves * kCwSlots - 1) / (kCwWaves * kCwSlots);
+        const int cus = num_cus();
+        if (gw > cus) gw = cus;
+        if (gw < 1) gw = 1;
+        if (mode == 1)
+            hipLaunchKernelGGL(k_canon_wave<true>, dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
+                               (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
+                               &w.ctr->n_split_nonfinite, w.ctr->clk);
+        else
+            hipLaunchKernelGGL(k_canon_wave<false>, dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
+                               (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
+                               &w.ctr->n_canon, &w.ctr->n_split_nonfinite, w.ctr->clk);
+    } else {
+        LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
+                      kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
+                      &w.ctr->n_skin_fwd, &w.ctr->n_canon, w.ctr->clk);
+    }
     if (g_canon_ev1) hipEventRecord(g_canon_ev1, s);
     return check_launch();
 }

@@ -1,0 +1,477 @@
+// canon_wave.hpp -- loop C (RFU:267-362, broyden.py:4-78) as a resident kernel of POINT-OWNING waves.
+//
+// Included by arah_hip.hip inside its anonymous namespace, after k_canon_solve (whose slot-state layout, seed convention
+// and per-point tail it shares).  k_canon_solve (8 waves slice the CHANNELS of one 64-point tile) pays ten workgroup
+// barriers per pass and leaves four of its eight waves idle through the per-point tail and the refill; here
+//
+//   * a wave owns kCwNT * 16 points and ALL 128 channels of the skinning MLP: lane (j, g) of a 16x16 accumulator tile
+//     holds channels mt*16 + 4g + r of point j -- exactly one lane group's share of the next layer's B fragment, in
+//     the channel order the weights were packed for (SkinWave, mlp.hpp).  A layer's output never leaves the registers:
+//     no activation traffic through LDS, no workgroup barrier after the launch prologue, and the eight waves of a
+//     workgroup drift apart so that one wave's Softplus epilogues run under another's MFMAs;
+//   * inside a wave the epilogue of M-tile pair q of layer L (= B chunk q of layer L + 1) is issued between the MFMA
+//     steps of chunk q - 1 of layer L + 1, and pair 0 between the steps of the last chunk of layer L itself (the
+//     M-tile pair is final as soon as its own step of the last chunk has issued);
+//   * A operands: the hi halves of the four weight matrices live in LDS (104 KB, staged once per workgroup), the lo
+//     halves stream from L2 two steps ahead -- an all-L2 delivery at 32 points per wave would ask for twice the
+//     fragment bytes per point of the tile kernel;
+//   * every slot keeps a PREFETCHED start state (claimed from the launch-wide queue when the slot last refilled, its
+//     80 bytes loaded while the point before it was being solved), so a retiring point is replaced without waiting for
+//     HBM; the four lanes of a point keep its best transform in registers, its Broyden state (27 floats) in the wave's
+//     private LDS.
+// Activations travel in z = 100 log2(e) x (softplus_z); results differ from the tile kernel's by rounding only.
+#pragma once
+
+constexpr int kCwNT = 2;                        // N-tiles (16 points each) per wave
+constexpr int kCwWaves = 8;
+constexpr int kCwThreads = kCwWaves * 64;
+constexpr int kCwSlots = 16 * kCwNT;            // points per wave
+constexpr int kCwRowLd = 36;                    // logits row stride (floats): 16-byte aligned rows
+constexpr int kCwHiBytes = (3 * 32 + 8) * 1024; // hi fragments: 3 x (8 M-tiles x 4 chunks) + 2 x 4, 1 KB each
+constexpr int kCwConstFloats = kCwInv;          // w0c, bz, b4 are staged in LDS (the four scales stay scalar)
+constexpr int kCwWaveFloats = kCwSlots * ST_SIZE + 16 * kCwRowLd;   // per wave: slot states | logits rows
+constexpr size_t kLdsCanonWave = (size_t)kCwHiBytes + (kCwConstFloats + 24 * 16 + kCwWaves * kCwWaveFloats) * 4;
+constexpr int kCwSeedChunk = 64;                // seeds a wave takes from the queue per atomic
+
+struct CwStep {   // MFMA step G of a pass: layer L (1..4), chunk kc, M-tile pair mp
+    int L, kc, mp;
+};
+__host__ __device__ constexpr CwStep cw_step(int G) {
+    return G < 48 ? CwStep{G / 16 + 1, (G % 16) / 4, G % 4} : CwStep{4, G - 48, 0};
+}
+constexpr int kCwSteps = 52;
+
+// compile-time loop: the body sees its index as a constant expression (register arrays are indexed statically whatever
+// the unroller's thresholds say)
+template <int I>
+struct IC {
+    static constexpr int value = I;
+};
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <bool HI_LDS>
+__global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
+                                                              int* queue_head, CanonOut outp, unsigned long long* ctr,
+                                                              unsigned long long* ctr_canon,
+                                                              unsigned long long* ctr_bad, unsigned long long* clk_out) {
+    constexpr int NT = kCwNT;
+    const BodyConst bc = load_bc(fr);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    KernelClk clk;
+#ifdef ARAH_CLOCKS
+    clk.start();
+#endif
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int j = lane & 15, g = lane >> 4;
+    char* whi = reinterpret_cast<char*>(smem);
+    float* w0c = reinterpret_cast<float*>(whi + (HI_LDS ? kCwHiBytes : 0));
+    float* bz = w0c + kCwBz;
+    float* b4 = w0c + kCwB4;
+    float* sbones = w0c + kCwConstFloats;
+    float* state = sbones + 24 * 16 + wave * kCwWaveFloats;   // [kCwSlots][ST_SIZE]
+    float* rows = state + kCwSlots * ST_SIZE;                 // [16][kCwRowLd] logits of the N-tile in the tail
+    const float* cst = fr.skw.consts;
+    // ---- launch prologue: operands into LDS (the only workgroup barrier of the kernel)
+    for (int i = tid; i < kCwConstFloats; i += kCwThreads) w0c[i] = cst[i];
+    for (int i = tid; i < 24 * 16; i += kCwThreads) sbones[i] = fr.bones[i];
+    if (HI_LDS) {
+#pragma unroll
+        for (int L = 0; L < 4; ++L) {
+            const int nf = L < 3 ? 32 : 8;
+            for (int f = wave; f < nf; f += kCwWaves)
+                reinterpret_cast<f16x8*>(whi + (L * 32 + f) * 1024)[lane] =
+                    fr.skw.wpr[(size_t)L * (kCwLayerBytes / 16) + (size_t)(f * 2) * 64 + lane];
+        }
+    }
+    const float inv1 = cst[kCwInv], inv2 = cst[kCwInv + 1], inv3 = cst[kCwInv + 2], c_out = cst[kCwInv + 3];
+    // RFU:37-44 as one fma per coordinate: x_norm = (x - center - cmin + pad) * 2 / (1.1 rng) - 1
+    const float nrm_s = 2.0f / ((bc.cmax - bc.cmin) * 1.1f);
+    float nrm_o[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) nrm_o[c] = ((bc.cmax - bc.cmin) * 0.05f - bc.center[c] - bc.cmin) * nrm_s - 1.0f;
+    const int n = *count;
+    float* st[NT];
+    int* sti[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        st[t] = state + (t * 16 + j) * ST_SIZE;
+        sti[t] = reinterpret_cast<int*>(st[t]);
+        if (g == 0) sti[t][ST_ID] = -1;
+    }
+    __syncthreads();
+
+    const unsigned aoff = (unsigned)lane * 16u;
+    // weight fragments from L2: one buffer descriptor for the whole block, the lane's 16-byte slot in the vector offset,
+    // the fragment as a compile-time scalar offset -- no address registers per fragment for the compiler to hoist
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16x8*>(fr.skw.wpr), 0, kCwWeightBytes, 0x00020000);
+    auto ld_w = [&](int L, int f, int s) {
+        return __builtin_bit_cast(
+            f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, (int)aoff, (L - 1) * kCwLayerBytes + (f * 2 + s) * 1024, 0));
+    };
+    auto ld_lo = [&](int L, int f) { return ld_w(L, f, 1); };
+    auto ld_hi = [&](int L, int f) {
+        if (HI_LDS) return *reinterpret_cast<const f16x8*>(whi + ((L - 1) * 32 + f) * 1024 + aoff);
+        return ld_w(L, f, 0);
+    };
+
+    // the prefetched start state of every slot (all four lanes of a point hold its id; lane g holds row g of T0, with
+    // the target riding in row 3; lanes g < 3 hold coordinate g of x0)
+    int nid[NT];
+    f32x4 nT[NT];
+    float nx[NT];
+    f32x4 tbr[NT];   // row g of the best transform so far
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        nid[t] = -1;
+        nT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nx[t] = 0.f;
+        tbr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int cid = -1;                    // this wave's piece of the queue: lane l holds list[q_base + l]
+    int q_base = 0, q_pos = 0, q_end = 0;
+    bool exhausted = n <= 0;
+    int n_eval = 0, n_bad = 0;
+    const unsigned long long below = (1ull << j) - 1ull;
+    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+
+    for (int pass = 0;; ++pass) {
+        // watchdog: a launch of this kernel is tens of milliseconds; a wave that is still here after 5 s gives up (its
+        // remaining points keep their start states and are reported through n_split_nonfinite)
+        if (__builtin_amdgcn_s_memrealtime() - t_start > 500000000ull) {
+            n_bad += 1 << 20;
+            break;
+        }
+        // ---- (1) empty slots take their prefetched start state; then every empty slot claims the seed after that
+        int id[NT];
+        bool was_empty[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            id[t] = sti[t][ST_ID];
+            was_empty[t] = id[t] < 0;
+            if (was_empty[t] && nid[t] >= 0) {
+                id[t] = nid[t];
+                f32x4 t0 = nT[t];
+                if (g == 3) {
+                    st[t][ST_TG] = t0[0];
+                    st[t][ST_TG + 1] = t0[1];
+                    st[t][ST_TG + 2] = t0[2];
+                    t0 = f32x4{0.f, 0.f, 0.f, t0[3]};
+                } else {
+                    st[t][ST_X + g] = nx[t];
+                    st[t][ST_XB + g] = nx[t];
+                }
+                tbr[t] = t0;                                   // T0 doubles as the initial best T (broyden.py:41)
+                if (g == 0) {
+                    sti[t][ST_ID] = id[t];
+                    sti[t][ST_NEV] = 0;
+                }
+            }
+        }
+        {
+            unsigned long long m[NT];
+            int rank[NT], need = 0;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                m[t] = __ballot(was_empty[t]) & 0xffffull;   // lanes 0..15 speak for their slots
+                rank[t] = need + __popcll(m[t] & below);
+                need += __popcll(m[t]);
+                if (was_empty[t]) nid[t] = -1;
+            }
+            int given = 0;
+            while (need > 0 && !exhausted) {   // wave-uniform
+                if (q_pos == q_end) {
+                    int p = 0;
+                    if (lane == 0) p = atomicAdd(queue_head, kCwSeedChunk);
+                    p = __builtin_amdgcn_readfirstlane(p);
+                    if (p >= n) {
+                        exhausted = true;
+                        break;
+                    }
+                    q_base = q_pos = p;
+                    q_end = min(p + kCwSeedChunk, n);
+                    cid = p + lane < n ? list[p + lane] : -1;
+                }
+                const int take = min(q_end - q_pos, need);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int src = q_pos - q_base + (rank[t] - given);   // lane of cid that holds this slot's seed
+                    const int got = __shfl(cid, src & 63);
+                    if (was_empty[t] && rank[t] >= given && rank[t] < given + take) nid[t] = got;
+                }
+                q_pos += take;
+                given += take;
+                need -= take;
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {   // the start state sits where the result will go (pts, T with the target in row 3)
+                if (was_empty[t] && nid[t] >= 0) {
+                    nT[t] = reinterpret_cast<const f32x4*>(outp.T + (size_t)nid[t] * 16)[g];
+                    nx[t] = outp.pts[(size_t)nid[t] * 3 + min(g, 2)];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        unsigned long long live_any = 0ull;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const unsigned long long live = __ballot(id[t] >= 0) & 0xffffull;
+            live_any |= live;
+            n_eval += __popcll(live);
+        }
+        if (live_any == 0ull) {
+            bool pending = false;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) pending |= __any(nid[t] >= 0) != 0;
+            if (!pending) break;     // nothing in the slots, nothing prefetched: the queue is dry
+            continue;                // (only when a prefetched seed arrived for an empty wave: take it next pass)
+        }
+        // ---- (2) normalised coordinates of the lane's points (the four lanes of a point compute the same values)
+        f32x4 xr[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            xr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (id[t] >= 0)
+                xr[t] = f32x4{fmaf(st[t][ST_X], nrm_s, nrm_o[0]), fmaf(st[t][ST_X + 1], nrm_s, nrm_o[1]),
+                              fmaf(st[t][ST_X + 2], nrm_s, nrm_o[2]), 0.f};
+        }
+        clk.mark(0);
+        // ---- (3) skinning MLP, accumulators -> B fragments in registers
+        f32x4 acc[2][8][NT];
+        f16x8 bch[NT], bcl[NT], bnh[NT], bnl[NT];
+        float ev[NT][8];
+        f16x8 lo_ring[3][2], hi_ring[2][2];
+        // part p of the epilogue of layer L's M-tile pair q (L = 0: the K = 3 input layer) -> B chunk q of layer L + 1
+        auto epart = [&](auto Lc, auto qc, auto pc) {
+            constexpr int L = decltype(Lc)::value, q = decltype(qc)::value, p = decltype(pc)::value;
+            constexpr int t = p >> 1, h = p & 1;
+            constexpr int mt = 2 * q + h;
+            if constexpr (L == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(w0c + (mt * 16 + 4 * g + r) * 4);
+                    ev[t][h * 4 + r] = softplus_z(fmaf(w[2], xr[t][2], fmaf(w[1], xr[t][1], fmaf(w[0], xr[t][0], w[3]))));
+                }
+            } else {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bz + (L - 1) * 128 + mt * 16 + 4 * g);
+                const float inv = L == 1 ? inv1 : (L == 2 ? inv2 : inv3);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ev[t][h * 4 + r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, b[r]));
+            }
+            if constexpr (h == 1) split8(ev[t], bnh[t], bnl[t]);
+        };
+        auto load_lo = [&](auto Gc) {
+            constexpr int G = decltype(Gc)::value;
+            constexpr CwStep s = cw_step(G);
+            lo_ring[G % 3][0] = ld_lo(s.L, (2 * s.mp + 0) * 4 + s.kc);
+            lo_ring[G % 3][1] = ld_lo(s.L, (2 * s.mp + 1) * 4 + s.kc);
+        };
+        auto load_hi = [&](auto Gc) {
+            constexpr int G = decltype(Gc)::value;
+            constexpr CwStep s = cw_step(G);
+            hi_ring[G & 1][0] = ld_hi(s.L, (2 * s.mp + 0) * 4 + s.kc);
+            hi_ring[G & 1][1] = ld_hi(s.L, (2 * s.mp + 1) * 4 + s.kc);
+        };
+        load_lo(IC<0>{});
+        load_lo(IC<1>{});
+        load_hi(IC<0>{});
+        static_for<0, 2 * NT>([&](auto pc) { epart(IC<0>{}, IC<0>{}, pc); });
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            bch[t] = bnh[t];
+            bcl[t] = bnl[t];
+        }
+        clk.mark(1);
+        static_for<0, kCwSteps>([&](auto Gc) {
+            constexpr int G = decltype(Gc)::value;
+            constexpr CwStep s = cw_step(G);
+            constexpr int MP = s.L < 4 ? 4 : 1;
+            if constexpr (G + 2 < kCwSteps) load_lo(IC<G + 2>{});
+            if constexpr (G + 1 < kCwSteps) load_hi(IC<G + 1>{});
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        lo_ring[G % 3][h], bch[t], s.kc == 0 ? zero4 : acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        hi_ring[G & 1][h], bcl[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+                        hi_ring[G & 1][h], bch[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+            // the vector work that rides with this step
+            if constexpr (s.kc < 3) {
+                if constexpr (MP == 4) {
+                    epart(IC<s.L - 1>{}, IC<s.kc + 1>{}, IC<s.mp>{});
+                } else {
+                    static_for<0, 2 * NT>([&](auto pc) { epart(IC<s.L - 1>{}, IC<s.kc + 1>{}, pc); });
+                }
+            } else if constexpr (s.L < 4) {   // last chunk: M-tile pair 0 of THIS layer is final after its own step
+                if constexpr (s.mp == 1) epart(IC<s.L>{}, IC<0>{}, IC<0>{});
+                if constexpr (s.mp == 2) epart(IC<s.L>{}, IC<0>{}, IC<1>{});
+                if constexpr (s.mp == 3) {
+                    epart(IC<s.L>{}, IC<0>{}, IC<2>{});
+                    epart(IC<s.L>{}, IC<0>{}, IC<3>{});
+                }
+            }
+            if constexpr (s.mp == MP - 1 && !(s.L == 4 && s.kc == 3)) {   // chunk done: the fragments produced meanwhile are next
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bch[t] = bnh[t];
+                    bcl[t] = bnl[t];
+                }
+            }
+            if constexpr (G == 15) clk.mark(2);
+            if constexpr (G == 31) clk.mark(3);
+            if constexpr (G == 47) clk.mark(4);
+        });
+        clk.mark(5);
+        // ---- (4) per point: weights, row g of T = sum_j w_j A_j, residual, Broyden bookkeeping (as k_canon_solve)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            float* row = rows + j * kCwRowLd;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(b4 + h * 16 + 4 * g);
+                f32x4 lg;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) lg[r] = fmaf(acc[0][h][t][r], c_out, b[r]);
+                *reinterpret_cast<f32x4*>(row + h * 16 + 4 * g) = lg;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            f32x4 Trow = {0.f, 0.f, 0.f, 0.f};
+            {
+                float w[24];
+                hsoftmax_quad(row, g, w);
+#pragma unroll
+                for (int jn = 0; jn < 24; ++jn) {
+                    if ((jn & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // four bone rows in flight, not all 24 (VGPRs)
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sbones + jn * 16 + g * 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) Trow[c] = fmaf(w[jn], b[c], Trow[c]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float* s_ = st[t];
+            int* si_ = sti[t];
+            const int idc = id[t];
+            const int nev = si_[ST_NEV];
+            const float x0 = s_[ST_X], x1 = s_[ST_X + 1], x2 = s_[ST_X + 2];
+            const float xbar_g = fmaf(Trow[0], x0, fmaf(Trow[1], x1, fmaf(Trow[2], x2, Trow[3])));
+            const float gn_g = xbar_g - s_[ST_TG + min(g, 2)];
+            float gnew[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) gnew[r] = __shfl(gn_g, j + 16 * r);
+            const bool first = nev == 0;
+            float J[9];
+            if (__any(idc >= 0 && first)) {   // wave-uniform: J^-1_0 = (T[:3,:3])^-1 from the same weights (RFU:327-328)
+                float T9[16];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) T9[r * 4 + c] = __shfl(Trow[c], j + 16 * r);
+                inv3_of44(T9, J);
+            }
+            int flags = 0;   // bit 0: keep, bit 1: improved
+            if (g == 0 && idc >= 0) {
+                float gx[3], stp[3], eb;
+                bool keep, improved = false;
+                if (first) {
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
+                    eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                    keep = true;                                        // every point takes at least one step
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
+                } else {
+                    float dg[3], dxv[3];
+                    eb = s_[ST_EB];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const float gp = s_[ST_G + r];
+                        dxv[r] = s_[ST_STEP + r];
+                        dg[r] = gnew[r] - gp;
+                        gx[r] = gp + dg[r];                             // broyden.py:50-51
+                    }
+                    const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                    improved = err < eb;                                // broyden.py:54-61
+                    if (improved) {
+                        eb = err;
+                        s_[ST_XB] = x0;
+                        s_[ST_XB + 1] = x1;
+                        s_[ST_XB + 2] = x2;
+                    }
+                    keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
+                    if (keep) {
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) J[e] = s_[ST_J + e];
+                        broyden_update<3>(J, dxv, dg, gx, stp);          // broyden.py:69-75
+                    }
+                }
+                const float gsum = gx[0] + gx[1] + gx[2];
+                if (!(fabsf(gsum) < 3.0e38f)) ++n_bad;                  // a residual that is not finite: f16 overflow upstream
+                if (nev + 1 > kBroydenSteps) keep = false;              // 1 + 50 evaluations (broyden.py:44)
+                si_[ST_NEV] = nev + 1;
+                s_[ST_EB] = eb;
+                if (keep) {
+                    s_[ST_X] = x0 + stp[0];
+                    s_[ST_X + 1] = x1 + stp[1];
+                    s_[ST_X + 2] = x2 + stp[2];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        s_[ST_STEP + r] = stp[r];
+                        s_[ST_G + r] = gx[r];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) s_[ST_J + e] = J[e];
+                }
+                flags = (keep ? 1 : 0) | (improved ? 2 : 0);
+            }
+            flags = __shfl(flags, j);
+            if (flags & 2) tbr[t] = Trow;
+            if (idc >= 0 && !(flags & 1)) {   // retire: the best iterate is the result (broyden.py:78)
+                reinterpret_cast<f32x4*>(outp.T + (size_t)idc * 16)[g] = tbr[t];
+                if (g == 0) {
+                    outp.pts[(size_t)idc * 3] = s_[ST_XB];
+                    outp.pts[(size_t)idc * 3 + 1] = s_[ST_XB + 1];
+                    outp.pts[(size_t)idc * 3 + 2] = s_[ST_XB + 2];
+                    outp.err[idc] = s_[ST_EB];
+                    si_[ST_ID] = -1;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        clk.mark(6);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) n_bad += __shfl_xor(n_bad, o);
+    if (lane == 0) {
+        count_add(ctr, n_eval);
+        count_add(ctr_canon, n_eval);
+        count_add(ctr_bad, n_bad);
+    }
+#ifdef ARAH_CLOCKS
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&clk_out[wave * 16 + i], (unsigned long long)clk.acc[i]);
+#endif
+}

@@ -302,6 +302,22 @@ __device__ __forceinline__ void store_split4(float* act, int ld, int lo_off, int
     *reinterpret_cast<u32x2*>(row + lo_off + ch0 * 2) = lo;
 }
 
+// 8 fp32 values -> the hi and lo B fragments of a 16x16x32 step, in registers (same arithmetic as store_split4)
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 h, l;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f16x2 h2 = __builtin_convertvector(f32x2{v[2 * p], v[2 * p + 1]}, f16x2);
+        h[p] = __builtin_bit_cast(unsigned, h2);
+        l[p] = split_residual2(v[2 * p], v[2 * p + 1], h[p]);
+    }
+    hi = __builtin_bit_cast(f16x8, h);
+    lo = __builtin_bit_cast(f16x8, l);
+}
+
 __device__ __forceinline__ float load_split(const float* act, int ld, int lo_off, int pt, int ch) {
     const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4;
     return ((float)*reinterpret_cast<const _Float16*>(row + ch * 2) +
@@ -667,6 +683,36 @@ struct SkinNet {
 
 constexpr int kSkinLd = 132;
 constexpr int kLogitLd = 33;
+
+// Operands of the POINT-OWNING-wave kernels (csrc/canon_wave.hpp): a wave owns its points AND all 128 channels, a
+// layer's accumulators become the next layer's B fragments without leaving the registers.  That fixes the order in
+// which a 32-chunk of the contraction walks the channels -- lane (j, g) of a 16x16 accumulator tile holds channels
+// mt*16 + 4g + r of point j, so chunk kc, lane group g, element e is channel (2 kc + (e >> 2)) * 16 + 4 g + (e & 3)
+// -- and the weights are split-packed in that order (k_pack_split<PERM>).  Activations travel in the unit
+// z = 100 log2(e) x, in which Softplus(beta = 100) is log2(1 + 2^z) and needs no constants.
+struct SkinWave {
+    const f16x8* wpr;      // layer L (0..3) at byte kCwLayerBytes * L: [(mt*4 + kc)*2 + s][64 lanes] of 8 halves (s = 0 hi,
+                           // 1 lo) in the permuted channel order -- ONE block, so that a single buffer descriptor plus a
+                           // compile-time scalar offset addresses every fragment (no per-fragment address registers)
+    const float* consts;   // kCwW0 ..: see the enum
+};
+constexpr int kCwLayerBytes = 128 * 128 * 4;                 // hi + lo halves of a 128 x 128 layer
+constexpr int kCwWeightBytes = 3 * kCwLayerBytes + 32 * 128 * 4;
+enum {
+    kCwW0 = 0,      // [128][4]  {w0x, w0y, w0z, b0} * 100 log2(e)
+    kCwBz = 512,    // [3][128]  b_k * 100 log2(e), k = 1..3
+    kCwB4 = 896,    // [32]      b_4 (25 valid)
+    kCwInv = 928,   // [4]       1 / weight scale of layers 1..3; ln(2)/100 / weight scale of layer 4
+    kCwSize = 936
+};
+constexpr float kZUnit = 144.269504088896341f;   // 100 log2(e)
+
+// Softplus(beta = 100) in z units: S(z) = log2(1 + 2^z) = max(z, 0) + log2(1 + 2^-|z|).  Two transcendentals and
+// three plain operations; the absolute error is that of 1 + e (6e-8 in z, 4e-10 in x).
+__device__ __forceinline__ float softplus_z(float z) {
+    const float e = __builtin_amdgcn_exp2f(-fabsf(z));
+    return fmaxf(z, 0.f) + __builtin_amdgcn_logf(1.0f + e);
+}
 
 // Softplus(beta=100): log1p(exp(100 x))/100 == max(x,0) + log1p(exp(-|100 x|))/100.  The correction is
 // <= 0.00693 and needs only ABSOLUTE accuracy (~1e-9 here), so the hardware exp2/log2 are fed directly: the

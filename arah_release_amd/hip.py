@@ -58,7 +58,7 @@ class ArahFrame(C.Structure):
                 ("sdf_bias", _fp), ("sdf_freq", _fp), ("sdf_phase", _fp),
                 ("sdf_wps", _fp * 5), ("sdf_fw", _fp), ("sdf_pw", _fp), ("sdf_fws", _fp),
                 ("skin_w0", _fp), ("skin_wp", _fp * 3), ("skin_w4p", _fp), ("skin_bias", _fp),
-                ("skin_wps", _fp * 4), ("skin_scales", _fp),
+                ("skin_wps", _fp * 4), ("skin_scales", _fp), ("skin_wpr", _fp), ("skin_wconsts", _fp),
                 ("col_w0p", _fp), ("col_w1p", _fp), ("col_w2p", _fp), ("col_w3ap", _fp), ("col_w3bp", _fp),
                 ("col_w4p", _fp), ("col_w5", _fp), ("col_bias", _fp),
                 ("col_w0pT", _fp), ("col_w1pT", _fp), ("col_w2pT", _fp), ("col_w3apT", _fp), ("col_w3bpT", _fp),
@@ -83,7 +83,7 @@ class ArahTrainGrads(C.Structure):
 class ArahCounters(C.Structure):
     _fields_ = [("n_sdf_fwd", C.c_uint64), ("n_sdf_grad", C.c_uint64), ("n_skin_fwd", C.c_uint64),
                 ("n_skin_jac", C.c_uint64), ("n_col", C.c_uint64), ("n_knn", C.c_uint64),
-                ("n_density", C.c_uint64), ("n_canon", C.c_uint64)]
+                ("n_density", C.c_uint64), ("n_canon", C.c_uint64), ("n_split_nonfinite", C.c_uint64)]
 
 
 COUNTER_BYTES = C.sizeof(ArahCounters)
@@ -241,7 +241,7 @@ class Workspace:
             _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream(self.device)),
                    "arah_counters_read")
         return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn",
-                                                   "n_density", "n_canon")}
+                                                   "n_density", "n_canon", "n_split_nonfinite")}
 
 
 class Frame:

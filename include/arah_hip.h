@@ -143,6 +143,8 @@ typedef struct ArahFrame {
     const float* skin_bias;     /* [4][128] + [32] */
     const void* skin_wps[4];    /* split-packed 128x128 x3 and [32][128] */
     const float* skin_scales;   /* [8] activation scales S_k (probed per frame) and accumulator un-scales */
+    const void* skin_wpr;       /* 4 layers, split-packed in the channel order of the point-owning-wave kernels (csrc/canon_wave.hpp) */
+    const float* skin_wconsts;  /* their constants: first layer, biases in z = 100 log2(e) x units, un-scales */
     const float* col_w0p;       /* packed [256][KIN_PAD] (columns permuted to [feat,x,n,view]) */
     const float* col_w1p;       /* packed [256][256] */
     const float* col_w2p;       /* packed [128][256] */
@@ -174,7 +176,10 @@ typedef struct ArahFrame {
 typedef struct ArahCounters {
     uint64_t n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn;
     uint64_t n_density;   /* samples seen by the density pre-pass of lazy shading (a subset of n_sdf_fwd) */
-    uint64_t n_canon;     /* skinning-MLP evaluations of loop C (k_canon_solve; a subset of n_skin_fwd) */
+    uint64_t n_canon;     /* skinning-MLP evaluations of loop C (k_canon_wave / k_canon_solve; a subset of n_skin_fwd) */
+    uint64_t n_split_nonfinite; /* loop-C evaluations of the split engine whose residual was not finite (an activation
+                                   left the f16 range): non-zero means the frame should be re-prepared with
+                                   ARAH_PRECISION_FP32 */
 } ArahCounters;
 
 /* ---- frame preparation ------------------------------------------------------------------ */

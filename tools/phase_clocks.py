@@ -15,7 +15,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "tools", "ubench", "bin", "libarah_clk.so")
-NAMES = ["refill", "bar0", "layer0", "gemm1", "epi1", "gemm2", "epi2", "gemm3", "epi3", "out", "tail", "bar1"]
+NAMES_TILE = ["refill", "bar0", "layer0", "gemm1", "epi1", "gemm2", "epi2", "gemm3", "epi3", "out", "tail", "bar1"]
+# k_canon_wave (the default): 0 refill + claim, 1 first chunk of the input layer, 2..4 hidden layers 1..3 (MFMA steps with the
+# epilogue parts that ride along), 5 output layer, 6 per-point tail
+NAMES_WAVE = ["refill", "layer0.0", "layer1", "layer2", "layer3", "out", "tail"]
+NAMES = NAMES_TILE if os.environ.get("ARAH_CANON_KERNEL") == "tile" else NAMES_WAVE
 
 
 def build():
