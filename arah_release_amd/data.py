@@ -340,7 +340,8 @@ def training_item(model, camera, body, faces, image, mask, mask_erode, img_size,
                          item["image.T"][0], num_fg_samples, num_bg_samples, generator)
     item.update(rays)
     item.pop("inputs.image_mask", None)
-    item["inputs.novel_seq"] = torch.tensor([False])
+    item.pop("inputs.novel_seq", None)   # the training dataset never emits the key (zju_mocap.py); its PRESENCE is what
+                                         # compose_inputs tests (lightning_model.py:497-498) before dropping the frame index
     pts = training_samples(item["image.minimal_shape"][0], torch.as_tensor(np.asarray(faces), device=device),
                            f32(body.lbs_weights), item["image.coord_min"][0], item["image.coord_max"][0],
                            item["image.center"][0], sample_reg_surface, sample_inside, off_surface_thr, inside_thr, generator)

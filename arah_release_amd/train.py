@@ -49,16 +49,120 @@ def epoch_indices(n_items, epoch, rank, world, seed=0):
     return idx[rank:total:world]
 
 
+class GradientExchange:
+    """The data-parallel gradient exchange of one training step (what DistributedDataParallel with
+    find_unused_parameters=True did for the reference's `strategy='ddp'`, train.py:131).
+
+    * The parameter list and its partition into buckets (~25 MB, in reverse registration order: the order gradients
+      become ready in) are the same on every rank, whatever subset of the parameters a rank's item touched -- per-frame
+      SMPL parameters (train_smpl, models/__init__.py:117-123) get a gradient only on the rank that drew their frame.
+    * A bucket whose gradients have all arrived is all-reduced at once, from the gradient hooks, while backward() is
+      still running: the 348 MB exchange overlaps the backward pass.  Collectives are matched by issue order, so buckets
+      go out strictly in bucket order on every rank: a bucket holding a parameter that did not fire on this rank, and
+      every bucket after it, goes out in finish(), the missing gradients zero-filled.
+    * finish() also sums a presence map: a parameter that received a gradient on NO rank keeps grad None (Adam skips it,
+      like under DDP); every other parameter gets the mean over ALL ranks (absent contributions count as zero).  The
+      last entry of the map carries the ranks' stop requests (--exit-after), so that all ranks leave together."""
+
+    def __init__(self, params, world, dist, bucket_bytes=25 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.world, self.dist = world, dist
+        self.order = list(range(len(self.params)))[::-1]
+        self.buckets, cur, size = [], [], 0
+        for i in self.order:
+            n = self.params[i].numel() * self.params[i].element_size()
+            if cur and size + n > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(i)
+            size += n
+        if cur:
+            self.buckets.append(cur)
+        self.bucket_of, self.offset = {}, {}
+        self.flat = []
+        for b, idx in enumerate(self.buckets):
+            off = 0
+            for i in idx:
+                self.bucket_of[i], self.offset[i] = b, off
+                off += self.params[i].numel()
+            p0 = self.params[idx[0]]
+            self.flat.append(torch.zeros(off, dtype=p0.dtype, device=p0.device))
+        self.hooks = []
+        if world > 1:
+            for i, p in enumerate(self.params):
+                self.hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._ready(i)))
+        self.begin()
+
+    def begin(self):
+        self.fired = [False] * len(self.params)
+        self.missing = [len(idx) for idx in self.buckets]
+        self.work = [None] * len(self.buckets)
+        self.next = 0        # first bucket that has not been sent yet
+
+    def _slice(self, i):
+        p = self.params[i]
+        return self.flat[self.bucket_of[i]][self.offset[i]:self.offset[i] + p.numel()]
+
+    def _ready(self, i):
+        if self.fired[i]:
+            return          # (a second accumulation into the same parameter would need a second exchange: not the case here)
+        self.fired[i] = True
+        self._slice(i).copy_(self.params[i].grad.reshape(-1))
+        self.missing[self.bucket_of[i]] -= 1
+        while self.next < len(self.buckets) and self.missing[self.next] == 0:
+            self.work[self.next] = self.dist.all_reduce(self.flat[self.next], async_op=True)
+            self.next += 1
+
+    def finish(self, stop=False):
+        """Call after backward().  Returns True if any rank asked to stop."""
+        if self.world == 1:
+            self.begin()
+            return bool(stop)
+        dev = self.params[0].device
+        for i, p in enumerate(self.params):                       # gradients set without a hook firing (tests, manual .grad)
+            if not self.fired[i] and p.grad is not None:
+                self._ready(i)
+        for b in range(self.next, len(self.buckets)):
+            for i in self.buckets[b]:
+                if not self.fired[i]:
+                    self._slice(i).zero_()
+            self.work[b] = self.dist.all_reduce(self.flat[b], async_op=True)
+        self.next = len(self.buckets)
+        seen = torch.tensor([1.0 if f else 0.0 for f in self.fired] + [1.0 if stop else 0.0], device=dev)
+        seen_work = self.dist.all_reduce(seen, async_op=True)
+        seen_work.wait()
+        seen = seen.cpu()
+        for b in range(len(self.buckets)):
+            self.work[b].wait()
+            self.flat[b].div_(self.world)
+        for i, p in enumerate(self.params):
+            if seen[i] > 0:
+                if p.grad is None:
+                    p.grad = self._slice(i).view_as(p).clone()
+                else:
+                    p.grad.copy_(self._slice(i).view_as(p))
+        self.begin()
+        return bool(seen[-1] > 0)
+
+
 def allreduce_gradients(params, world, dist):
-    """One flat all-reduce (mean) of every gradient: 348 MB fp32 for the ARAH model, a single RCCL collective per step."""
-    grads = [p.grad for p in params if p.grad is not None]
-    if world == 1 or not grads:
+    """One-shot form of GradientExchange for gradients that are already in place (no overlap with backward)."""
+    if world == 1:
         return
-    flat = torch._utils._flatten_dense_tensors(grads)
-    dist.all_reduce(flat)
-    flat.div_(world)
-    for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
-        g.copy_(f)
+    ex = GradientExchange(params, world, dist)
+    for h in ex.hooks:
+        h.remove()
+    ex.finish()
+
+
+def broadcast_state(module, world, dist):
+    """Rank 0's parameters and buffers to every rank (what Lightning's DDP does when it wraps the model): the parts that
+    are not loaded from files -- the colour network, the latent codes, most of the hypernetwork -- are drawn from each
+    process's own generator."""
+    if world == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, 0)
 
 
 def save_checkpoint(path, lm, opt, epoch, global_step):
@@ -102,6 +206,7 @@ def main(argv=None, body=None, faces=None, log=print):
         off_surface_thr=d["off_surface_thr"], inside_thr=d["inside_thr"], box_margin=d["box_margin"], sampling=d["sampling"],
         sample_reg_surface=d["sample_reg_surface"], sample_inside=t_cfg.get("inside_weight", 0) > 0, erode_mask=d["erode_mask"],
         body=body, faces=faces, body_models=args.body_models)
+    torch.manual_seed(0)
     lm = config.get_model(cfg, dataset=dataset, mode="train", body_model=body).to(device)
     lm.train()
     opt = lm.configure_optimizers()
@@ -113,9 +218,11 @@ def main(argv=None, body=None, faces=None, log=print):
         if ck.get("optimizer_states"):
             opt.load_state_dict(ck["optimizer_states"][0])
         epoch0, step, ckpt_epoch = ck["epoch"], ck.get("global_step", 0), ck["epoch"]
+    broadcast_state(lm.model, world, dist)
     max_epochs = epochs_to_run(t_cfg["max_epochs"], args.epochs_per_run, ckpt_epoch)
     every = t_cfg.get("checkpoint_every_n_epochs", 1)
     params = [p for p in lm.model.parameters() if p.requires_grad]
+    exchange = GradientExchange(params, world, dist)
     gen = torch.Generator(device=device)
     gen.manual_seed(1234 + rank)
     t_start = time.time()
@@ -124,15 +231,18 @@ def main(argv=None, body=None, faces=None, log=print):
             item = dataset.item(idx, device, generator=gen)
             opt.zero_grad(set_to_none=True)
             losses = lm.compute_loss(item)
-            losses["loss"].backward()
-            allreduce_gradients(params, world, dist)
+            losses["loss"].backward()           # buckets of gradients are all-reduced from the hooks while this runs
+            stop = exchange.finish(stop=args.exit_after > 0 and time.time() - t_start > args.exit_after)
             opt.step()
             step += 1
             if rank == 0 and step % 10 == 0:          # log_every_n_steps=10 (train.py:125)
                 log("epoch %d step %d " % (epoch, step) + " ".join("%s %.5f" % (k, float(v)) for k, v in losses.items()))
-            if args.exit_after > 0 and time.time() - t_start > args.exit_after:
+            if stop:                                  # a collective decision: every rank sees the same flag at the same step
                 if rank == 0:
                     save_checkpoint(ckpt_path, lm, opt, epoch, step)
+                if world > 1:
+                    dist.barrier()
+                    dist.destroy_process_group()
                 sys.exit(2)
         if rank == 0 and ((epoch + 1) % every == 0 or epoch + 1 == max_epochs):
             save_checkpoint(ckpt_path, lm, opt, epoch + 1, step)

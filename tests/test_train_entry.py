@@ -82,6 +82,70 @@ def test_allreduce_gradients_two_ranks_gloo():
         assert torch.equal(g0, torch.full((3, 4), 1.5)) and torch.equal(g1, torch.arange(5.0) * 1.5) and g2 is None
 
 
+def _exchange_worker(rank, world, port, out):
+    """Two replicas whose items touch DIFFERENT parameters (per-frame parameters under train_smpl): gradients arrive through
+    the hooks during backward(), small buckets force several collectives, one parameter is used by no rank."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                              # replicas start from different draws ...
+    net = torch.nn.ModuleDict({"shared": torch.nn.Linear(6, 5), "frames": torch.nn.ParameterDict(
+        {"pose_0": torch.nn.Parameter(torch.randn(6)), "pose_1": torch.nn.Parameter(torch.randn(6)),
+         "pose_2": torch.nn.Parameter(torch.randn(6))}), "head": torch.nn.Linear(5, 1)})
+    train.broadcast_state(net, world, dist)                    # ... and are made equal, like Lightning's DDP does
+    start = {k: v.clone() for k, v in net.state_dict().items()}
+    params = list(net.parameters())
+    ex = train.GradientExchange(params, world, dist, bucket_bytes=64)
+    assert len(ex.buckets) > 2
+    opt = torch.optim.Adam(params, lr=0.1)
+    stops = []
+    for step in range(3):
+        opt.zero_grad(set_to_none=True)
+        x = net["frames"]["pose_%d" % rank] * (step + 1.0)     # rank r draws frame r: pose_2 is never used
+        loss = net["head"](torch.tanh(net["shared"](x))).sum()
+        loss.backward()
+        stops.append(ex.finish(stop=(rank == 1 and step == 2)))
+        if step == 0:
+            grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+        opt.step()
+    out[rank] = (start, grads, {k: v.clone() for k, v in net.state_dict().items()}, stops, loss.item())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_with_rank_dependent_parameter_sets():
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    (s0, g0, e0, stop0, _), (s1, g1, e1, stop1, _) = out[0], out[1]
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k                    # broadcast_state
+    assert g0["frames.pose_2"] is None and g1["frames.pose_2"] is None            # used by no rank: stays None
+    for k in g0:
+        if g0[k] is not None:
+            assert torch.equal(g0[k], g1[k]), k                # every rank holds the same averaged gradient
+    # reference: the mean over ranks of the local gradients, absent contributions counted as zero
+    torch.manual_seed(0)
+    net = torch.nn.ModuleDict({"shared": torch.nn.Linear(6, 5), "frames": torch.nn.ParameterDict(
+        {"pose_0": torch.nn.Parameter(torch.zeros(6)), "pose_1": torch.nn.Parameter(torch.zeros(6)),
+         "pose_2": torch.nn.Parameter(torch.zeros(6))}), "head": torch.nn.Linear(5, 1)})
+    net.load_state_dict(s0)
+    want = {n: torch.zeros_like(p) for n, p in net.named_parameters()}
+    for rank in range(2):
+        net.zero_grad(set_to_none=True)
+        net["head"](torch.tanh(net["shared"](net["frames"]["pose_%d" % rank]))).sum().backward()
+        for n, p in net.named_parameters():
+            if p.grad is not None:
+                want[n] += p.grad / 2
+    for n in want:
+        if g0[n] is not None:
+            torch.testing.assert_close(g0[n], want[n], rtol=1e-6, atol=1e-7)
+    assert not torch.equal(e0["frames.pose_0"], s0["frames.pose_0"]) and torch.equal(e0["frames.pose_2"], s0["frames.pose_2"])
+    for k in e0:
+        assert torch.equal(e0[k], e1[k]), k                    # replicas stay identical after three Adam steps
+    assert stop0 == stop1 == [False, False, True]              # the stop request of one rank reaches every rank, same step
+
+
 @pytest.mark.gpu
 def test_train_entry_end_to_end(tmp_path, scene, monkeypatch):
     """python -m arah_release_amd.train on a capture written in the reference's layout: two epochs over two views, the

@@ -20,6 +20,10 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="zju313")
+    ap.add_argument("--exchange", default="native", choices=["native", "ddp"],
+                    help="native: arah_release_amd.train.GradientExchange (the product's train entry: fixed bucket order, "
+                         "presence map for parameters a rank did not use); ddp: torch DistributedDataParallel with "
+                         "find_unused_parameters=True (what the reference's Lightning strategy='ddp' amounts to)")
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -33,10 +37,17 @@ def main():
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from arah_release_amd import config, synthetic, training
+    from arah_release_amd import config, synthetic, training, train
+    torch.manual_seed(0)
     model, cfg = config.build_synthetic_model(args.config, device=dev)
     model.train()
-    net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local]) if world > 1 else model
+    exchange = None
+    if world > 1 and args.exchange == "ddp":
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
+    else:
+        net = model
+        train.broadcast_state(model, world, dist)
+        exchange = train.GradientExchange([p for p in model.parameters() if p.requires_grad], world, dist)
     opt = training.configure_optimizers(model, cfg)
     crit = training.build_loss(cfg)
     scene = synthetic.SyntheticScene(0)
@@ -48,6 +59,8 @@ def main():
         opt.zero_grad(set_to_none=True)
         losses = training.training_step(net, crit, inp)
         losses["loss"].backward()
+        if exchange is not None:
+            exchange.finish()
         opt.step()
         return losses
 
