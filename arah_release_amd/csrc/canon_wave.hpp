@@ -40,6 +40,13 @@ __host__ __device__ constexpr CwStep cw_step(int G) {
     return G < 48 ? CwStep{G / 16 + 1, (G % 16) / 4, G % 4} : CwStep{4, G - 48, 0};
 }
 constexpr int kCwSteps = 52;
+#ifndef CW_LO_DIST
+#define CW_LO_DIST 2    // MFMA steps the lo fragments (L2) are requested ahead of their use
+#endif
+#ifndef CW_HI_DIST
+#define CW_HI_DIST 1    // the same for the hi fragments (LDS)
+#endif
+constexpr int kCwLoDist = CW_LO_DIST, kCwHiDist = CW_HI_DIST;
 
 // compile-time loop: the body sees its index as a constant expression (register arrays are indexed statically whatever
 // the unroller's thresholds say)
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
     for (int pass = 0;; ++pass) {
         // watchdog: a launch of this kernel is tens of milliseconds; a wave that is still here after 5 s gives up (its
         // remaining points keep their start states and are reported through n_split_nonfinite)
-        if (__builtin_amdgcn_s_memrealtime() - t_start > 500000000ull) {
+        if ((pass & 63) == 63 && __builtin_amdgcn_s_memrealtime() - t_start > 500000000ull) {
             n_bad += 1 << 20;
             break;
         }
@@ -247,42 +254,52 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
         // ---- (3) skinning MLP, accumulators -> B fragments in registers
         f32x4 acc[2][8][NT];
         f16x8 bch[NT], bcl[NT], bnh[NT], bnl[NT];
-        float ev[NT][8];
-        f16x8 lo_ring[3][2], hi_ring[2][2];
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 pkh[NT], pkl[NT];   // the fragments being produced, as packed words
+        f16x8 lo_ring[kCwLoDist + 1][2], hi_ring[kCwHiDist + 1][2];
         // part p of the epilogue of layer L's M-tile pair q (L = 0: the K = 3 input layer) -> B chunk q of layer L + 1
         auto epart = [&](auto Lc, auto qc, auto pc) {
             constexpr int L = decltype(Lc)::value, q = decltype(qc)::value, p = decltype(pc)::value;
             constexpr int t = p >> 1, h = p & 1;
             constexpr int mt = 2 * q + h;
+            float v[4];
             if constexpr (L == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const f32x4 w = *reinterpret_cast<const f32x4*>(w0c + (mt * 16 + 4 * g + r) * 4);
-                    ev[t][h * 4 + r] = softplus_z(fmaf(w[2], xr[t][2], fmaf(w[1], xr[t][1], fmaf(w[0], xr[t][0], w[3]))));
+                    v[r] = softplus_z(fmaf(w[2], xr[t][2], fmaf(w[1], xr[t][1], fmaf(w[0], xr[t][0], w[3]))));
                 }
             } else {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(bz + (L - 1) * 128 + mt * 16 + 4 * g);
                 const float inv = L == 1 ? inv1 : (L == 2 ? inv2 : inv3);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) ev[t][h * 4 + r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, b[r]));
+                for (int r = 0; r < 4; ++r) v[r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, b[r]));
             }
-            if constexpr (h == 1) split8(ev[t], bnh[t], bnl[t]);
+            unsigned h0, h1, l0, l1;
+            split4(v, h0, h1, l0, l1);
+            pkh[t][2 * h] = h0;
+            pkh[t][2 * h + 1] = h1;
+            pkl[t][2 * h] = l0;
+            pkl[t][2 * h + 1] = l1;
+            if constexpr (h == 1) {
+                bnh[t] = __builtin_bit_cast(f16x8, pkh[t]);
+                bnl[t] = __builtin_bit_cast(f16x8, pkl[t]);
+            }
         };
         auto load_lo = [&](auto Gc) {
             constexpr int G = decltype(Gc)::value;
             constexpr CwStep s = cw_step(G);
-            lo_ring[G % 3][0] = ld_lo(s.L, (2 * s.mp + 0) * 4 + s.kc);
-            lo_ring[G % 3][1] = ld_lo(s.L, (2 * s.mp + 1) * 4 + s.kc);
+            lo_ring[G % (kCwLoDist + 1)][0] = ld_lo(s.L, (2 * s.mp + 0) * 4 + s.kc);
+            lo_ring[G % (kCwLoDist + 1)][1] = ld_lo(s.L, (2 * s.mp + 1) * 4 + s.kc);
         };
         auto load_hi = [&](auto Gc) {
             constexpr int G = decltype(Gc)::value;
             constexpr CwStep s = cw_step(G);
-            hi_ring[G & 1][0] = ld_hi(s.L, (2 * s.mp + 0) * 4 + s.kc);
-            hi_ring[G & 1][1] = ld_hi(s.L, (2 * s.mp + 1) * 4 + s.kc);
+            hi_ring[G % (kCwHiDist + 1)][0] = ld_hi(s.L, (2 * s.mp + 0) * 4 + s.kc);
+            hi_ring[G % (kCwHiDist + 1)][1] = ld_hi(s.L, (2 * s.mp + 1) * 4 + s.kc);
         };
-        load_lo(IC<0>{});
-        load_lo(IC<1>{});
-        load_hi(IC<0>{});
+        static_for<0, kCwLoDist>([&](auto Gc) { load_lo(Gc); });
+        static_for<0, kCwHiDist>([&](auto Gc) { load_hi(Gc); });
         static_for<0, 2 * NT>([&](auto pc) { epart(IC<0>{}, IC<0>{}, pc); });
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -294,27 +311,27 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
             constexpr int G = decltype(Gc)::value;
             constexpr CwStep s = cw_step(G);
             constexpr int MP = s.L < 4 ? 4 : 1;
-            if constexpr (G + 2 < kCwSteps) load_lo(IC<G + 2>{});
-            if constexpr (G + 1 < kCwSteps) load_hi(IC<G + 1>{});
+            if constexpr (G + kCwLoDist < kCwSteps) load_lo(IC<G + kCwLoDist>{});
+            if constexpr (G + kCwHiDist < kCwSteps) load_hi(IC<G + kCwHiDist>{});
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        lo_ring[G % 3][h], bch[t], s.kc == 0 ? zero4 : acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+                        lo_ring[G % (kCwLoDist + 1)][h], bch[t], s.kc == 0 ? zero4 : acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        hi_ring[G & 1][h], bcl[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+                        hi_ring[G % (kCwHiDist + 1)][h], bcl[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        hi_ring[G & 1][h], bch[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+                        hi_ring[G % (kCwHiDist + 1)][h], bch[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
             // the vector work that rides with this step
             if constexpr (s.kc < 3) {
                 if constexpr (MP == 4) {
@@ -426,8 +443,9 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
                         broyden_update<3>(J, dxv, dg, gx, stp);          // broyden.py:69-75
                     }
                 }
-                const float gsum = gx[0] + gx[1] + gx[2];
-                if (!(fabsf(gsum) < 3.0e38f)) ++n_bad;                  // a residual that is not finite: f16 overflow upstream
+                // a FIRST residual (at the nearest-vertex start) that is not finite: an activation left the f16 range
+                // (later ones also come from iterates that genuinely diverge; either way the point retires below)
+                if (first && !(fabsf(gx[0] + gx[1] + gx[2]) < 3.0e38f)) ++n_bad;
                 if (nev + 1 > kBroydenSteps) keep = false;              // 1 + 50 evaluations (broyden.py:44)
                 si_[ST_NEV] = nev + 1;
                 s_[ST_EB] = eb;

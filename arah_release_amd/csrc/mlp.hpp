@@ -318,6 +318,16 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
     lo = __builtin_bit_cast(f16x8, l);
 }
 
+// 4 fp32 values -> two packed words of hi halves and two of lo halves (half a split8)
+__device__ __forceinline__ void split4(const float (&v)[4], unsigned& h0, unsigned& h1, unsigned& l0, unsigned& l1) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    h0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[0], v[1]}, f16x2));
+    h1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2], v[3]}, f16x2));
+    l0 = split_residual2(v[0], v[1], h0);
+    l1 = split_residual2(v[2], v[3], h1);
+}
+
 __device__ __forceinline__ float load_split(const float* act, int ld, int lo_off, int pt, int ch) {
     const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4;
     return ((float)*reinterpret_cast<const _Float16*>(row + ch * 2) +
