@@ -22,8 +22,14 @@
 // Activations travel in z = 100 log2(e) x (softplus_z); results differ from the tile kernel's by rounding only.
 #pragma once
 
-constexpr int kCwNT = 2;                        // N-tiles (16 points each) per wave
-constexpr int kCwWaves = 8;
+#ifndef CW_NT
+#define CW_NT 2
+#endif
+constexpr int kCwNT = CW_NT;                        // N-tiles (16 points each) per wave
+#ifndef CW_WAVES
+#define CW_WAVES 8
+#endif
+constexpr int kCwWaves = CW_WAVES;
 constexpr int kCwThreads = kCwWaves * 64;
 constexpr int kCwSlots = 16 * kCwNT;            // points per wave
 constexpr int kCwRowLd = 36;                    // logits row stride (floats): 16-byte aligned rows
@@ -40,6 +46,25 @@ __host__ __device__ constexpr CwStep cw_step(int G) {
     return G < 48 ? CwStep{G / 16 + 1, (G % 16) / 4, G % 4} : CwStep{4, G - 48, 0};
 }
 constexpr int kCwSteps = 52;
+
+// Which parts (of the 2 NT an M-tile pair's epilogue has: N-tile x M-tile of the pair) ride with MFMA step (L, kc, mp).
+// kc < 3: the parts belong to pair kc + 1 of layer L - 1 -- spread over the four steps of a hidden layer's chunk, all of
+// them in the single step of an output-layer chunk.  Last chunk of a hidden layer: pair 0 of layer L itself, which is
+// final once its own step (mp = 0) has issued.
+struct CwParts {
+    int first, count;
+};
+__host__ __device__ constexpr CwParts cw_parts(int NT, int L, int kc, int mp) {
+    const int n = 2 * NT;
+    if (kc < 3) {
+        if (L == 4) return CwParts{0, n};
+        if (n >= 4) return CwParts{mp * (n / 4), n / 4};          // n = 4 (two N-tiles): one part per step
+        return (mp & 1) ? CwParts{0, 0} : CwParts{mp / 2, 1};      // n = 2 (one N-tile): steps 0 and 2
+    }
+    if (L == 4 || mp == 0) return CwParts{0, 0};
+    if (n >= 4) return mp == 3 ? CwParts{2 * (n / 4), n - 2 * (n / 4)} : CwParts{(mp - 1) * (n / 4), n / 4};
+    return mp == 3 ? CwParts{0, 0} : CwParts{mp - 1, 1};
+}
 #ifndef CW_LO_DIST
 #define CW_LO_DIST 2    // MFMA steps the lo fragments (L2) are requested ahead of their use
 #endif
@@ -63,7 +88,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 
 template <bool HI_LDS>
-__global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
+__global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
                                                               int* queue_head, CanonOut outp, unsigned long long* ctr,
                                                               unsigned long long* ctr_canon,
                                                               unsigned long long* ctr_bad, unsigned long long* clk_out) {
@@ -76,13 +101,15 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
 #endif
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
-    char* whi = reinterpret_cast<char*>(smem);
-    float* w0c = reinterpret_cast<float*>(whi + (HI_LDS ? kCwHiBytes : 0));
+    // small operands first: their absolute LDS offsets stay below 64 KB, i.e. inside the offset field of the DS
+    // instructions (one address register per lane pattern, not one per constant for the compiler to hoist and spill)
+    float* w0c = smem;
     float* bz = w0c + kCwBz;
     float* b4 = w0c + kCwB4;
     float* sbones = w0c + kCwConstFloats;
     float* state = sbones + 24 * 16 + wave * kCwWaveFloats;   // [kCwSlots][ST_SIZE]
     float* rows = state + kCwSlots * ST_SIZE;                 // [16][kCwRowLd] logits of the N-tile in the tail
+    char* whi = reinterpret_cast<char*>(sbones + 24 * 16 + kCwWaves * kCwWaveFloats);   // hi fragments (HI_LDS)
     const float* cst = fr.skw.consts;
     // ---- launch prologue: operands into LDS (the only workgroup barrier of the kernel)
     for (int i = tid; i < kCwConstFloats; i += kCwThreads) w0c[i] = cst[i];
@@ -257,23 +284,36 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 pkh[NT], pkl[NT];   // the fragments being produced, as packed words
         f16x8 lo_ring[kCwLoDist + 1][2], hi_ring[kCwHiDist + 1][2];
-        // part p of the epilogue of layer L's M-tile pair q (L = 0: the K = 3 input layer) -> B chunk q of layer L + 1
-        auto epart = [&](auto Lc, auto qc, auto pc) {
+        // part p of the epilogue of layer L's M-tile pair q (L = 0: the K = 3 input layer) -> B chunk q of layer L + 1.
+        // Its constants (bias quad; first-layer rows) are fetched by epre ahead of the MFMAs of the step the part rides with.
+        struct EpiPre {
+            f32x4 v[4];
+        };
+        auto epre = [&](auto Lc, auto qc, auto pc) {
+            constexpr int L = decltype(Lc)::value, q = decltype(qc)::value, p = decltype(pc)::value;
+            constexpr int mt = 2 * q + (p & 1);
+            EpiPre e;
+            if constexpr (L == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) e.v[r] = *reinterpret_cast<const f32x4*>(w0c + (mt * 16 + 4 * g + r) * 4);
+            } else {
+                e.v[0] = *reinterpret_cast<const f32x4*>(bz + (L - 1) * 128 + mt * 16 + 4 * g);
+            }
+            return e;
+        };
+        auto epart = [&](auto Lc, auto qc, auto pc, const EpiPre& e) {
             constexpr int L = decltype(Lc)::value, q = decltype(qc)::value, p = decltype(pc)::value;
             constexpr int t = p >> 1, h = p & 1;
             constexpr int mt = 2 * q + h;
             float v[4];
             if constexpr (L == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(w0c + (mt * 16 + 4 * g + r) * 4);
-                    v[r] = softplus_z(fmaf(w[2], xr[t][2], fmaf(w[1], xr[t][1], fmaf(w[0], xr[t][0], w[3]))));
-                }
+                for (int r = 0; r < 4; ++r)
+                    v[r] = softplus_z(fmaf(e.v[r][2], xr[t][2], fmaf(e.v[r][1], xr[t][1], fmaf(e.v[r][0], xr[t][0], e.v[r][3]))));
             } else {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(bz + (L - 1) * 128 + mt * 16 + 4 * g);
                 const float inv = L == 1 ? inv1 : (L == 2 ? inv2 : inv3);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, b[r]));
+                for (int r = 0; r < 4; ++r) v[r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, e.v[0][r]));
             }
             unsigned h0, h1, l0, l1;
             split4(v, h0, h1, l0, l1);
@@ -300,7 +340,7 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
         };
         static_for<0, kCwLoDist>([&](auto Gc) { load_lo(Gc); });
         static_for<0, kCwHiDist>([&](auto Gc) { load_hi(Gc); });
-        static_for<0, 2 * NT>([&](auto pc) { epart(IC<0>{}, IC<0>{}, pc); });
+        static_for<0, 2 * NT>([&](auto pc) { epart(IC<0>{}, IC<0>{}, pc, epre(IC<0>{}, IC<0>{}, pc)); });
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             bch[t] = bnh[t];
@@ -313,6 +353,15 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
             constexpr int MP = s.L < 4 ? 4 : 1;
             if constexpr (G + kCwLoDist < kCwSteps) load_lo(IC<G + kCwLoDist>{});
             if constexpr (G + kCwHiDist < kCwSteps) load_hi(IC<G + kCwHiDist>{});
+            // which epilogue parts ride with this step (up to four): kc < 3 -> pair kc + 1 of the previous layer (one part per
+            // step of a hidden layer, all four in a step of the output layer); last chunk -> pair 0 of THIS layer, which is
+            // final after its own step (mp = 0)
+            constexpr bool prev = s.kc < 3;
+            constexpr int EL = prev ? s.L - 1 : s.L, EQ = prev ? s.kc + 1 : 0;
+            constexpr CwParts parts = cw_parts(NT, s.L, s.kc, s.mp);
+            constexpr int P0 = parts.first, NP = parts.count;
+            EpiPre pre[NP > 0 ? NP : 1];
+            static_for<0, NP>([&](auto ic) { pre[decltype(ic)::value] = epre(IC<EL>{}, IC<EQ>{}, IC<P0 + decltype(ic)::value>{}); });
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -332,21 +381,7 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
                 for (int t = 0; t < NT; ++t)
                     acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                         hi_ring[G % (kCwHiDist + 1)][h], bch[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
-            // the vector work that rides with this step
-            if constexpr (s.kc < 3) {
-                if constexpr (MP == 4) {
-                    epart(IC<s.L - 1>{}, IC<s.kc + 1>{}, IC<s.mp>{});
-                } else {
-                    static_for<0, 2 * NT>([&](auto pc) { epart(IC<s.L - 1>{}, IC<s.kc + 1>{}, pc); });
-                }
-            } else if constexpr (s.L < 4) {   // last chunk: M-tile pair 0 of THIS layer is final after its own step
-                if constexpr (s.mp == 1) epart(IC<s.L>{}, IC<0>{}, IC<0>{});
-                if constexpr (s.mp == 2) epart(IC<s.L>{}, IC<0>{}, IC<1>{});
-                if constexpr (s.mp == 3) {
-                    epart(IC<s.L>{}, IC<0>{}, IC<2>{});
-                    epart(IC<s.L>{}, IC<0>{}, IC<3>{});
-                }
-            }
+            static_for<0, NP>([&](auto ic) { epart(IC<EL>{}, IC<EQ>{}, IC<P0 + decltype(ic)::value>{}, pre[decltype(ic)::value]); });
             if constexpr (s.mp == MP - 1 && !(s.L == 4 && s.kc == 3)) {   // chunk done: the fragments produced meanwhile are next
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -359,7 +394,14 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
             if constexpr (G == 47) clk.mark(4);
         });
         clk.mark(5);
-        // ---- (4) per point: weights, row g of T = sum_j w_j A_j, residual, Broyden bookkeeping (as k_canon_solve)
+        // ---- (4) per point: hierarchical softmax, T = sum_j w_j A_j, residual; then the Broyden bookkeeping of k_canon_solve
+        // (a) per N-tile: the four lanes of a point share the 25 gates through its logits row; T on the matrix pipe:
+        //     D[entry][point] += bones[joint][entry] w[joint][point] in six fp32 steps of four joints (an fmaf chain in joint
+        //     order, like the loop it replaces) -- lane (j, g) supplies bones[4 s + g][entry j] and w[4 s + g] of its point
+        //     and receives entries 4 g .. 4 g + 3 = row g of T
+        f32x4 Trow[NT];
+        float gn[NT];
+        const unsigned long long kOddG = 0xffff0000ffff0000ull, kHighG = 0xffffffff00000000ull;   // lanes with g & 1, g & 2
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             float* row = rows + j * kCwRowLd;
@@ -374,50 +416,71 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            f32x4 Trow = {0.f, 0.f, 0.f, 0.f};
+            f32x4 tr = {0.f, 0.f, 0.f, 0.f};
             {
                 float w[24];
                 hsoftmax_quad(row, g, w);
 #pragma unroll
-                for (int jn = 0; jn < 24; ++jn) {
-                    if ((jn & 3) == 0) __builtin_amdgcn_sched_barrier(0);   // four bone rows in flight, not all 24 (VGPRs)
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(sbones + jn * 16 + g * 4);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) Trow[c] = fmaf(w[jn], b[c], Trow[c]);
+                for (int s6 = 0; s6 < 6; ++s6) {
+                    const float a = sbones[(4 * s6 + g) * 16 + j];
+                    // w[4 s + g] by three selects on constant lane masks (written out: left to itself the compiler turns
+                    // the selection into a lane-indexed load from a scratch copy of w)
+                    float wl, wh, wb;
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(wl) : "v"(w[4 * s6]), "v"(w[4 * s6 + 1]), "s"(kOddG));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(wh) : "v"(w[4 * s6 + 2]), "v"(w[4 * s6 + 3]), "s"(kOddG));
+                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(wb) : "v"(wl), "v"(wh), "s"(kHighG));
+                    tr = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb, tr, 0, 0, 0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
-            float* s_ = st[t];
-            int* si_ = sti[t];
-            const int idc = id[t];
-            const int nev = si_[ST_NEV];
-            const float x0 = s_[ST_X], x1 = s_[ST_X + 1], x2 = s_[ST_X + 2];
-            const float xbar_g = fmaf(Trow[0], x0, fmaf(Trow[1], x1, fmaf(Trow[2], x2, Trow[3])));
-            const float gn_g = xbar_g - s_[ST_TG + min(g, 2)];
-            float gnew[3];
+            Trow[t] = tr;
+            const float* s_ = st[t];
+            gn[t] = fmaf(tr[0], s_[ST_X], fmaf(tr[1], s_[ST_X + 1], fmaf(tr[2], s_[ST_X + 2], tr[3]))) - s_[ST_TG + min(g, 2)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        // (b) both N-tiles at once: point (t, j) hands {rows 0..2 of T | residual} to lane (j, g = t) through the logits
+        //     rows (free by now), which does the point's Broyden step -- one pass over this code for kCwNT * 16 points
+        static_assert(NT <= 4 && NT * 16 * 16 <= 16 * kCwRowLd, "exchange area");
 #pragma unroll
-            for (int r = 0; r < 3; ++r) gnew[r] = __shfl(gn_g, j + 16 * r);
-            const bool first = nev == 0;
-            float J[9];
-            if (__any(idc >= 0 && first)) {   // wave-uniform: J^-1_0 = (T[:3,:3])^-1 from the same weights (RFU:327-328)
-                float T9[16];
-#pragma unroll
-                for (int r = 0; r < 3; ++r)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) T9[r * 4 + c] = __shfl(Trow[c], j + 16 * r);
-                inv3_of44(T9, J);
+        for (int t = 0; t < NT; ++t) {
+            float* xp = rows + (t * 16 + j) * 16;
+            if (g < 3) {
+                *reinterpret_cast<f32x4*>(xp + 4 * g) = Trow[t];
+                xp[12 + g] = gn[t];
             }
-            int flags = 0;   // bit 0: keep, bit 1: improved
-            if (g == 0 && idc >= 0) {
-                float gx[3], stp[3], eb;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        int flags = 0;   // bit 0: keep, bit 1: improved
+        {
+            int idc = id[0];
+#pragma unroll
+            for (int t = 1; t < NT; ++t) idc = g == t ? id[t] : idc;
+            if (g < NT && idc >= 0) {
+                float* s_ = state + (g * 16 + j) * ST_SIZE;
+                int* si_ = reinterpret_cast<int*>(s_);
+                const float* xp = rows + (g * 16 + j) * 16;
+                const f32x4 r0 = *reinterpret_cast<const f32x4*>(xp), r1 = *reinterpret_cast<const f32x4*>(xp + 4),
+                            r2 = *reinterpret_cast<const f32x4*>(xp + 8), gnew = *reinterpret_cast<const f32x4*>(xp + 12);
+                const int nev = si_[ST_NEV];
+                const float x0 = s_[ST_X], x1 = s_[ST_X + 1], x2 = s_[ST_X + 2];
+                const bool first = nev == 0;
+                float gx[3], stp[3], eb, J[9];
                 bool keep, improved = false;
-                if (first) {
+                if (first) {   // J^-1_0 = (T[:3,:3])^-1 from the same weights (RFU:327-328)
+                    const float T9[16] = {r0[0], r0[1], r0[2], 0.f, r1[0], r1[1], r1[2], 0.f, r2[0], r2[1], r2[2], 0.f, 0.f, 0.f, 0.f, 1.f};
+                    inv3_of44(T9, J);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
                     eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
                     keep = true;                                        // every point takes at least one step
 #pragma unroll
                     for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
+                    // a FIRST residual (at the nearest-vertex start) that is not finite: an activation left the f16 range
+                    // (later ones also come from iterates that genuinely diverge; either way the point retires below)
+                    if (!(fabsf(gx[0] + gx[1] + gx[2]) < 3.0e38f)) ++n_bad;
                 } else {
                     float dg[3], dxv[3];
                     eb = s_[ST_EB];
@@ -443,13 +506,10 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
                         broyden_update<3>(J, dxv, dg, gx, stp);          // broyden.py:69-75
                     }
                 }
-                // a FIRST residual (at the nearest-vertex start) that is not finite: an activation left the f16 range
-                // (later ones also come from iterates that genuinely diverge; either way the point retires below)
-                if (first && !(fabsf(gx[0] + gx[1] + gx[2]) < 3.0e38f)) ++n_bad;
                 if (nev + 1 > kBroydenSteps) keep = false;              // 1 + 50 evaluations (broyden.py:44)
-                si_[ST_NEV] = nev + 1;
-                s_[ST_EB] = eb;
                 if (keep) {
+                    si_[ST_NEV] = nev + 1;
+                    s_[ST_EB] = eb;
                     s_[ST_X] = x0 + stp[0];
                     s_[ST_X + 1] = x1 + stp[1];
                     s_[ST_X + 2] = x2 + stp[2];
@@ -460,25 +520,26 @@ __global__ __launch_bounds__(kCwThreads, 2) void k_canon_wave(FrameDev fr, const
                     }
 #pragma unroll
                     for (int e = 0; e < 9; ++e) s_[ST_J + e] = J[e];
+                } else {   // retire: the best iterate is the result (broyden.py:78); its T row follows below
+                    const float xb0 = improved ? x0 : s_[ST_XB], xb1 = improved ? x1 : s_[ST_XB + 1], xb2 = improved ? x2 : s_[ST_XB + 2];
+                    outp.pts[(size_t)idc * 3] = xb0;
+                    outp.pts[(size_t)idc * 3 + 1] = xb1;
+                    outp.pts[(size_t)idc * 3 + 2] = xb2;
+                    outp.err[idc] = eb;
+                    si_[ST_ID] = -1;
                 }
                 flags = (keep ? 1 : 0) | (improved ? 2 : 0);
             }
-            flags = __shfl(flags, j);
-            if (flags & 2) tbr[t] = Trow;
-            if (idc >= 0 && !(flags & 1)) {   // retire: the best iterate is the result (broyden.py:78)
-                reinterpret_cast<f32x4*>(outp.T + (size_t)idc * 16)[g] = tbr[t];
-                if (g == 0) {
-                    outp.pts[(size_t)idc * 3] = s_[ST_XB];
-                    outp.pts[(size_t)idc * 3 + 1] = s_[ST_XB + 1];
-                    outp.pts[(size_t)idc * 3 + 2] = s_[ST_XB + 2];
-                    outp.err[idc] = s_[ST_EB];
-                    si_[ST_ID] = -1;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int f = __shfl(flags, j + 16 * t);
+            if (f & 2) tbr[t] = Trow[t];
+            if (id[t] >= 0 && !(f & 1)) reinterpret_cast<f32x4*>(outp.T + (size_t)id[t] * 16)[g] = tbr[t];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         clk.mark(6);
     }
 #pragma unroll
