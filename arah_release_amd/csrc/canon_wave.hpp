@@ -25,7 +25,8 @@
 #ifndef CW_NT
 #define CW_NT 2
 #endif
-constexpr int kCwNT = CW_NT;                        // N-tiles (16 points each) per wave
+constexpr int kCwNT = CW_NT;                    // N-tiles (16 points each) per wave
+static_assert(kCwNT == 2, "the only validated geometry (one N-tile per wave gave wrong roots on the MI355X and was slower)");
 #ifndef CW_WAVES
 #define CW_WAVES 8
 #endif
@@ -69,7 +70,10 @@ __host__ __device__ constexpr CwParts cw_parts(int NT, int L, int kc, int mp) {
 #define CW_LO_DIST 2    // MFMA steps the lo fragments (L2) are requested ahead of their use
 #endif
 #ifndef CW_HI_DIST
-#define CW_HI_DIST 1    // the same for the hi fragments (LDS)
+#define CW_HI_DIST 0    // the same for the hi fragments (LDS): requested ahead they cost more in registers than they hide
+#endif
+#ifndef CW_PIN_MASK
+#define CW_PIN_MASK 0x040f
 #endif
 constexpr int kCwLoDist = CW_LO_DIST, kCwHiDist = CW_HI_DIST;
 
@@ -155,19 +159,48 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
         return ld_w(L, f, 0);
     };
 
-    // the prefetched start state of every slot (all four lanes of a point hold its id; lane g holds row g of T0, with
-    // the target riding in row 3; lanes g < 3 hold coordinate g of x0)
-    int nid[NT];
-    f32x4 nT[NT];
-    float nx[NT];
+    // The NEXT start state of every slot, claimed from the launch-wide queue when the slot last refilled, travels in three
+    // stages so that no pass ever waits for HBM: claimed at the top of pass p (cl), requested at the start of pass p's tail
+    // -- behind the MLP's fragment loads, with the tail and the next refill to land in -- into (fid, fT, fx), handed over
+    // to (nid, nT, nx) at the start of pass p + 1's tail, taken at the top of pass p + 2 at the earliest: a point needs at
+    // least two evaluations (broyden.py:44-64), so a slot refilled in pass p is not empty again before the end of pass
+    // p + 1.  The hand-over is where the wave waits for the request (an asm "use" pins the s_waitcnt there: by then it is
+    // a pass old); left to the compiler the wait sits at the take, right behind the retire stores and the youngest
+    // requests, and every pass pays a memory round trip.  All four lanes of a point hold its id; lane g holds row g of
+    // T0, with the target riding in row 3; lanes g < 3 hold coordinate g of x0.
+    int nid[NT], fid[NT];
+    f32x4 nT[NT], fT[NT];
+    float nx[NT], fx[NT];
     f32x4 tbr[NT];   // row g of the best transform so far
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        nid[t] = -1;
-        nT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        nx[t] = 0.f;
+        nid[t] = fid[t] = -1;
+        nT[t] = fT[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        nx[t] = fx[t] = 0.f;
         tbr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    auto request = [&](const int (&cl)[NT]) {   // the start state sits where the result will go (pts, T with the target in row 3)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (cl[t] >= 0) {
+                fid[t] = cl[t];
+                fT[t] = reinterpret_cast<const f32x4*>(outp.T + (size_t)cl[t] * 16)[g];
+                fx[t] = outp.pts[(size_t)cl[t] * 3 + min(g, 2)];
+            }
+        }
+    };
+    auto hand_over = [&]() {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            asm volatile("" : "+v"(fT[t][0]), "+v"(fT[t][1]), "+v"(fT[t][2]), "+v"(fT[t][3]), "+v"(fx[t]));
+            if (fid[t] >= 0) {
+                nid[t] = fid[t];
+                nT[t] = fT[t];
+                nx[t] = fx[t];
+                fid[t] = -1;
+            }
+        }
+    };
     int cid = -1;                    // this wave's piece of the queue: lane l holds list[q_base + l]
     int q_base = 0, q_pos = 0, q_end = 0;
     bool exhausted = n <= 0;
@@ -182,15 +215,16 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             n_bad += 1 << 20;
             break;
         }
-        // ---- (1) empty slots take their prefetched start state; then every empty slot claims the seed after that
-        int id[NT];
-        bool was_empty[NT];
+        // ---- (1) empty slots take their next start state; a slot left without one claims a seed
+        int id[NT], cl[NT];
+        bool want[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             id[t] = sti[t][ST_ID];
-            was_empty[t] = id[t] < 0;
-            if (was_empty[t] && nid[t] >= 0) {
+            cl[t] = -1;
+            if (id[t] < 0 && nid[t] >= 0) {
                 id[t] = nid[t];
+                nid[t] = -1;
                 f32x4 t0 = nT[t];
                 if (g == 3) {
                     st[t][ST_TG] = t0[0];
@@ -206,6 +240,9 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                     sti[t][ST_ID] = id[t];
                     sti[t][ST_NEV] = 0;
                 }
+                want[t] = true;
+            } else {
+                want[t] = id[t] < 0 && nid[t] < 0 && fid[t] < 0;   // empty, nothing ready, nothing on its way
             }
         }
         {
@@ -213,10 +250,9 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             int rank[NT], need = 0;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                m[t] = __ballot(was_empty[t]) & 0xffffull;   // lanes 0..15 speak for their slots
+                m[t] = __ballot(want[t]) & 0xffffull;   // lanes 0..15 speak for their slots
                 rank[t] = need + __popcll(m[t] & below);
                 need += __popcll(m[t]);
-                if (was_empty[t]) nid[t] = -1;
             }
             int given = 0;
             while (need > 0 && !exhausted) {   // wave-uniform
@@ -231,24 +267,18 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                     q_base = q_pos = p;
                     q_end = min(p + kCwSeedChunk, n);
                     cid = p + lane < n ? list[p + lane] : -1;
+                    asm volatile("" : "+v"(cid));   // wait for the ids HERE (once per 64 seeds), not at every shuffle below
                 }
                 const int take = min(q_end - q_pos, need);
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     const int src = q_pos - q_base + (rank[t] - given);   // lane of cid that holds this slot's seed
                     const int got = __shfl(cid, src & 63);
-                    if (was_empty[t] && rank[t] >= given && rank[t] < given + take) nid[t] = got;
+                    if (want[t] && rank[t] >= given && rank[t] < given + take) cl[t] = got;
                 }
                 q_pos += take;
                 given += take;
                 need -= take;
-            }
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {   // the start state sits where the result will go (pts, T with the target in row 3)
-                if (was_empty[t] && nid[t] >= 0) {
-                    nT[t] = reinterpret_cast<const f32x4*>(outp.T + (size_t)nid[t] * 16)[g];
-                    nx[t] = outp.pts[(size_t)nid[t] * 3 + min(g, 2)];
-                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -261,12 +291,14 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             live_any |= live;
             n_eval += __popcll(live);
         }
-        if (live_any == 0ull) {
+        if (live_any == 0ull) {   // start of the launch, or a wave whose slots all ran dry at once: fetch and wait
+            request(cl);
+            hand_over();
             bool pending = false;
 #pragma unroll
             for (int t = 0; t < NT; ++t) pending |= __any(nid[t] >= 0) != 0;
-            if (!pending) break;     // nothing in the slots, nothing prefetched: the queue is dry
-            continue;                // (only when a prefetched seed arrived for an empty wave: take it next pass)
+            if (!pending) break;     // nothing in the slots, nothing on its way: the queue is dry
+            continue;
         }
         // ---- (2) normalised coordinates of the lane's points (the four lanes of a point compute the same values)
         f32x4 xr[NT];
@@ -362,6 +394,12 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             constexpr int P0 = parts.first, NP = parts.count;
             EpiPre pre[NP > 0 ? NP : 1];
             static_for<0, NP>([&](auto ic) { pre[decltype(ic)::value] = epre(IC<EL>{}, IC<EQ>{}, IC<P0 + decltype(ic)::value>{}); });
+#ifndef CW_NO_PIN
+            // the requests above stay above: ALU work may cross (mask: ALU | VALU | SALU | MFMA | transcendental), memory
+            // operations may not -- under register pressure the scheduler otherwise sinks every request to just ahead of
+            // its first use and the wave sits out the L2 / LDS latency fifty times per pass
+            __builtin_amdgcn_sched_barrier(CW_PIN_MASK);
+#endif
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -399,6 +437,8 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
         //     D[entry][point] += bones[joint][entry] w[joint][point] in six fp32 steps of four joints (an fmaf chain in joint
         //     order, like the loop it replaces) -- lane (j, g) supplies bones[4 s + g][entry j] and w[4 s + g] of its point
         //     and receives entries 4 g .. 4 g + 3 = row g of T
+        hand_over();     // last pass's requests have landed long ago
+        request(cl);     // this pass's claims: a whole pass to land in
         f32x4 Trow[NT];
         float gn[NT];
         const unsigned long long kOddG = 0xffff0000ffff0000ull, kHighG = 0xffffffff00000000ull;   // lanes with g & 1, g & 2

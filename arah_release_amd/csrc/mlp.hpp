@@ -172,6 +172,19 @@ __device__ __forceinline__ f32x4 gemm_one(const float* __restrict__ wp, int mt, 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
+// LDS placement of a split activation plane: a point's row is a sequence of 64-byte chunks (32 channels as halves), four
+// 16-byte slots each -- slot g of chunk kc is what lane group g of the B fragment reads.  Rows are 8 dwords (mod 64) apart
+// (kSdfLd = 264, kSkinLd = 136 floats) and the slots of a chunk are permuted by the point index, slot' = slot ^ ((pt >> 2) & 3):
+// the sixteen lanes that one LDS cycle of a ds_read_b128 serves (lane groups of the form {j 0..3, 12..15 | g; j 4..11 | g + 1})
+// then fall on sixteen different 16-byte bank groups.  With 260-float rows and no permutation every B-fragment read took
+// two passes (tools/lds_layout.py counts them; rocprofv3 SQ_LDS_BANK_CONFLICT was 60 % of the LDS-active cycles of
+// k_density).  The epilogue's 8-byte stores stay 2-way, which the store path hides.
+__device__ __forceinline__ int split_slot(int pt, int slot) { return slot ^ ((pt >> 2) & 3); }
+// byte offset inside a plane of channel ch of point pt
+__device__ __forceinline__ int split_byte(int pt, int ch) {
+    return (ch >> 5) * 64 + split_slot(pt, (ch >> 3) & 3) * 16 + (ch & 7) * 2;
+}
+
 // acc[m][n] += Wsplit(M-tiles mt0..mt0+MT-1, KC32 32-chunks) * act(16 NT points)
 //   weights : wp[((mt*KC32 + kc)*2 + s)*64 + lane]  (s = 0 hi, 1 lo), lane (j, g) holds W[mt*16 + j][kc*32 + 8g .. +7]
 //   act     : LDS rows of ld floats; hi plane at byte 0, lo plane at byte lo_off; lane reads k = kc*32 + 8g .. +7
@@ -182,7 +195,7 @@ template <int KC32, int MT, int NT, bool DEEP = false>
 __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int mt0, const float* act, int ld,
                                                int lo_off, f32x4 (&acc)[MT][NT], int lane) {
     const int j = lane & 15, g = lane >> 4;
-    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + g * 16;
+    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
     const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
     auto lda = [&](int idx) { return ld_frag<f16x8>(wp, aoff, idx * 1024); };
     if constexpr (DEEP || KC32 <= 4) {
@@ -297,9 +310,9 @@ __device__ __forceinline__ void store_split4(float* act, int ld, int lo_off, int
         hi[p] = __builtin_bit_cast(unsigned, h2);
         lo[p] = split_residual2(hs[2 * p], hs[2 * p + 1], hi[p]);
     }
-    char* row = reinterpret_cast<char*>(act) + pt * ld * 4;
-    *reinterpret_cast<u32x2*>(row + ch0 * 2) = hi;
-    *reinterpret_cast<u32x2*>(row + lo_off + ch0 * 2) = lo;
+    char* row = reinterpret_cast<char*>(act) + pt * ld * 4 + split_byte(pt, ch0);
+    *reinterpret_cast<u32x2*>(row) = hi;
+    *reinterpret_cast<u32x2*>(row + lo_off) = lo;
 }
 
 // 8 fp32 values -> the hi and lo B fragments of a 16x16x32 step, in registers (same arithmetic as store_split4)
@@ -329,9 +342,8 @@ __device__ __forceinline__ void split4(const float (&v)[4], unsigned& h0, unsign
 }
 
 __device__ __forceinline__ float load_split(const float* act, int ld, int lo_off, int pt, int ch) {
-    const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4;
-    return ((float)*reinterpret_cast<const _Float16*>(row + ch * 2) +
-            (float)*reinterpret_cast<const _Float16*>(row + lo_off + ch * 2)) * kInvActScale;
+    const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4 + split_byte(pt, ch);
+    return ((float)*reinterpret_cast<const _Float16*>(row) + (float)*reinterpret_cast<const _Float16*>(row + lo_off)) * kInvActScale;
 }
 
 // One 16x16 output tile (M-tile mt, N-tile nt) on the split engine: narrow output layers split over waves.
@@ -357,7 +369,7 @@ template <int KC32>
 __device__ __forceinline__ f32x4 gemm_one_split(const SplitA<KC32>& a, int nt, const float* act, int ld, int lo_off,
                                                 int lane) {
     const int j = lane & 15, g = lane >> 4;
-    const char* bptr = reinterpret_cast<const char*>(act) + (nt * 16 + j) * ld * 4 + g * 16;
+    const char* bptr = reinterpret_cast<const char*>(act) + (nt * 16 + j) * ld * 4 + split_slot(j, g) * 16;
     f16x8 bh[KC32], bl[KC32];
 #pragma unroll
     for (int kc = 0; kc < KC32; ++kc) {
@@ -392,7 +404,7 @@ struct SdfNet {
     const f16x8* wps[5];   // split-packed 256x256
 };
 
-constexpr int kSdfLd = 260;   // 256 + 4
+constexpr int kSdfLd = 264;   // 256 + 8: rows 8 dwords apart mod 64 (see split_slot)
 constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
 
 // FiLM-SIREN argument z = 30 (f (v + b) + phi) = kFilmTurn (fw v + pw): the folded constants fw, pw (k_fold_film) carry z
@@ -691,7 +703,7 @@ struct SkinNet {
                           // [4..7] 1 / (weight scale of layer k+1 * S_k): turns the split accumulator into W h
 };
 
-constexpr int kSkinLd = 132;
+constexpr int kSkinLd = 136;   // 128 + 8
 constexpr int kLogitLd = 33;
 
 // Operands of the POINT-OWNING-wave kernels (csrc/canon_wave.hpp): a wave owns its points AND all 128 channels, a
@@ -857,7 +869,7 @@ struct ColDims {
     static constexpr int kIn = 256 + kExtra;
     static constexpr int kKC0 = (kIn + 15) / 16;       // 19 / 17
     static constexpr int kInPad = kKC0 * 16;           // 304 / 272
-    static constexpr int kLdA = kInPad + 4;
+    static constexpr int kLdA = kInPad + 8;            // 8 dwords mod 64 apart (see split_slot)
 };
 
 template <int MT>
