@@ -2023,17 +2023,21 @@ __device__ __forceinline__ float volsdf_density(float sdf, float inv_beta) {
 // values: only samples with density > 0 go on to pass 2 (k_shade).  The composited image is
 // bit-identical to shading everything (tests/test_hip_parity.py::test_lazy_shading_is_exact).
 // ------------------------------------------------------------------------------------------
-template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
+// NT = 8 (the split engine on long lists): tiles of 128 points, one workgroup per CU.  The weight fragments of a layer
+// (256 KB as hi + lo halves) are then fetched from L2 once per 128 points instead of once per 64: at 64 points the
+// fragment stream of this kernel is 146 GB per 512x512x64 frame, two thirds of what the L2 delivers, and the matrix pipe
+// waits for it half of the time (rocprofv3 SQ counters, profiles/).
+template <bool SPLIT, int NT = kNT>
+__global__ __launch_bounds__(kThreads, NT > 4 ? 2 : 4) void k_density(FrameDev fr, const float* pts, const int* list, const int* count,
                                                        f32x4* shaded, int* next_list, int* next_count,
                                                        unsigned long long* ctr_fwd, unsigned long long* ctr_dens) {
     const BodyConst bc = load_bc(fr);
-    constexpr int TW = kTile;
+    constexpr int TW = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                                   // [TW][4]
     float* outv = xin + TW * 4;                          // [TW][4]
     int* ids = reinterpret_cast<int*>(outv + TW * 4);    // [TW]
-    float* actA = reinterpret_cast<float*>(ids + TW);    // [64][260]
+    float* actA = reinterpret_cast<float*>(ids + TW);    // [TW][kSdfLd]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = *count;
     const float scale = sdf_scale(bc);
@@ -2048,9 +2052,9 @@ __global__ __launch_bounds__(kThreads, 4) void k_density(FrameDev fr, const floa
             reinterpret_cast<f32x4*>(xin)[tid] = x;
         }
         __syncthreads();
-        f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<false, kNT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
-        sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid);
+        f32x4 dlast[kSdfMT][NT];
+        sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid, TW);
         __syncthreads();
         if (tid == 0) {
             count_add(ctr_fwd, min(TW, n - tile * TW));
@@ -2431,6 +2435,7 @@ inline int num_cus() {
 // dynamic LDS sizes (bytes)
 constexpr size_t kLdsSdfFwd = (64 * 4 * 2 + 64) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsSdfGrad = kLdsSdfFwd + (size_t)64 * kSdfLd * 4;
+constexpr size_t kLdsDensityWide = (128 * 4 * 2 + 128) * 4 + (size_t)128 * kSdfLd * 4;
 constexpr size_t kLdsSkin = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSkinLd * 4;
 constexpr size_t kLdsJoint = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsKnn = ((size_t)kMaxClusters * kClusterLds * 4 + kMaxClusters * 4 + 24 * 16) * 4;
@@ -2490,6 +2495,7 @@ int setup_attributes() {
     allow_lds(k_sdf_march<true>, kLdsSplitSolo);
     allow_lds(k_density<false>, kLdsSdfFwd);
     allow_lds(k_density<true>, kLdsSplitSolo);
+    allow_lds(k_density<true, 8>, kLdsDensityWide);
     allow_lds(k_skin_eval, kLdsSkin);
     allow_lds(k_skin_jac, kLdsSkin);
     allow_lds(k_canon_solve<false>, kLdsCanonSolve);
@@ -3232,9 +3238,16 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     const int* scount = &w.counts[0];
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
         if (g_density_ev0) hipEventRecord(g_density_ev0, s);
-        LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
-                      (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd,
-                      &w.ctr->n_density);
+        // long lists on the split engine: 128-point tiles, one workgroup per CU (ARAH_DENSITY_TILE=64 keeps the 64-point kernel)
+        static const bool wide = env_int("ARAH_DENSITY_TILE", 128) == 128;
+        if (fd.split && wide && Q >= 128ll * 1024)
+            hipLaunchKernelGGL((k_density<true, 8>), dim3(min(num_cus(), grid_for(Q, 128))), dim3(kThreads), kLdsDensityWide, s, fd,
+                               pts, (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1],
+                               &w.ctr->n_sdf_fwd, &w.ctr->n_density);
+        else
+            LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
+                          (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd,
+                          &w.ctr->n_density);
         if (g_density_ev1) hipEventRecord(g_density_ev1, s);
         slist = w.listB;
         scount = &w.counts[1];
