@@ -2652,7 +2652,7 @@ ColSegs one_seg(int len) {
 // =============================================================================================
 extern "C" {
 
-const char* arah_dominant_kernel(void) { return "k_canon_solve"; }   // largest single launch of the default path (loop C)
+const char* arah_dominant_kernel(void) { return "k_canon_wave"; }   // largest single launch of the default path (loop C)
 
 int arah_set_shade_events(void* start_event, void* stop_event) {
     g_shade_ev0 = reinterpret_cast<hipEvent_t>(start_event);

@@ -400,9 +400,13 @@ def _walk_tensors(obj):
             yield from _walk_tensors(v)
 
 
-def render_sequence(model, frames, n_streams=3, **forward_kwargs):
-    """Render independent frames (a test sequence, reference test.py / lightning_model.py:320) with `n_streams` of them
-    in flight: frame k runs on HIP stream k mod n_streams with its own scratch, so that the latency-bound stretches of one
+def render_sequence(model, frames, n_streams=1, **forward_kwargs):
+    """Render independent frames (a test sequence, reference test.py / lightning_model.py:320).  DEFAULT: one frame at a time
+    on the caller's stream.  n_streams > 1 is OPT-IN: the HIP runtime has stopped accepting launches once in about twenty
+    multi-stream bench.py passes on the MI355X box (host blocked inside hipLaunchKernel, nothing wrong on the device; DESIGN.md
+    section 4) and a product API must not deadlock -- until that is understood the pipelined form is for measurements only.
+    With `n_streams` frames
+    in flight, frame k runs on HIP stream k mod n_streams with its own scratch, so that the latency-bound stretches of one
     frame (the tails of sphere tracing and of the joint root find: a few hundred live rays, ~60 us of kernel latency per
     step) run under the other frames' wide kernels.  Per-frame results are bit-identical to one-at-a-time rendering
     (tests/test_zz_render_sequence.py); 56 -> 49 ms per 512x512 frame on one

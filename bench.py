@@ -11,7 +11,7 @@ i -> rank i mod N): no data-path collective, weak scaling, value = al
 / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline      largest single launch of the default path: k_canon_solve, loop C (every Broyden iteration of every
+  roofline      largest single launch of the default path: k_canon_wave, loop C (every Broyden iteration of every
                 valid sample in one resident kernel).  Algorithmic MFMA flops = skinning-MLP evaluations x 105 472
                 / HIP-event duration of the launch.  Peak: the default GEMM engine carries each fp32 operand as two
                 f16 and spends three v_mfma_f32_16x16x32_f16 per product, so its ceiling in algorithmic fp32 flops is
@@ -68,12 +68,14 @@ def aggregate(local_rays, local_seconds, dist=None):
     return float(r.item()), float(t.item())
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, full_shading=False):
     """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC summary (profiles/rNN_pmc_traffic.json,
-    made by tools/rocpd_pmc.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command); None if absent.
+    made by tools/rocpd_pmc.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command; ..._pmc_traffic_full.json
+    for the passes run with ARAH_FULL_SHADING=1); None if absent.
     PMC counters cannot be read from inside the process, so this is the one figure that is not measured live."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_full.json" if full_shading else "r*_pmc_traffic.json")))
+    files = [f for f in files if full_shading or not f.endswith("_full.json")]
     if not files:
         return None, None
     try:
@@ -421,9 +423,10 @@ def run(args, rt):
         flops_per_sample = F_SDF + F_SDF_GRAD + F_COL[mode]
         total_flops = path_flops(counters)
         tf = {True: "true", False: "false"}
-        dens_traffic, traffic_src = pmc_traffic("k_density<%s>" % tf[split])
-        canon_traffic, canon_src = pmc_traffic("k_canon_solve<%s>" % tf[split])
-        shade_traffic, _ = pmc_traffic("k_shade<%s, %s>" % (tf[mode == "idr"], tf[split]))
+        canon_kernel = "k_canon_wave" if split and os.environ.get("ARAH_CANON_KERNEL", "wave") != "tile" else "k_canon_solve"
+        dens_traffic, traffic_src = pmc_traffic("k_density<%s" % tf[split])
+        canon_traffic, canon_src = pmc_traffic(canon_kernel + "<")
+        shade_traffic, shade_src = pmc_traffic("k_shade<%s, %s>" % (tf[mode == "idr"], tf[split]), full_shading=True)
         peak_fwd = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         # k_shade: forward trunk on the default engine, reverse sweep and colour MLP on the exact engine
         peak_shade = mixed_peak([(F_SDF, peak_fwd), (F_SDF_GRAD + F_COL[mode], PEAK_F32_MFMA_TFLOPS)])
@@ -443,14 +446,17 @@ def run(args, rt):
                        "config": args.config, "rays_per_frame": n_rays_local / max(args.steps, 1),
                        "pixels_per_frame": args.size * args.size, "parallelism": "frame-parallel x%d" % world,
                        "frames_in_flight_per_gpu": args.streams},
-            "roofline": {"bound": "mfma", "kernel": "k_canon_solve", "achieved": canon_achieved, "peak": peak_fwd,
+            "roofline": {"bound": "mfma", "kernel": canon_kernel, "achieved": canon_achieved, "peak": peak_fwd,
                          "unit": "TFLOP/s", "frac": canon_achieved / peak_fwd, "traffic": canon_traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": canon_src, "traffic_live": False,
                          "avg_launch_ms": canon_avg_ms, "evaluations_per_launch": canon_evals,
                          "flops_per_evaluation": F_SKIN,
                          "peak_note": ("algorithmic fp32 MFMA flops of the skinning MLP against dense f16 MFMA peak / 3 (three "
-                                       "f16 MFMAs per fp32 product); the kernel's Softplus epilogues, softmax tree, LBS blend "
-                                       "and Broyden update are vector-ALU work on top (DESIGN.md section 7)" if split else
+                                       "f16 MFMAs per fp32 product) at the 2.4 GHz peak clock; under this kernel the chip runs "
+                                       "at 1.75-1.9 GHz (power), where the f16 16x16x32 MFMA microbenchmark ceiling is 1955 "
+                                       "TFLOP/s = 652 algorithmic (MI355X_MICROARCH.md); the kernel's Softplus epilogues, softmax "
+                                       "tree and Broyden update keep the vector ALU 76 % busy (rocprofv3 SQ counters, "
+                                       "profiles/): it is vector-ALU bound (DESIGN.md section 4)" if split else
                                        "dense fp32 MFMA peak")},
             "roofline_k_density": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
                                    "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
@@ -483,6 +489,7 @@ def run(args, rt):
                                     "roofline": {"bound": "mfma", "kernel": "k_shade", "achieved": achieved_full,
                                                  "peak": peak_shade, "unit": "TFLOP/s",
                                                  "frac": achieved_full / peak_shade, "traffic": shade_traffic,
+                                                 "traffic_source": shade_src, "traffic_live": False,
                                                  "peak_note": "time-weighted over the kernel's GEMM classes and their engines",
                                                  "avg_launch_ms": avg_ms, "samples_per_launch": samples_per_launch,
                                                  "flops_per_sample": flops_per_sample}}
@@ -502,6 +509,9 @@ def run(args, rt):
                                            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                            "frac": ach / PEAK_F32_MFMA_TFLOPS,
                                            "avg_launch_ms": sum(strict_ms) / n_l}}
+        # the reference shades every valid sample in fp32: the two reference-equivalent figures next to the headline
+        line["value_full_shading"] = line["full_shading"]["value"] if "full_shading" in line else None
+        line["value_strict"] = line["strict"]["value"] if "strict" in line else None
         if world == 1 and not args.no_train:
             line["training"] = rt.training_line()
         if world == 1 and not args.no_cpu_baseline:
