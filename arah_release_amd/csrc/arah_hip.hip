@@ -1876,6 +1876,8 @@ __global__ void k_trace_finalize(FrameDev fr, int n, const float* near_far, cons
     end[i] = fa;
 }
 
+#include "finish.hpp"
+
 // stratified jitter of an ascending run v[0..m) (perturb_z_vals, RT:298-311): sample i moves inside
 // [mid(i-1,i), mid(i,i+1)] by t in [0,1); `val(i)` evaluates the un-jittered run
 template <typename F>
@@ -2506,6 +2508,10 @@ int setup_attributes() {
     allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<false, false>, kLdsJoint);
     allow_lds(k_joint_iter<false, true>, kLdsSplitSolo);
+    allow_lds(k_trace_finish<true>, kLdsTraceFinish);
+    allow_lds(k_trace_finish<false>, kLdsTraceFinish);
+    allow_lds(k_joint_finish<true>, kLdsJointFinish);
+    allow_lds(k_joint_finish<false>, kLdsJointFinish);
     allow_lds(k_shade<false, false>, lds_shade<false>());
     allow_lds(k_shade<false, true>, lds_shade<false>());
     allow_lds(k_shade<true, false>, lds_shade<true>());
@@ -3091,7 +3097,10 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
     hipLaunchKernelGGL(k_joint_init, dim3(grid_for(n, 256)), dim3(256), 0, s, fd, st, rs, (const int*)w.listA,
                        (const int*)&cntB[0], (const float*)w.grad_sdf, (const float*)w.jac_lbs, (const float*)w.xcur,
                        (const float*)w.t, w.x0raw);
-    for (int it = 0; it <= kBroydenSteps; ++it) {
+    // the first iterations as one launch each over the compacted list; then the finisher adopts what is left
+    // (ARAH_JOINT_BULK_ITERS >= 51: every iteration as its own launch, round 2's schedule)
+    static const int bulk = max(1, min(kBroydenSteps + 1, env_int("ARAH_JOINT_BULK_ITERS", 3)));
+    for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
         if (it == 0)
@@ -3102,6 +3111,12 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
             LAUNCH_ENGINE(fd.split, (k_joint_iter<false, true>), (k_joint_iter<false, false>), dim3(gm), dim3(kThreads),
                           kLdsJoint, s, fd, st, rs, (const int*)lin, (const int*)&cntB[it], lout, &cntB[it + 1],
                           &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+    }
+    if (bulk <= kBroydenSteps) {
+        const int* lin = (bulk & 1) ? w.listB : w.listA;
+        const int gf = min(4 * num_cus(), max(1, (n + kFinTile - 1) / kFinTile));
+        LAUNCH_ENGINE(fd.split, k_joint_finish<true>, k_joint_finish<false>, dim3(gf), dim3(kThreads), kLdsJointFinish, s, fd,
+                      st, rs, lin, (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk, &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
     }
 }
 
@@ -3120,13 +3135,23 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
                        w.listA, &cntA[0]);
     TraceState ts{w.t, w.far, w.xcur, w.diverged};
     const int gm = grid_for(n, kTile);
-    for (int it = 0; it < kSphereIters; ++it) {
+    // the first steps as launches over the compacted list, the rest in the finisher (ARAH_TRACE_BULK_STEPS >= 50: round 2's
+    // schedule, every step its own launches)
+    static const int bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 12)));
+    for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
         launch_nearest<SRC_RAYS>(s, fd, n, (const float*)nullptr, rs, (const float*)w.t, 1, (const int*)lin,
                                  (const int*)&cntA[it], 0, w.nn_idx, w.xcur, w.Tcur, 0, &w.ctr->n_knn);
         LAUNCH_ENGINE(fd.split, k_sdf_march<true>, k_sdf_march<false>, dim3(gm), dim3(kThreads), kLdsSdfFwd, s, fd, ts,
                       (const int*)lin, (const int*)&cntA[it], lout, &cntA[it + 1], &w.ctr->n_sdf_fwd);
+    }
+    if (bulk < kSphereIters) {
+        const int* lin = (bulk & 1) ? w.listB : w.listA;
+        const int gf = min(4 * num_cus(), max(1, (n + kFinTile - 1) / kFinTile));
+        LAUNCH_ENGINE(fd.split, k_trace_finish<true>, k_trace_finish<false>, dim3(gf), dim3(kThreads), kLdsTraceFinish, s, fd,
+                      knn_of(fd), rs, ts, w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk], kSphereIters - bulk, &w.ctr->n_knn,
+                      &w.ctr->n_sdf_fwd);
     }
     // joint root find on the non-diverged rays; best-iterate arrays: x -> xbest_ray, depth -> zbest_ray, T -> T (output)
     hipLaunchKernelGGL(k_joint_select, dim3(gb), dim3(256), 0, s, fd, n, (const float*)w.xcur, (const float*)w.Tcur,
