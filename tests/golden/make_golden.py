@@ -477,7 +477,169 @@ def make_f14():
     print("psnr", res["psnr"], "nan->-1 pixels", int((res["normal_pred"] == 0).all(0).sum()))
 
 
+def make_f7(which):
+    """F7: the reference's whole MetaAvatarRender.forward(eval=True) on small synthetic frames.  The last entry is BASELINE
+    config 5's sampling (128 samples per ray, 32 near / 32 far, H36M shapes) on a small frame."""
+    torch.set_num_threads(os.cpu_count())
+    scene = synthetic.SyntheticScene(seed=0)
+    for name, (H, W), (S, near, far), fidx in which:
+        model, cfg = build_reference_model(name, S, near, far)
+        inputs = scene.make_inputs(H, W, frame_idx=fidx)
+        with torch.no_grad():
+            out = model(inputs, gen_cano_mesh=False, eval=True)
+        save("f7_forward_%s_%dx%d_s%d.npz" % (name, H, W, S), frame_idx=fidx, H=H, W=W, n_steps=S, n_near=near,
+             n_far=far, rgb_values=out["rgb_values"][0], points_cam=out["points_cam"][0],
+             network_body_mask=out["network_body_mask"][0], sdf_param0=out["sdf_params"][0][0, :16],
+             ray_dirs=inputs["ray_dirs"][0], body_bounds_intersections=inputs["body_bounds_intersections"][0])
+
+
+def make_f15():
+    """F15: the lattice of the canonical-mesh branch as the reference's OWN create_mesh_vertices_and_faces
+    (utils/sdf_meshing.py:13-70) builds it -- the only parts of that branch that are reference code rather than skimage /
+    pytorch3d: which coordinates the decoder is asked for and in which order, how the values are laid out in the (N,N,N)
+    volume handed to marching cubes, the level / spacing it is called with, and the map from its vertices back to
+    coordinates.  `.cuda()` is patched to the identity, the decoder records its inputs and returns an asymmetric affine
+    function of them, skimage's marching_cubes_lewiner is replaced by a recorder that returns a fixed vertex list."""
+    import skimage.measure as skm
+    from im2mesh.utils import sdf_meshing
+    rec = {}
+
+    class Decoder(torch.nn.Module):
+        def forward(self, x):
+            rec.setdefault("coords", []).append(x.reshape(-1, 3).clone())
+            rec.setdefault("batch", []).append(x.shape[1])
+            return (0.3 * x[..., 0] - 0.5 * x[..., 1] + 0.7 * x[..., 2] + 0.11).unsqueeze(-1)
+
+    def fake_mc(volume, level=None, spacing=None, **kw):
+        rec["volume"], rec["level"], rec["spacing"] = np.array(volume), level, np.array(spacing, np.float64)
+        idx = np.array([[0.0, 0.0, 0.0], [1.5, 2.25, 3.0], [5.0, 4.0, 0.5], [2.0, 2.0, 2.0]])
+        rec["verts_idx"] = idx
+        return idx * np.asarray(spacing), np.array([[0, 1, 2], [1, 2, 3]]), np.zeros((4, 3)), np.zeros(4)
+
+    old_cuda, old_mc = torch.Tensor.cuda, getattr(skm, "marching_cubes_lewiner", None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    skm.marching_cubes_lewiner = fake_mc
+    try:
+        out = {}
+        N = 6
+        pts, faces = sdf_meshing.create_mesh_vertices_and_faces(Decoder(), N=N, max_batch=50)
+        out.update(N=N, coords=torch.cat(rec["coords"]).numpy(), batches=np.array(rec["batch"]), volume=rec["volume"],
+                   level=np.float64(rec["level"]), spacing=rec["spacing"], verts_idx=rec["verts_idx"], mesh_points=pts,
+                   faces=faces)
+        pts2, _ = sdf_meshing.convert_sdf_samples_to_vertices_and_faces(torch.zeros(N, N, N), [-1, -1, -1], 2.0 / (N - 1),
+                                                                        offset=np.array([0.1, -0.2, 0.3]), scale=2.0)
+        out["mesh_points_scaled"] = pts2
+        rec.clear()
+        N = 256                                            # the size the model asks for (models/__init__.py:205): one axis
+        pts, _ = sdf_meshing.create_mesh_vertices_and_faces(Decoder(), N=N, max_batch=64 ** 3)
+        c = torch.cat(rec["coords"]).reshape(N, N, N, 3)
+        assert torch.equal(c[:, 0, 0, 0], c[:, 5, 9, 0]) and torch.equal(c[0, :, 0, 1], c[3, :, 8, 1])
+        out.update(axis256=c[:, 0, 0, 0].numpy(), axis256_y=c[0, :, 0, 1].numpy(), axis256_z=c[0, 0, :, 2].numpy(),
+                   batches256=np.array(rec["batch"]), spacing256=rec["spacing"], mesh_points256=pts)
+    finally:
+        torch.Tensor.cuda = old_cuda
+        if old_mc is not None:
+            skm.marching_cubes_lewiner = old_mc
+    save("f15_sdf_lattice.npz", **out)
+
+
+def make_f16():
+    """F16: files written by the reference's OWN preprocessing script (preprocess_datasets/preprocess_ZJU-MoCap.py, run as
+    __main__): models/000000.npz through its np.savez call (:150-158) and cam_params.json through its json.dump (:163-164).
+    The script needs the licensed SMPL model, EasyMocap and a raw capture; here its inputs are synthetic (a one-frame,
+    23-camera 'CoreView_377' with random SMPL parameters) and the three things it imports for the body -- human_body_prior's
+    BodyModel, EasyMocap's load_model, `.cuda()` -- are stand-ins that return tensors of the real shapes.  What the fixture
+    pins is therefore the on-disk SCHEMA as reference code writes it: key names, shapes, dtypes, units (T in metres),
+    nesting of the JSON -- what data.load_model_npz / load_cam_params must read."""
+    import json
+    import runpy
+    import shutil
+    import tempfile
+    import types
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(16)
+    tmp = tempfile.mkdtemp()
+    raw, outd = os.path.join(tmp, "raw", "CoreView_377"), os.path.join(tmp, "out")
+    os.makedirs(os.path.join(raw, "Camera_B1"))
+    os.makedirs(os.path.join(raw, "mask_cihp", "Camera_B1"))
+    os.makedirs(os.path.join(raw, "new_params"))
+    os.makedirs(os.path.join(tmp, "body_models", "misc"))
+    np.savez(os.path.join(tmp, "body_models", "misc", "faces.npz"), faces=np.zeros((13776, 3), np.int64))
+    for f in (os.path.join(raw, "Camera_B1", "000000.jpg"), os.path.join(raw, "mask_cihp", "Camera_B1", "000000.png")):
+        open(f, "wb").write(b"x")
+    cams = {"K": [np.array([[1000.0 + c, 0, 512], [0, 1001.0 + c, 513], [0, 0, 1]]) for c in range(23)],
+            "D": [rng.randn(5, 1) * 0.01 for _ in range(23)], "R": [Rotation.from_rotvec(rng.randn(3) * 0.3).as_matrix() for _ in range(23)],
+            "T": [rng.randn(3, 1) * 1000.0 for _ in range(23)]}
+    np.save(os.path.join(raw, "annots.npy"), {"cams": cams}, allow_pickle=True)
+    np.save(os.path.join(raw, "new_params", "0.npy"), {"Rh": rng.randn(1, 3) * 0.2, "Th": rng.randn(1, 3), "shapes": rng.randn(1, 10) * 0.5,
+                                                      "poses": rng.randn(1, 72) * 0.2}, allow_pickle=True)
+    verts = torch.from_numpy(rng.randn(1, 6890, 3).astype(np.float32) * 0.3)
+
+    class _Body:
+        v, Jtr = verts, torch.from_numpy(rng.randn(1, 24, 3).astype(np.float32))
+        bone_transforms = torch.from_numpy(rng.randn(1, 24, 4, 4).astype(np.float32))
+
+    class BodyModel:
+        def __init__(self, *a, **k):
+            pass
+
+        def cuda(self):
+            return self
+
+        def __call__(self, **k):
+            return _Body()
+
+    stubs = {"preprocess_datasets": types.ModuleType("preprocess_datasets"),
+             "preprocess_datasets.easymocap": types.ModuleType("easymocap"),
+             "preprocess_datasets.easymocap.mytools": types.ModuleType("mytools"),
+             "preprocess_datasets.easymocap.mytools.camera_utils": types.ModuleType("camera_utils"),
+             "preprocess_datasets.easymocap.smplmodel": types.ModuleType("smplmodel"),
+             "human_body_prior.body_model.body_model": types.ModuleType("body_model")}
+    for name, mod in stubs.items():          # parents expose their children, packages have a __path__
+        parent, _, child = name.rpartition(".")
+        if parent in stubs:
+            setattr(stubs[parent], child, mod)
+            stubs[parent].__path__ = []
+    stubs["human_body_prior.body_model.body_model"].BodyModel = BodyModel
+    stubs["preprocess_datasets.easymocap.smplmodel"].load_model = lambda **k: (lambda **kk: [verts[0] + 0.01])
+    saved = {k: sys.modules.get(k) for k in stubs}
+    sys.modules.update(stubs)
+    old_cuda, old_argv, old_cwd = torch.Tensor.cuda, sys.argv, os.getcwd()
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        os.chdir(tmp)
+        sys.argv = ["preprocess_ZJU-MoCap.py", "--data-dir", os.path.join(tmp, "raw"), "--out-dir", outd, "--seqname", "CoreView_377"]
+        runpy.run_path(os.path.join(ref_shim.REF_ROOT, "preprocess_datasets", "preprocess_ZJU-MoCap.py"), run_name="__main__")
+    finally:
+        os.chdir(old_cwd)
+        sys.argv, torch.Tensor.cuda = old_argv, old_cuda
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    dst = os.path.join(HERE, "f16_preprocessed_CoreView_377")
+    os.makedirs(os.path.join(dst, "models"), exist_ok=True)
+    shutil.copy(os.path.join(outd, "CoreView_377", "models", "000000.npz"), os.path.join(dst, "models", "000000.npz"))
+    shutil.copy(os.path.join(outd, "CoreView_377", "cam_params.json"), os.path.join(dst, "cam_params.json"))
+    # what went in, for the reader test
+    np.savez(os.path.join(dst, "inputs.npz"), K=np.stack(cams["K"]), D=np.stack(cams["D"]), R=np.stack(cams["R"]), T=np.stack(cams["T"]),
+             verts=verts[0].numpy(), Jtr=_Body.Jtr[0].numpy(), bone_transforms=_Body.bone_transforms[0].numpy())
+    shutil.rmtree(tmp)
+    print("wrote", dst, os.listdir(dst))
+
+
+F7_SET = (("zju377_mono", (64, 64), (64, 16, 16), 0), ("zju313", (64, 64), (64, 16, 16), 1), ("h36m", (48, 48), (32, 8, 8), 2),
+          ("zju377_mono", (128, 128), (32, 8, 8), 5), ("h36m", (40, 40), (128, 32, 32), 3))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f7c5":
+        return make_f7(F7_SET[-1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "f16":
+        return make_f16()
+    if len(sys.argv) > 1 and sys.argv[1] == "f15":
+        return make_f15()
     if len(sys.argv) > 1 and sys.argv[1] == "f14":
         return make_f14()
     if len(sys.argv) > 1 and sys.argv[1] == "f13":
@@ -608,18 +770,7 @@ def main():
         save("f4_color_%s.npz" % name, points=pts, normals=nrm, view=view, feat=feat, rgb=rgb)
 
     # ------------------------------------------------------------------ F7 whole forward
-    for name, (H, W), (S, near, far), fidx in (("zju377_mono", (64, 64), (64, 16, 16), 0),
-                                               ("zju313", (64, 64), (64, 16, 16), 1),
-                                               ("h36m", (48, 48), (32, 8, 8), 2),
-                                               ("zju377_mono", (128, 128), (32, 8, 8), 5)):
-        model, cfg = build_reference_model(name, S, near, far)
-        inputs = scene.make_inputs(H, W, frame_idx=fidx)
-        with torch.no_grad():
-            out = model(inputs, gen_cano_mesh=False, eval=True)
-        save("f7_forward_%s_%dx%d_s%d.npz" % (name, H, W, S), frame_idx=fidx, H=H, W=W, n_steps=S, n_near=near,
-             n_far=far, rgb_values=out["rgb_values"][0], points_cam=out["points_cam"][0],
-             network_body_mask=out["network_body_mask"][0], sdf_param0=out["sdf_params"][0][0, :16],
-             ray_dirs=inputs["ray_dirs"][0], body_bounds_intersections=inputs["body_bounds_intersections"][0])
+    make_f7(F7_SET)
 
 
 if __name__ == "__main__":

@@ -138,6 +138,34 @@ def test_bound_mask_is_the_projected_box(body):
     np.testing.assert_allclose(d.norm(dim=-1).numpy(), 1.0, atol=1e-5)
 
 
+def test_readers_on_files_written_by_the_reference():
+    """Fixture F16: models/000000.npz and cam_params.json as the reference's OWN preprocessing script writes them
+    (preprocess_datasets/preprocess_ZJU-MoCap.py:150-164, run on synthetic inputs by tests/golden/make_golden.py f16).
+    The readers must take them as they are: key names, shapes, dtypes, the metre translations, the JSON nesting."""
+    from arah_release_amd import data
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f16_preprocessed_CoreView_377")
+    src = np.load(os.path.join(root, "inputs.npz"))
+    frames, files = data.list_sequence(root)
+    assert frames == [0] and files[0].endswith("models/000000.npz")
+    m = data.load_model_npz(files[0])
+    assert set(m) == set(data.MODEL_KEYS)
+    for k, shp in data.MODEL_SHAPES.items():
+        assert m[k].shape == shp and m[k].dtype == np.float32, k
+    assert m["betas"].shape == (1, 10)
+    np.testing.assert_array_equal(m["minimal_shape"], src["verts"])          # what the (stand-in) body model returned
+    np.testing.assert_array_equal(m["Jtr_posed"], src["Jtr"])
+    np.testing.assert_array_equal(m["bone_transforms"], src["bone_transforms"])
+    assert m["pose_body"].shape == (63,) and m["pose_hand"].shape == (6,) and m["root_orient"].shape == (3,)
+    cams = data.load_cam_params(os.path.join(root, "cam_params.json"))
+    assert cams["all_cam_names"] == [str(c) for c in range(1, 24)]            # preprocess_ZJU-MoCap.py:46-49
+    for c, name in enumerate(cams["all_cam_names"]):
+        cam = cams[name]
+        np.testing.assert_allclose(cam["K"], src["K"][c], rtol=1e-6)
+        np.testing.assert_allclose(cam["R"], src["R"][c], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(cam["T"], src["T"][c].reshape(3) / 1000.0, rtol=1e-6)   # millimetres -> metres (:70-71)
+        np.testing.assert_allclose(cam["D"], src["D"][c].reshape(-1), rtol=1e-6, atol=1e-9)
+
+
 def test_on_disk_formats_round_trip(tmp_path, scene, body):
     """cam_params.json / models/*.npz as preprocess_ZJU-MoCap.py:150-158 writes them."""
     from arah_release_amd import data

@@ -352,7 +352,8 @@ def test_shade_composite_against_reference(scene, name, tag, eng):
 @pytest.mark.parametrize("fname,name", [("f7_forward_zju377_mono_64x64_s64.npz", "zju377_mono"),
                                         ("f7_forward_zju313_64x64_s64.npz", "zju313"),
                                         ("f7_forward_h36m_48x48_s32.npz", "h36m"),
-                                        ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono")])
+                                        ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono"),
+                                        ("f7_forward_h36m_40x40_s128.npz", "h36m")])   # BASELINE config 5's sampling (128, 32, 32)
 @pytest.mark.parametrize("eng", ENGINES)
 def test_forward_against_reference(scene, fname, name, eng):
     """MetaAvatarRender.forward(inputs, eval=True): dict in / dict out vs the reference's dict (f7)."""

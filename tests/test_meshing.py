@@ -106,6 +106,68 @@ def test_rasterize_against_oracle():
     assert not np.isin(got, np.arange(7)).any()
 
 
+def _f15():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f15_sdf_lattice.npz"))
+
+
+def test_lattice_convention_is_the_references():
+    """Fixture F15 (the reference's own create_mesh_vertices_and_faces with a recording decoder and a recording stand-in
+    for skimage): the volume handed to marching cubes is indexed [ix, iy, iz] with ix slowest, on coordinates
+    index * (2 / (N - 1)) - 1 formed by a float32 product and a float32 sum; marching cubes runs at level 0 with that
+    spacing and its vertices (index * spacing) map back through origin + vertex.  The build's marching_cubes restates the
+    last step; its lattice restates the first (checked on the device in test_sdf_grid_is_the_references_lattice)."""
+    from arah_release_amd import meshing
+    g = _f15()
+    N = int(g["N"])
+    vs = np.float32(2.0 / (N - 1))
+    ax = (np.arange(N, dtype=np.float32) * vs + np.float32(-1.0)).astype(np.float32)
+    X, Y, Z = np.meshgrid(ax, ax, ax, indexing="ij")
+    np.testing.assert_array_equal(np.stack([X, Y, Z], -1).reshape(-1, 3), g["coords"])            # order and bits
+    f = lambda c: (0.3 * c[..., 0] - 0.5 * c[..., 1] + 0.7 * c[..., 2] + 0.11)
+    np.testing.assert_allclose(g["volume"], f(g["coords"].reshape(N, N, N, 3)), rtol=0, atol=1e-6)     # volume[ix, iy, iz]
+    assert float(g["level"]) == 0.0 and np.allclose(g["spacing"], 2.0 / (N - 1))
+    np.testing.assert_allclose(g["mesh_points"], g["verts_idx"] * (2.0 / (N - 1)) - 1.0, atol=1e-12)
+    np.testing.assert_allclose(g["mesh_points_scaled"], (g["verts_idx"] * (2.0 / (N - 1)) - 1.0) / 2.0 - np.array([0.1, -0.2, 0.3]),
+                               atol=1e-12)
+    ax256 = (np.arange(256, dtype=np.float32) * np.float32(2.0 / 255) + np.float32(-1.0)).astype(np.float32)
+    for k in ("axis256", "axis256_y", "axis256_z"):
+        np.testing.assert_array_equal(g[k], ax256)
+    assert g["batches256"].tolist() == [64 ** 3] * 64
+    # the build's extraction on the reference's own volume: the plane 0.3 x - 0.5 y + 0.7 z + 0.11 = 0, vertices in the
+    # reference's coordinates (origin + index * spacing)
+    tri = meshing.marching_cubes(torch.from_numpy(g["volume"]))
+    assert tri.shape[0] > 0 and float(tri.abs().max()) <= 1.0 + 1e-6
+    v = tri.reshape(-1, 3).double().numpy()
+    assert np.abs(f(v)).max() < 1e-5                                        # on the level set, in the reference's frame
+    n = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0]).astype(np.float64)
+    assert (n @ np.array([0.3, -0.5, 0.7]) < 0).all()                       # right-hand normals point down the gradient
+
+
+@gpu
+def test_sdf_grid_is_the_references_lattice(scene):
+    """arah_sdf_grid against fixture F15: the value at [ix, iy, iz] is the SDF at the coordinates the reference asks its
+    decoder for at that position of its volume -- bit for bit the same inputs, hence the same outputs as a point query."""
+    from arah_release_amd import hip
+    g = _f15()
+    dev = torch.device("cuda:0")
+    model, cfg = get_model("zju377_mono", dev)
+    with torch.no_grad():
+        model(scene.make_inputs(32, 32, frame_idx=1, device=dev), eval=True)
+    frame, ws = model.idhr_network.last_frame, model.idhr_network.ray_tracer.workspace(dev)
+    N = int(g["N"])
+    grid = hip.sdf_grid(frame, ws, N)
+    sdf, _, _ = hip.sdf_eval(frame, ws, torch.from_numpy(g["coords"]).to(dev))
+    assert torch.equal(grid.reshape(-1), sdf)
+    big = hip.sdf_grid(frame, ws, 256)
+    rng = np.random.RandomState(0)
+    idx = rng.randint(0, 256, size=(4096, 3))
+    ax = torch.from_numpy(g["axis256"]).to(dev)
+    pts = torch.stack([ax[idx[:, 0]], ax[idx[:, 1]], ax[idx[:, 2]]], dim=-1)
+    sdf, _, _ = hip.sdf_eval(frame, ws, pts)
+    assert torch.equal(big[idx[:, 0], idx[:, 1], idx[:, 2]], sdf)
+
+
 @gpu
 def test_sdf_grid_matches_point_queries(scene):
     from arah_release_amd import hip

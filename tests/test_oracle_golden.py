@@ -162,7 +162,8 @@ def test_f6_shade(scene, name, tag):
 @pytest.mark.parametrize("fname,name", [("f7_forward_zju377_mono_64x64_s64.npz", "zju377_mono"),
                                         ("f7_forward_zju313_64x64_s64.npz", "zju313"),
                                         ("f7_forward_h36m_48x48_s32.npz", "h36m"),
-                                        ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono")])
+                                        ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono"),
+                                        ("f7_forward_h36m_40x40_s128.npz", "h36m")])   # BASELINE config 5's sampling (128, 32, 32)
 def test_f7_forward(scene, fname, name):
     g = golden(fname)
     model, cfg = get_model(name)
