@@ -2596,7 +2596,8 @@ FrameLayout frame_layout(int col_mode) {
     L.sdf_bias = take(6 * 256);
     L.sdf_freq = take(6 * 256);
     L.sdf_phase = take(6 * 256);
-    for (int i = 0; i < 5; ++i) L.sdf_wps[i] = take(256 * 256);   // hi + lo halves = 4 bytes per weight
+    for (int i = 0; i < 5; ++i) L.sdf_wps[i] = take(256 * 256);   // hi + lo halves = 4 bytes per weight; CONTIGUOUS, kSdfSplitLayerBytes
+                                                                  // apart (sdf_trunk_tile16 addresses them through one descriptor)
     L.sdf_fw = take(6 * 256);
     L.sdf_pw = take(6 * 256);
     L.sdf_fws = take(6 * 256);
@@ -2691,6 +2692,8 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     if (nets->precision != ARAH_PRECISION_SPLIT_F16 && nets->precision != ARAH_PRECISION_FP32) return ARAH_E_BADARG;
     const FrameLayout L = frame_layout(nets->col_mode);
     if (frame_bytes < L.bytes) return ARAH_E_WORKSPACE;
+    for (int i = 0; i < 4; ++i)
+        if (L.sdf_wps[i + 1] - L.sdf_wps[i] != (size_t)kSdfSplitLayerBytes) return ARAH_E_SHAPE;   // layout contract of sdf_trunk_tile16
     if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* base = reinterpret_cast<char*>(frame_buf);

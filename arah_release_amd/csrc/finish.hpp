@@ -15,7 +15,7 @@ constexpr size_t kLdsJointFinish = (kFinTile * 4 * 3 + 24 * 16 + kFinTile * 2 + 
 
 // ---- loop A: the remaining sphere-tracing steps of the rays in list[0 .. *count)
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnData kd, RaySet rs, TraceState st, float* Tcur,
+__global__ __launch_bounds__(kThreads, 2) void k_trace_finish(FrameDev fr, KnnData kd, RaySet rs, TraceState st, float* Tcur,
                                                             int* nn_idx, const int* list, const int* count, int steps_left,
                                                             unsigned long long* ctr_knn, unsigned long long* ctr_fwd) {
     const BodyConst bc = load_bc(fr);
@@ -100,8 +100,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
                 }
             }
             __syncthreads();
-            f32x4 dlast[kSdfMT][1];
-            sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+            if constexpr (SPLIT) {
+                sdf_trunk_tile16(fr.sdf, xin, actA, kSdfLd, wave, lane);
+            } else {
+                f32x4 dlast[kSdfMT][1];
+                sdf_trunk<false, 1, false>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+            }
             sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid, kFinTile);
             __syncthreads();
             if (tid < kFinTile) {
@@ -138,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
 
 // ---- loop B: the remaining Broyden iterations (none of them the first) of the rays in list[0 .. *count)
 template <bool SPLIT>
-__global__ __launch_bounds__(kThreads) void k_joint_finish(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
+__global__ __launch_bounds__(kThreads, 2) void k_joint_finish(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
                                                             const int* count, int iters_left, unsigned long long* ctr_skin,
                                                             unsigned long long* ctr_sdf) {
     const BodyConst bc = load_bc(fr);
@@ -183,8 +187,12 @@ __global__ __launch_bounds__(kThreads) void k_joint_finish(FrameDev fr, Broyden4
             __syncthreads();
             if (!*s_live) break;
             skin_mlp<1>(fr.skin, xin, act, logits, wave, lane);
-            f32x4 dlast[kSdfMT][1];
-            sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+            if constexpr (SPLIT) {
+                sdf_trunk_tile16(fr.sdf, xin, act, kSdfLd, wave, lane);
+            } else {
+                f32x4 dlast[kSdfMT][1];
+                sdf_trunk<false, 1, false>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+            }
             sdf_head<SPLIT>(fr.sdf, act, kSdfLd, outv, 4, tid, TW);
             __syncthreads();
             if (tid < TW) {

@@ -404,6 +404,7 @@ struct SdfNet {
     const f16x8* wps[5];   // split-packed 256x256
 };
 
+constexpr int kSdfSplitLayerBytes = 256 * 256 * 4;   // hi + lo halves of one 256 x 256 layer; SdfNet::wps[k] = wps[0] + k * this
 constexpr int kSdfLd = 264;   // 256 + 8: rows 8 dwords apart mod 64 (see split_slot)
 constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
 
@@ -590,6 +591,98 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
                     else dlast[m][n] = d;
                 }
             }
+        }
+        ARAH_SYNC();
+    }
+}
+
+// The forward trunk of ONE 16-point tile on the split engine, arranged for latency (the resident finishers of loops A
+// and B, csrc/finish.hpp, run it hundreds of times back to back with nothing else on the CU).  sdf_trunk<false, 1, true>
+// streams a layer's weight fragments one 32-chunk ahead of six MFMAs: at this tile width every chunk waits for L2.  Here
+// a wave requests its whole slice of the NEXT layer (32 fragments, 128 registers) as soon as the MFMAs of the current
+// one have issued -- the request travels under the epilogue and the two barriers -- and takes all B fragments of a layer
+// from LDS in one batch.  Same MFMA order per accumulator and the same epilogue as sdf_trunk: bit-identical results.
+__device__ __forceinline__ void sdf_trunk_tile16(const SdfNet& net, const float* xin, float* act, int ld, int wave, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const int mt0 = wave * kSdfMT;
+    constexpr float amp = kActScale;
+    f16x8 ah[kSdfMT][8], al[kSdfMT][8];
+    // one buffer descriptor over the five split-packed layers (contiguous in the frame buffer, kSdfSplitLayerBytes apart):
+    // the lane's slot in the vector offset, layer and fragment in the scalar offset -- no address registers per fragment
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16x8*>(net.wps[0]), 0, 5 * kSdfSplitLayerBytes, 0x00020000);
+    const int voff = (mt0 * 8 * 2 * 64 + lane) * 16;
+    auto request = [&](int layer) {   // layer = 1..5: fragments of net.wps[layer - 1]
+        const int lbase = (layer - 1) * kSdfSplitLayerBytes;
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+            for (int kc = 0; kc < 8; ++kc) {
+                ah[m][kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, voff, lbase + ((m * 8 + kc) * 2 + 0) * 1024, 0));
+                al[m][kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, voff, lbase + ((m * 8 + kc) * 2 + 1) * 1024, 0));
+            }
+    };
+    request(1);
+    {   // layer 1: K = 3 on the vector ALU (as sdf_trunk)
+        const f32x4 x = *reinterpret_cast<const f32x4*>(xin + j * 4);
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            f32x4 w[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+            f32x4 v, h, d;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], w[r][0] * x[0]));
+            no_pack(v);
+            film_sine<false>(v, fw, pw, fw, amp, h, d);
+            store_split4(act, ld, 512, j, ch0, h);
+        }
+    }
+    ARAH_SYNC();
+    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
+#pragma unroll 1
+    for (int k = 1; k < 6; ++k) {
+        f32x4 acc[kSdfMT];
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) zero_acc(acc[m]);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {   // B fragments in two batches of four chunks (registers)
+            f16x8 bh[4], bl[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                bh[c] = *reinterpret_cast<const f16x8*>(bptr + (half * 4 + c) * 64);
+                bl[c] = *reinterpret_cast<const f16x8*>(bptr + 512 + (half * 4 + c) * 64);
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int kc = half * 4 + c;
+#pragma unroll
+                for (int m = 0; m < kSdfMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kc], bh[c], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < kSdfMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kc], bl[c], acc[m], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < kSdfMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kc], bh[c], acc[m], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the requests below reuse the registers of the fragments just consumed
+        if (k < 5) request(k + 1);
+        f32x4 fwm[kSdfMT], pwm[kSdfMT];
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            fwm[m] = *reinterpret_cast<const f32x4*>(net.fws + k * 256 + ch0);
+            pwm[m] = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+        }
+        ARAH_SYNC();   // everyone is done reading the layer input
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            f32x4 h, d;
+            film_sine<false>(acc[m], fwm[m], pwm[m], fwm[m], amp, h, d);
+            store_split4(act, ld, 512, j, ch0, h);
         }
         ARAH_SYNC();
     }
