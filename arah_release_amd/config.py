@@ -512,6 +512,18 @@ def synthetic_state_dict(cfg, asset_path=None):
     return sd
 
 
+def widen_skinning_(module_or_state, scale=8.0):
+    """Test subject with a WIDE-RANGE skinning MLP: the weight-norm gains of its three hidden 128 x 128 layers times
+    `scale` (pre-activations and Softplus outputs grow by about that factor per layer).  Works in place on a model (this
+    build's or the reference's: same parameter names) or on a state dict; fixture F17 is the reference on such a subject."""
+    pre = "skinning_model.skinning_decoder_fwd."
+    sd = module_or_state if isinstance(module_or_state, dict) else module_or_state.state_dict()
+    with torch.no_grad():
+        for k in (1, 2, 3):
+            sd[pre + "lin%d.weight_g" % k].mul_(scale)
+    return module_or_state
+
+
 def build_synthetic_model(name="zju377_mono", n_steps=64, near=16, far=16, device="cpu", seed=0, training=None):
     """Builtin config + synthetic weights; deterministic.  The emitted SDF MLP is the fitted SIREN plus a seeded,
     pose- and latent-dependent residual of about a percent per weight (synthetic_state_dict)."""

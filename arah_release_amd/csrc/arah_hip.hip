@@ -302,8 +302,21 @@ __global__ void k_skin_wave_consts(SkinRaw net, const float* __restrict__ w4b, c
         for (int k = 1; k < 4; ++k) c[kCwBz + (k - 1) * 128 + i] = net.b[k][i] * kZUnit;
     }
     if (i < 32) c[kCwB4 + i] = i < 25 ? w4b[i] : 0.f;
-    if (i < 3) c[kCwInv + i] = 1.0f / split_weight_scale(amax[4 + i]);
-    if (i == 3) c[kCwInv + 3] = (float)(0.6931471805599453 / 100.0) / split_weight_scale(amax[7]);
+    if (i < 4) {
+        // activation scale of layer i's output (z units: 100 log2(e) x): 1 for an ordinary network, smaller when the
+        // probed maximum times 32 would leave the f16 range (amax[0..3]: k_skin_probe, x units)
+        auto act_scale = [&](int k) {
+            const float a = __uint_as_float(amax[k]) * kZUnit;
+            if (!(a > 0.f) || a > 3.0e38f) return 1.0f;
+            int e;
+            frexpf(a, &e);   // a = m 2^e, m in [0.5, 1)
+            return e > 11 ? ldexpf(1.0f, 11 - e) : 1.0f;
+        };
+        c[kCwActS + i] = act_scale(i);
+        if (i == 0) c[kCwScaled] = (act_scale(0) != 1.0f || act_scale(1) != 1.0f || act_scale(2) != 1.0f || act_scale(3) != 1.0f) ? 1.0f : 0.0f;
+        const float k4 = i == 3 ? (float)(0.6931471805599453 / 100.0) : 1.0f;
+        c[kCwInv + i] = k4 / (split_weight_scale(amax[4 + i]) * act_scale(i));
+    }
 }
 
 // the per-frame scalars stay on the device: trans(3), center(3), coord_min, coord_max, |variance| -> scal[9]
@@ -1011,7 +1024,7 @@ __global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
             if (id >= 0 && grid_n > 0) {
                 // lattice point id = (ix * N + iy) * N + iz of [-1, 1]^3, coordinates as sdf_meshing.py:26-38 forms them
-                const float vs = 2.0f / (float)(grid_n - 1);
+                const float vs = (float)(2.0 / (double)(grid_n - 1));   // voxel_size is a Python float, rounded once (sdf_meshing.py:21)
                 const int iz = id % grid_n, iy = (id / grid_n) % grid_n, ix = id / (grid_n * grid_n);
                 // product and sum rounded separately, like the two tensor operations of the reference (no fma contraction)
                 x = f32x4{__fadd_rn(__fmul_rn((float)ix, vs), -1.0f), __fadd_rn(__fmul_rn((float)iy, vs), -1.0f),
@@ -2502,16 +2515,20 @@ int setup_attributes() {
     allow_lds(k_skin_jac, kLdsSkin);
     allow_lds(k_canon_solve<false>, kLdsCanonSolve);
     allow_lds(k_canon_solve<true>, kLdsSplitSolo);
-    allow_lds(k_canon_wave<true>, kLdsCanonWave);
-    allow_lds(k_canon_wave<false>, kLdsCanonWave);
+    allow_lds((k_canon_wave<true, false>), kLdsCanonWave);
+    allow_lds((k_canon_wave<true, true>), kLdsCanonWave);
+    allow_lds((k_canon_wave<false, false>), kLdsCanonWave);
+    allow_lds((k_canon_wave<false, true>), kLdsCanonWave);
     allow_lds(k_joint_iter<true, false>, kLdsJoint);
     allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<false, false>, kLdsJoint);
     allow_lds(k_joint_iter<false, true>, kLdsSplitSolo);
-    allow_lds(k_trace_finish<true>, kLdsTraceFinish);
-    allow_lds(k_trace_finish<false>, kLdsTraceFinish);
-    allow_lds(k_joint_finish<true>, kLdsJointFinish);
-    allow_lds(k_joint_finish<false>, kLdsJointFinish);
+    allow_lds((k_trace_finish<true, true>), kLdsTraceFinish);
+    allow_lds((k_trace_finish<true, false>), kLdsTraceFinish);
+    allow_lds((k_trace_finish<false, false>), kLdsTraceFinish);
+    allow_lds((k_joint_finish<true, true>), kLdsJointFinish);
+    allow_lds((k_joint_finish<true, false>), kLdsJointFinish);
+    allow_lds((k_joint_finish<false, false>), kLdsJointFinish);
     allow_lds(k_shade<false, false>, lds_shade<false>());
     allow_lds(k_shade<false, true>, lds_shade<false>());
     allow_lds(k_shade<true, false>, lds_shade<true>());
@@ -3047,14 +3064,23 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
         const int cus = num_cus();
         if (gw > cus) gw = cus;
         if (gw < 1) gw = 1;
-        if (mode == 1)
-            hipLaunchKernelGGL(k_canon_wave<true>, dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
+        // two instances are launched, one returns at once: whether the activations of this frame's skinning MLP need scaling
+        // down to stay inside the f16 range is known on the device only (k_skin_probe), and the plain instance is the faster
+        if (mode == 1) {
+            hipLaunchKernelGGL((k_canon_wave<true, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
                                (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
                                &w.ctr->n_split_nonfinite, w.ctr->clk);
-        else
-            hipLaunchKernelGGL(k_canon_wave<false>, dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
+            hipLaunchKernelGGL((k_canon_wave<true, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
+                               (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
+                               &w.ctr->n_split_nonfinite, w.ctr->clk);
+        } else {
+            hipLaunchKernelGGL((k_canon_wave<false, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
                                (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
                                &w.ctr->n_canon, &w.ctr->n_split_nonfinite, w.ctr->clk);
+            hipLaunchKernelGGL((k_canon_wave<false, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
+                               (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
+                               &w.ctr->n_canon, &w.ctr->n_split_nonfinite, w.ctr->clk);
+        }
     } else {
         LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
                       kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
@@ -3118,8 +3144,14 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
     if (bulk <= kBroydenSteps) {
         const int* lin = (bulk & 1) ? w.listB : w.listA;
         const int gf = min(4 * num_cus(), max(1, (n + kFinTile - 1) / kFinTile));
-        LAUNCH_ENGINE(fd.split, k_joint_finish<true>, k_joint_finish<false>, dim3(gf), dim3(kThreads), kLdsJointFinish, s, fd,
-                      st, rs, lin, (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk, &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+        static const bool fast = env_int("ARAH_FINISH_FAST", 0) != 0;   // the latency-arranged trunk (one workgroup per CU)
+        if (fd.split && fast)
+            hipLaunchKernelGGL((k_joint_finish<true, true>), dim3(gf), dim3(kThreads), kLdsJointFinish, s, fd, st, rs, lin,
+                               (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk, &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+        else
+            LAUNCH_ENGINE(fd.split, (k_joint_finish<true, false>), (k_joint_finish<false, false>), dim3(gf), dim3(kThreads),
+                          kLdsJointFinish, s, fd, st, rs, lin, (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk,
+                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
     }
 }
 
@@ -3152,9 +3184,14 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     if (bulk < kSphereIters) {
         const int* lin = (bulk & 1) ? w.listB : w.listA;
         const int gf = min(4 * num_cus(), max(1, (n + kFinTile - 1) / kFinTile));
-        LAUNCH_ENGINE(fd.split, k_trace_finish<true>, k_trace_finish<false>, dim3(gf), dim3(kThreads), kLdsTraceFinish, s, fd,
-                      knn_of(fd), rs, ts, w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk], kSphereIters - bulk, &w.ctr->n_knn,
-                      &w.ctr->n_sdf_fwd);
+        static const bool fast = env_int("ARAH_FINISH_FAST", 0) != 0;
+        if (fd.split && fast)
+            hipLaunchKernelGGL((k_trace_finish<true, true>), dim3(gf), dim3(kThreads), kLdsTraceFinish, s, fd, knn_of(fd), rs, ts,
+                               w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk], kSphereIters - bulk, &w.ctr->n_knn, &w.ctr->n_sdf_fwd);
+        else
+            LAUNCH_ENGINE(fd.split, (k_trace_finish<true, false>), (k_trace_finish<false, false>), dim3(gf), dim3(kThreads),
+                          kLdsTraceFinish, s, fd, knn_of(fd), rs, ts, w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk],
+                          kSphereIters - bulk, &w.ctr->n_knn, &w.ctr->n_sdf_fwd);
     }
     // joint root find on the non-diverged rays; best-iterate arrays: x -> xbest_ray, depth -> zbest_ray, T -> T (output)
     hipLaunchKernelGGL(k_joint_select, dim3(gb), dim3(256), 0, s, fd, n, (const float*)w.xcur, (const float*)w.Tcur,

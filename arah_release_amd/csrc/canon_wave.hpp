@@ -91,12 +91,15 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <bool HI_LDS>
+template <bool HI_LDS, bool SCALED>
 __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
                                                               int* queue_head, CanonOut outp, unsigned long long* ctr,
                                                               unsigned long long* ctr_canon,
                                                               unsigned long long* ctr_bad, unsigned long long* clk_out) {
     constexpr int NT = kCwNT;
+    // SCALED: the instance for skinning networks whose activations must travel scaled down (kCwActS); the frame's constants
+    // say which of the two instances of a launch pair runs
+    if ((fr.skw.consts[kCwScaled] != 0.f) != SCALED) return;
     const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     KernelClk clk;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
         }
     }
     const float inv1 = cst[kCwInv], inv2 = cst[kCwInv + 1], inv3 = cst[kCwInv + 2], c_out = cst[kCwInv + 3];
+    const float as0 = cst[kCwActS], as1 = cst[kCwActS + 1], as2 = cst[kCwActS + 2], as3 = cst[kCwActS + 3];
     // RFU:37-44 as one fma per coordinate: x_norm = (x - center - cmin + pad) * 2 / (1.1 rng) - 1
     const float nrm_s = 2.0f / ((bc.cmax - bc.cmin) * 1.1f);
     float nrm_o[3];
@@ -346,6 +350,11 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                 const float inv = L == 1 ? inv1 : (L == 2 ? inv2 : inv3);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, e.v[0][r]));
+            }
+            if constexpr (SCALED) {   // a wide-range layer travels scaled down (a power of two: exact)
+                const float as = L == 0 ? as0 : (L == 1 ? as1 : (L == 2 ? as2 : as3));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] *= as;
             }
             unsigned h0, h1, l0, l1;
             split4(v, h0, h1, l0, l1);

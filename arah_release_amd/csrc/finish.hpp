@@ -14,8 +14,8 @@ constexpr size_t kLdsTraceFinish = (kFinTile * 4 * 2 + kFinTile * 16 + 24 * 16 +
 constexpr size_t kLdsJointFinish = (kFinTile * 4 * 3 + 24 * 16 + kFinTile * 2 + kFinTile * kLogitLd + 32) * 4 + (size_t)kFinTile * kSdfLd * 4;
 
 // ---- loop A: the remaining sphere-tracing steps of the rays in list[0 .. *count)
-template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, 2) void k_trace_finish(FrameDev fr, KnnData kd, RaySet rs, TraceState st, float* Tcur,
+template <bool SPLIT, bool FAST>
+__global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_trace_finish(FrameDev fr, KnnData kd, RaySet rs, TraceState st, float* Tcur,
                                                             int* nn_idx, const int* list, const int* count, int steps_left,
                                                             unsigned long long* ctr_knn, unsigned long long* ctr_fwd) {
     const BodyConst bc = load_bc(fr);
@@ -35,6 +35,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_trace_finish(FrameDev fr, KnnDa
     const int n = *count;
     const GridInfo g = *kd.grid;
     const float scale = sdf_scale(bc);
+    int n_done = 0;   // evaluations of this workgroup (one atomic at the end: a counter bumped every step by every tile is the
+                      // most contended word of the launch, and the waves' next loads queue behind it)
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * kFinTile < n; tile += gridDim.x) {
         __syncthreads();
@@ -51,11 +53,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_trace_finish(FrameDev fr, KnnDa
             __syncthreads();
             if (wave == 0) {
                 const unsigned long long live = __ballot(lane < kFinTile && ids[lane] >= 0);
-                if (lane == 0) {
-                    *s_live = live != 0ull;
-                    count_add(ctr_knn, __popcll(live));
-                    count_add(ctr_fwd, __popcll(live));
-                }
+                n_done += __popcll(live);
+                if (lane == 0) *s_live = live != 0ull;
             }
             __syncthreads();
             if (!*s_live) break;
@@ -100,11 +99,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_trace_finish(FrameDev fr, KnnDa
                 }
             }
             __syncthreads();
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT && FAST) {
                 sdf_trunk_tile16(fr.sdf, xin, actA, kSdfLd, wave, lane);
             } else {
                 f32x4 dlast[kSdfMT][1];
-                sdf_trunk<false, 1, false>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+                sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
             }
             sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid, kFinTile);
             __syncthreads();
@@ -138,11 +137,15 @@ __global__ __launch_bounds__(kThreads, 2) void k_trace_finish(FrameDev fr, KnnDa
             }
         }
     }
+    if (tid == 0) {
+        count_add(ctr_knn, n_done);
+        count_add(ctr_fwd, n_done);
+    }
 }
 
 // ---- loop B: the remaining Broyden iterations (none of them the first) of the rays in list[0 .. *count)
-template <bool SPLIT>
-__global__ __launch_bounds__(kThreads, 2) void k_joint_finish(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
+template <bool SPLIT, bool FAST>
+__global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_joint_finish(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
                                                             const int* count, int iters_left, unsigned long long* ctr_skin,
                                                             unsigned long long* ctr_sdf) {
     const BodyConst bc = load_bc(fr);
@@ -159,6 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void k_joint_finish(FrameDev fr, Broyd
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = *count;
     const float scale = sdf_scale(bc);
+    int n_done = 0;
     for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
         __syncthreads();
@@ -170,11 +174,8 @@ __global__ __launch_bounds__(kThreads, 2) void k_joint_finish(FrameDev fr, Broyd
             __syncthreads();
             if (wave == 0) {
                 const unsigned long long live = __ballot(lane < TW && ids[lane] >= 0);
-                if (lane == 0) {
-                    *s_live = live != 0ull;
-                    count_add(ctr_skin, __popcll(live));
-                    count_add(ctr_sdf, __popcll(live));
-                }
+                n_done += __popcll(live);
+                if (lane == 0) *s_live = live != 0ull;
             }
             if (tid < TW) {
                 const int id = ids[tid];
@@ -187,11 +188,11 @@ __global__ __launch_bounds__(kThreads, 2) void k_joint_finish(FrameDev fr, Broyd
             __syncthreads();
             if (!*s_live) break;
             skin_mlp<1>(fr.skin, xin, act, logits, wave, lane);
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT && FAST) {
                 sdf_trunk_tile16(fr.sdf, xin, act, kSdfLd, wave, lane);
             } else {
                 f32x4 dlast[kSdfMT][1];
-                sdf_trunk<false, 1, false>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
+                sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
             }
             sdf_head<SPLIT>(fr.sdf, act, kSdfLd, outv, 4, tid, TW);
             __syncthreads();
@@ -241,5 +242,9 @@ __global__ __launch_bounds__(kThreads, 2) void k_joint_finish(FrameDev fr, Broyd
                 }
             }
         }
+    }
+    if (tid == 0) {
+        count_add(ctr_skin, n_done);
+        count_add(ctr_sdf, n_done);
     }
 }

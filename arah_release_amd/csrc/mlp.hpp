@@ -817,8 +817,11 @@ enum {
     kCwW0 = 0,      // [128][4]  {w0x, w0y, w0z, b0} * 100 log2(e)
     kCwBz = 512,    // [3][128]  b_k * 100 log2(e), k = 1..3
     kCwB4 = 896,    // [32]      b_4 (25 valid)
-    kCwInv = 928,   // [4]       1 / weight scale of layers 1..3; ln(2)/100 / weight scale of layer 4
-    kCwSize = 936
+    kCwInv = 928,   // [4]       1 / (weight scale of layer k * activation scale of layer k - 1), k = 1..3; the same * ln(2)/100 for k = 4
+    kCwActS = 932,  // [4]       activation scale of layers 0..3: 1 unless the probed activations (k_skin_probe) call for
+                    //           less -- a power of two that keeps 32 x the probed maximum inside the f16 range
+    kCwScaled = 936, // [1]      1 if any activation scale differs from 1 (selects the SCALED instance of the kernel), else 0
+    kCwSize = 940
 };
 constexpr float kZUnit = 144.269504088896341f;   // 100 log2(e)
 

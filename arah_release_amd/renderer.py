@@ -176,6 +176,10 @@ class IDHRNetwork(nn.Module):
         self.render_last_pt = render_last_pt
         self.low_vram = low_vram
         self.last_counters = None
+        # range guard of the split engine (ArahCounters.n_split_nonfinite): see _split_guard
+        self.split_nonfinite = 0
+        self._guard = {}
+        self._precision = None   # None: ARAH_PRECISION / default; becomes hip.PRECISION_FP32 once the guard has fired
 
     def forward_train(self, input):
         """Training forward (IDR:42-248): HIP kernels for the ray tracer (no_grad, like the reference), autograd
@@ -238,6 +242,34 @@ class IDHRNetwork(nn.Module):
             out["inside_sdf"] = inside_sdf
         return out
 
+    def _split_guard(self, ws, dev):
+        """The split engine carries activations as f16 pairs; a network whose activations leave the f16 range makes loop C's
+        first residual of a sample non-finite, the kernel counts those (ArahCounters.n_split_nonfinite) and retires the
+        sample at its start state.  The count of frame k is copied to pinned host memory behind frame k (eight bytes, no
+        stream drain) and looked at when frame k + 1 starts: if it grew, every later frame of this renderer is prepared
+        for the exact fp32 engine, with a warning (`split_nonfinite` holds the total; a caller that needs frame k itself
+        exact re-renders it)."""
+        g = self._guard.get(dev)
+        if g is not None and g["event"].query():
+            now = int(g["host"].item())
+            grew = now - g["seen"] if now >= g["seen"] else now      # the counters may have been reset in between
+            g["seen"] = now
+            if grew > 0:
+                self.split_nonfinite += grew
+                if self._precision != hip.PRECISION_FP32:
+                    import warnings
+                    warnings.warn("split-f16 engine: %d loop-C samples met activations outside the f16 range; following frames "
+                                  "use the exact fp32 engine (ARAH_PRECISION=fp32)" % grew)
+                    self._precision = hip.PRECISION_FP32
+        if g is None:
+            g = self._guard[dev] = {"host": torch.zeros(1, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(), "seen": 0}
+        return g
+
+    def _split_guard_arm(self, g, ws):
+        # n_split_nonfinite is the ninth 64-bit counter at the head of the workspace (include/arah_hip.h: ArahCounters)
+        g["host"].copy_(ws.buf[64:72].view(torch.int64), non_blocking=True)
+        g["event"].record()
+
     def forward(self, input):
         if self.training:
             return self.forward_train(input)
@@ -249,16 +281,19 @@ class IDHRNetwork(nn.Module):
         if N == 0:
             raise ValueError("No valid depth.")
         dev = ray_dirs.device
+        guard = self._split_guard(None, dev) if dev.type == "cuda" else None
         frame = build_frame(input["sdf_network"], self.skinning_model, self.rendering_network,
                             self.deviation_network, input["pose_cond"], input["smpl_verts"],
                             input["skinning_weights"], input["bone_transforms"], input["trans"],
-                            input["coord_min"], input["coord_max"], input["center"])
+                            input["coord_min"], input["coord_max"], input["center"], precision=self._precision)
         self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
         ws = self.ray_tracer.workspace(dev)
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                       ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2),
                                                       pose[0, :3, :4].detach().float().contiguous())
+        if guard is not None:
+            self._split_guard_arm(guard, ws)
         pcam = pcam.reshape(B, N, 3)
         if B > 1:   # per-view camera pose for the remaining batch elements (IDR:114-115)
             pw = cam_loc.reshape(B, 1, 3) + dists.reshape(B, N, 1) * ray_dirs

@@ -629,6 +629,59 @@ def make_f16():
     print("wrote", dst, os.listdir(dst))
 
 
+def make_f17():
+    """F17: the pointwise skinning seams and the D = 3 Broyden known-answer test of F2 / F1 on a subject whose skinning MLP
+    has wide-range activations (hidden weight-norm gains x 8, config.widen_skinning_): what the f16-pair engine of loop C has
+    to survive on weights it has not been tuned on."""
+    torch.set_num_threads(os.cpu_count())
+    scene = synthetic.SyntheticScene(seed=0)
+    model, cfg = build_reference_model("zju377_mono")
+    my_config.widen_skinning_(model, 8.0)
+    inputs = scene.make_inputs(64, 64, frame_idx=0)
+    ft = frame_tensors(model, inputs)
+    loc, sc, vol = ft["loc"], ft["sc_factor"], ft["vol_feat"]
+    cmin, cmax, center = inputs["coord_min"], inputs["coord_max"], inputs["center"]
+    bones = inputs["bone_transforms"]
+    skin = model.skinning_model
+    g = torch.Generator().manual_seed(1234)
+    P = 1024
+    x_norm = torch.rand(1, P, 3, generator=g) * 1.6 - 0.8
+    x_hat = RFU.unnormalize_canonical_points(x_norm, cmin, cmax, center)
+    with torch.no_grad():
+        dlog = skin.decode_w(x_norm, c=torch.empty(1, 0), forward=True)
+        w = RFU.query_weights(x_hat, loc, sc, cmin, cmax, center, skin, vol)
+        xbar, T = RFU.forward_skinning(x_hat, loc, sc, cmin, cmax, center, skin, vol, bones)
+        Pb = 256
+        xh_true = x_hat[:, :Pb]
+        tgt, _ = RFU.forward_skinning(xh_true, loc, sc, cmin, cmax, center, skin, vol, bones)
+        x0 = xh_true + torch.randn(1, Pb, 3, generator=g) * 0.01
+        x0[:, :8] += 0.5
+
+        def g3(x, mask=None):
+            xx = x.reshape(1, Pb, 3)
+            xb, Tt = RFU.forward_skinning(xx, loc, sc, cmin, cmax, center, skin, vol, bones, mask=mask)
+            err = (xb - tgt).flatten(0, 1)[mask].unsqueeze(-1)
+            return err, Tt.flatten(0, 1)[mask]
+
+        w0 = RFU.query_weights(x0, loc, sc, cmin, cmax, center, skin, vol)
+        T0 = torch.einsum("bpn,bnij->bpij", w0, bones)
+        Jinv0 = T0[:, :, :3, :3].inverse()
+        T_init = torch.eye(4).expand(Pb, 4, 4).clone() * 7.0
+        r3 = ref_broyden(g3, x0.reshape(Pb, 3, 1), T_init, Jinv0.flatten(0, 1))
+        # the largest hidden activation the reference's network produced on these points (for the record)
+        h = skin.skinning_decoder_fwd
+        act = x_norm[0]
+        amax = []
+        for k in range(4):
+            lin = getattr(h, "lin%d" % k)
+            act = torch.nn.functional.softplus(lin(act), beta=100)
+            amax.append(float(act.abs().max()))
+    save("f17_wide_skinning.npz", scale=8.0, x_norm=x_norm[0], x_hat=x_hat[0], deformer_logits=dlog[0], weights=w[0], x_bar=xbar[0],
+         T=T[0], tgt=tgt[0], x0=x0[0], T0=T_init, result=r3["result"][:, :, 0], transforms=r3["transforms"], diff=r3["diff"],
+         valid=r3["valid_ids"], hidden_absmax=np.array(amax, np.float32))
+    print("hidden |activation| max per layer:", amax, "converged", int(r3["valid_ids"].sum()), "of", Pb)
+
+
 F7_SET = (("zju377_mono", (64, 64), (64, 16, 16), 0), ("zju313", (64, 64), (64, 16, 16), 1), ("h36m", (48, 48), (32, 8, 8), 2),
           ("zju377_mono", (128, 128), (32, 8, 8), 5), ("h36m", (40, 40), (128, 32, 32), 3))
 
@@ -636,6 +689,8 @@ F7_SET = (("zju377_mono", (64, 64), (64, 16, 16), 0), ("zju313", (64, 64), (64, 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "f7c5":
         return make_f7(F7_SET[-1:])
+    if len(sys.argv) > 1 and sys.argv[1] == "f17":
+        return make_f17()
     if len(sys.argv) > 1 and sys.argv[1] == "f16":
         return make_f16()
     if len(sys.argv) > 1 and sys.argv[1] == "f15":

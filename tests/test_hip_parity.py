@@ -122,10 +122,14 @@ class engine:
             os.environ["ARAH_PRECISION"] = self.prev
 
 
-def _make_ctx(scene, eng):
-    from arah_release_amd import hip, renderer
+def _make_ctx(scene, eng, widen=None):
+    from arah_release_amd import config, hip, renderer
     dev = torch.device("cuda:0")
-    model, cfg = get_model("zju377_mono", dev)
+    if widen:
+        model, cfg = config.build_synthetic_model("zju377_mono", device=dev)   # a private copy: its skinning MLP is altered
+        config.widen_skinning_(model, widen)
+    else:
+        model, cfg = get_model("zju377_mono", dev)
     inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
     with torch.no_grad():
         dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
@@ -169,6 +173,30 @@ def test_sdf_eval(ctx, ctx_fp32, eng):
         s, _, gr = hip.sdf_eval(ctx["frame"], ctx["ws"], T(g["x_norm"][:n]), want_grad=True)
         np.testing.assert_array_equal(s.cpu().numpy(), sdf.cpu().numpy()[:n])
         np.testing.assert_array_equal(gr.cpu().numpy(), grad.cpu().numpy()[:n])
+
+
+@gpu
+@pytest.mark.parametrize("eng", ENGINES)
+def test_wide_range_skinning_network(scene, eng):
+    """Fixture F17: the reference on a subject whose skinning MLP has hidden activations up to ~3000 (weight-norm gains x 8)
+    -- 4e5 in the z units the split engine's loop C computes in, far outside the f16 range.  The per-frame probe must scale
+    the wide layers down (the SCALED instance of k_canon_wave runs), the solver must still find the reference's roots, and the
+    range counter must stay at zero; the exact engine takes the same subject as it is."""
+    g = golden("f17_wide_skinning.npz")
+    assert float(g["hidden_absmax"].max()) > 1000.0
+    c = _make_ctx(scene, eng, widen=float(g["scale"]))
+    hip = c["hip"]
+    w, xb, Tm = hip.skin_lbs(c["frame"], c["ws"], T(g["x_hat"]))
+    np.testing.assert_allclose(w.cpu().numpy(), g["weights"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(xb.cpu().numpy(), g["x_bar"], rtol=2e-4, atol=2e-5)
+    c["ws"].reset_counters()
+    x, Tm, err, ok = hip.broyden3_lbs(c["frame"], c["ws"], T(g["tgt"]), T(g["x0"]), T(g["T0"]))
+    ok = ok.cpu().numpy()
+    valid = g["valid"]
+    assert (ok == valid).mean() >= 0.99
+    both = ok & valid
+    assert_rows_close(x.cpu().numpy()[both], g["result"][both], atol=5e-5, frac=0.98)
+    assert c["ws"].counters()["n_split_nonfinite"] == 0
 
 
 @gpu
