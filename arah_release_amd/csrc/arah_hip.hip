@@ -1026,9 +1026,12 @@ __global__ __launch_bounds__(kThreads, (GRAD || SPLIT) ? 2 : 4) void k_sdf_eval(
                 // lattice point id = (ix * N + iy) * N + iz of [-1, 1]^3, coordinates as sdf_meshing.py:26-38 forms them
                 const float vs = (float)(2.0 / (double)(grid_n - 1));   // voxel_size is a Python float, rounded once (sdf_meshing.py:21)
                 const int iz = id % grid_n, iy = (id / grid_n) % grid_n, ix = id / (grid_n * grid_n);
-                // product and sum rounded separately, like the two tensor operations of the reference (no fma contraction)
-                x = f32x4{__fadd_rn(__fmul_rn((float)ix, vs), -1.0f), __fadd_rn(__fmul_rn((float)iy, vs), -1.0f),
-                          __fadd_rn(__fmul_rn((float)iz, vs), -1.0f), 0.f};
+                // product and sum rounded separately, like the two tensor operations of the reference.  (__fmul_rn / __fadd_rn are
+                // plain * and + to hipcc, which contracts them into one fma under its default -ffp-contract=fast: the asm pins
+                // the rounded product.  Fixture F15 holds the reference's own coordinates: test_sdf_grid_is_the_references_lattice.)
+                float px = (float)ix * vs, py = (float)iy * vs, pz = (float)iz * vs;
+                asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+                x = f32x4{px + -1.0f, py + -1.0f, pz + -1.0f, 0.f};
             } else if (id >= 0) {
                 x = f32x4{x_norm[(size_t)id * 3], x_norm[(size_t)id * 3 + 1], x_norm[(size_t)id * 3 + 2], 0.f};
             }
@@ -2067,8 +2070,17 @@ __global__ __launch_bounds__(kThreads, NT > 4 ? 2 : 4) void k_density(FrameDev f
             reinterpret_cast<f32x4*>(xin)[tid] = x;
         }
         __syncthreads();
-        f32x4 dlast[kSdfMT][NT];
-        sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        if constexpr (SPLIT && NT == 8) {
+#ifndef ARAH_DENSITY_NO_PP
+            sdf_trunk_pp<4>(fr.sdf, xin, actA, kSdfLd, wave, lane);   // the two 64-point halves a phase apart
+#else
+            f32x4 dlast[kSdfMT][NT];
+            sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+#endif
+        } else {
+            f32x4 dlast[kSdfMT][NT];
+            sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        }
         sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid, TW);
         __syncthreads();
         if (tid == 0) {
@@ -2523,12 +2535,10 @@ int setup_attributes() {
     allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
     allow_lds(k_joint_iter<false, false>, kLdsJoint);
     allow_lds(k_joint_iter<false, true>, kLdsSplitSolo);
-    allow_lds((k_trace_finish<true, true>), kLdsTraceFinish);
-    allow_lds((k_trace_finish<true, false>), kLdsTraceFinish);
-    allow_lds((k_trace_finish<false, false>), kLdsTraceFinish);
-    allow_lds((k_joint_finish<true, true>), kLdsJointFinish);
-    allow_lds((k_joint_finish<true, false>), kLdsJointFinish);
-    allow_lds((k_joint_finish<false, false>), kLdsJointFinish);
+    allow_lds(k_trace_finish<true>, kLdsTraceFinish);
+    allow_lds(k_trace_finish<false>, kLdsTraceFinish);
+    allow_lds(k_joint_finish<true>, kLdsJointFinish);
+    allow_lds(k_joint_finish<false>, kLdsJointFinish);
     allow_lds(k_shade<false, false>, lds_shade<false>());
     allow_lds(k_shade<false, true>, lds_shade<false>());
     allow_lds(k_shade<true, false>, lds_shade<true>());
@@ -2613,8 +2623,7 @@ FrameLayout frame_layout(int col_mode) {
     L.sdf_bias = take(6 * 256);
     L.sdf_freq = take(6 * 256);
     L.sdf_phase = take(6 * 256);
-    for (int i = 0; i < 5; ++i) L.sdf_wps[i] = take(256 * 256);   // hi + lo halves = 4 bytes per weight; CONTIGUOUS, kSdfSplitLayerBytes
-                                                                  // apart (sdf_trunk_tile16 addresses them through one descriptor)
+    for (int i = 0; i < 5; ++i) L.sdf_wps[i] = take(256 * 256);   // hi + lo halves = 4 bytes per weight
     L.sdf_fw = take(6 * 256);
     L.sdf_pw = take(6 * 256);
     L.sdf_fws = take(6 * 256);
@@ -2709,8 +2718,6 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     if (nets->precision != ARAH_PRECISION_SPLIT_F16 && nets->precision != ARAH_PRECISION_FP32) return ARAH_E_BADARG;
     const FrameLayout L = frame_layout(nets->col_mode);
     if (frame_bytes < L.bytes) return ARAH_E_WORKSPACE;
-    for (int i = 0; i < 4; ++i)
-        if (L.sdf_wps[i + 1] - L.sdf_wps[i] != (size_t)kSdfSplitLayerBytes) return ARAH_E_SHAPE;   // layout contract of sdf_trunk_tile16
     if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     char* base = reinterpret_cast<char*>(frame_buf);
@@ -3144,14 +3151,8 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
     if (bulk <= kBroydenSteps) {
         const int* lin = (bulk & 1) ? w.listB : w.listA;
         const int gf = min(4 * num_cus(), max(1, (n + kFinTile - 1) / kFinTile));
-        static const bool fast = env_int("ARAH_FINISH_FAST", 0) != 0;   // the latency-arranged trunk (one workgroup per CU)
-        if (fd.split && fast)
-            hipLaunchKernelGGL((k_joint_finish<true, true>), dim3(gf), dim3(kThreads), kLdsJointFinish, s, fd, st, rs, lin,
-                               (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk, &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
-        else
-            LAUNCH_ENGINE(fd.split, (k_joint_finish<true, false>), (k_joint_finish<false, false>), dim3(gf), dim3(kThreads),
-                          kLdsJointFinish, s, fd, st, rs, lin, (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk,
-                          &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
+        LAUNCH_ENGINE(fd.split, k_joint_finish<true>, k_joint_finish<false>, dim3(gf), dim3(kThreads), kLdsJointFinish, s, fd,
+                      st, rs, lin, (const int*)&cntB[bulk], kBroydenSteps + 1 - bulk, &w.ctr->n_skin_fwd, &w.ctr->n_sdf_fwd);
     }
 }
 
@@ -3170,9 +3171,9 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
                        w.listA, &cntA[0]);
     TraceState ts{w.t, w.far, w.xcur, w.diverged};
     const int gm = grid_for(n, kTile);
-    // the first steps as launches over the compacted list, the rest in the finisher (ARAH_TRACE_BULK_STEPS >= 50: round 2's
-    // schedule, every step its own launches)
-    static const int bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 12)));
+    // every step as launches over the compacted list; ARAH_TRACE_BULK_STEPS = k < 50 hands the list to the resident finisher
+    // after k steps (measured slower: finish.hpp)
+    static const int bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 50)));
     for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
@@ -3184,14 +3185,9 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     if (bulk < kSphereIters) {
         const int* lin = (bulk & 1) ? w.listB : w.listA;
         const int gf = min(4 * num_cus(), max(1, (n + kFinTile - 1) / kFinTile));
-        static const bool fast = env_int("ARAH_FINISH_FAST", 0) != 0;
-        if (fd.split && fast)
-            hipLaunchKernelGGL((k_trace_finish<true, true>), dim3(gf), dim3(kThreads), kLdsTraceFinish, s, fd, knn_of(fd), rs, ts,
-                               w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk], kSphereIters - bulk, &w.ctr->n_knn, &w.ctr->n_sdf_fwd);
-        else
-            LAUNCH_ENGINE(fd.split, (k_trace_finish<true, false>), (k_trace_finish<false, false>), dim3(gf), dim3(kThreads),
-                          kLdsTraceFinish, s, fd, knn_of(fd), rs, ts, w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk],
-                          kSphereIters - bulk, &w.ctr->n_knn, &w.ctr->n_sdf_fwd);
+        LAUNCH_ENGINE(fd.split, k_trace_finish<true>, k_trace_finish<false>, dim3(gf), dim3(kThreads), kLdsTraceFinish, s, fd,
+                      knn_of(fd), rs, ts, w.Tcur, w.nn_idx, lin, (const int*)&cntA[bulk], kSphereIters - bulk, &w.ctr->n_knn,
+                      &w.ctr->n_sdf_fwd);
     }
     // joint root find on the non-diverged rays; best-iterate arrays: x -> xbest_ray, depth -> zbest_ray, T -> T (output)
     hipLaunchKernelGGL(k_joint_select, dim3(gb), dim3(256), 0, s, fd, n, (const float*)w.xcur, (const float*)w.Tcur,

@@ -1,12 +1,16 @@
 // finish.hpp -- resident finishers of loops A and B (RT:174-241, RFU:365-484).
 //
 // Included by arah_hip.hip inside its anonymous namespace.  Loops A and B run as one launch per iteration over
-// compacted lists (k_nearest_* + k_sdf_march, k_joint_iter): fine while the lists are wide, but after a dozen
+// compacted lists (k_nearest_* + k_sdf_march, k_joint_iter): fine while the lists are wide, but after a few
 // iterations a few thousand rays are left and every further iteration is the latency of two or three launches on a
-// nearly empty machine -- 37 + 45 iterations of 50 / 32 us in a 512 x 512 frame.  The finishers take over there: a
-// workgroup adopts a 16-ray tile of the list and runs its rays to the end of the loop without leaving the kernel
-// (one-wave-per-query nearest vertex, 16-point MLP tiles, the same device functions in the same order as the
-// per-iteration kernels: results are bit-identical per ray).  A frame is then ~45 launches instead of ~230.
+// nearly empty machine -- 37 + 47 iterations of 52 / 32 us in a 512 x 512 frame.  A finisher takes over there: a
+// workgroup adopts a 16-ray tile of the list and runs its rays to the end of the loop without leaving the kernel (the
+// same device functions in the same order as the per-iteration kernels: results are bit-identical per ray).
+// Measured on the MI355X (profiles/r03_*): the loop-B finisher replaces 48 launches (1.5 ms) by one of 1.36 ms and is
+// the default after three wide iterations.  The loop-A finisher is NOT: its step is bounded by the exact nearest-vertex
+// search of the straggler rays (25 us per one-wave-per-query search, measured in both forms), which the per-step
+// kernel runs for all rays at once while a tile's wave runs two of them back to back -- 95 us per step against 52
+// (3.6 ms against 1.9).  It stays available (ARAH_TRACE_BULK_STEPS < 50) for the day the search gets cheaper.
 #pragma once
 
 constexpr int kFinTile = 16;
@@ -14,8 +18,8 @@ constexpr size_t kLdsTraceFinish = (kFinTile * 4 * 2 + kFinTile * 16 + 24 * 16 +
 constexpr size_t kLdsJointFinish = (kFinTile * 4 * 3 + 24 * 16 + kFinTile * 2 + kFinTile * kLogitLd + 32) * 4 + (size_t)kFinTile * kSdfLd * 4;
 
 // ---- loop A: the remaining sphere-tracing steps of the rays in list[0 .. *count)
-template <bool SPLIT, bool FAST>
-__global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_trace_finish(FrameDev fr, KnnData kd, RaySet rs, TraceState st, float* Tcur,
+template <bool SPLIT>
+__global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnData kd, RaySet rs, TraceState st, float* Tcur,
                                                             int* nn_idx, const int* list, const int* count, int steps_left,
                                                             unsigned long long* ctr_knn, unsigned long long* ctr_fwd) {
     const BodyConst bc = load_bc(fr);
@@ -99,12 +103,8 @@ __global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_trace_finish(FrameDe
                 }
             }
             __syncthreads();
-            if constexpr (SPLIT && FAST) {
-                sdf_trunk_tile16(fr.sdf, xin, actA, kSdfLd, wave, lane);
-            } else {
-                f32x4 dlast[kSdfMT][1];
-                sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
-            }
+            f32x4 dlast[kSdfMT][1];
+            sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
             sdf_head<SPLIT>(fr.sdf, actA, kSdfLd, outv, 4, tid, kFinTile);
             __syncthreads();
             if (tid < kFinTile) {
@@ -144,8 +144,8 @@ __global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_trace_finish(FrameDe
 }
 
 // ---- loop B: the remaining Broyden iterations (none of them the first) of the rays in list[0 .. *count)
-template <bool SPLIT, bool FAST>
-__global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_joint_finish(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
+template <bool SPLIT>
+__global__ __launch_bounds__(kThreads, 4) void k_joint_finish(FrameDev fr, Broyden4State st, RaySet rs, const int* list,
                                                             const int* count, int iters_left, unsigned long long* ctr_skin,
                                                             unsigned long long* ctr_sdf) {
     const BodyConst bc = load_bc(fr);
@@ -188,12 +188,8 @@ __global__ __launch_bounds__(kThreads, FAST ? 2 : 4) void k_joint_finish(FrameDe
             __syncthreads();
             if (!*s_live) break;
             skin_mlp<1>(fr.skin, xin, act, logits, wave, lane);
-            if constexpr (SPLIT && FAST) {
-                sdf_trunk_tile16(fr.sdf, xin, act, kSdfLd, wave, lane);
-            } else {
-                f32x4 dlast[kSdfMT][1];
-                sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
-            }
+            f32x4 dlast[kSdfMT][1];
+            sdf_trunk<false, 1, SPLIT>(fr.sdf, xin, act, kSdfLd, nullptr, dlast, wave, lane);
             sdf_head<SPLIT>(fr.sdf, act, kSdfLd, outv, 4, tid, TW);
             __syncthreads();
             if (tid < TW) {

@@ -404,7 +404,6 @@ struct SdfNet {
     const f16x8* wps[5];   // split-packed 256x256
 };
 
-constexpr int kSdfSplitLayerBytes = 256 * 256 * 4;   // hi + lo halves of one 256 x 256 layer; SdfNet::wps[k] = wps[0] + k * this
 constexpr int kSdfLd = 264;   // 256 + 8: rows 8 dwords apart mod 64 (see split_slot)
 constexpr int kSdfMT = 2;     // 16 M-tiles / 8 waves
 
@@ -596,35 +595,27 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
     }
 }
 
-// The forward trunk of ONE 16-point tile on the split engine, arranged for latency (the resident finishers of loops A
-// and B, csrc/finish.hpp, run it hundreds of times back to back with nothing else on the CU).  sdf_trunk<false, 1, true>
-// streams a layer's weight fragments one 32-chunk ahead of six MFMAs: at this tile width every chunk waits for L2.  Here
-// a wave requests its whole slice of the NEXT layer (32 fragments, 128 registers) as soon as the MFMAs of the current
-// one have issued -- the request travels under the epilogue and the two barriers -- and takes all B fragments of a layer
-// from LDS in one batch.  Same MFMA order per accumulator and the same epilogue as sdf_trunk: bit-identical results.
-__device__ __forceinline__ void sdf_trunk_tile16(const SdfNet& net, const float* xin, float* act, int ld, int wave, int lane) {
+// Forward trunk of a tile of 2 x NTH x 16 points on the split engine with the two halves of the tile a phase apart: while
+// the MFMAs of one half's layer issue, the FiLM-sine epilogue of the other half's previous GEMM rides between them (one
+// 16 x 16 accumulator group per 32-chunk), so that matrix pipe and vector ALU work in the same phase instead of taking
+// turns between workgroup barriers.  One barrier per phase, two phases per layer -- the barrier count of sdf_trunk.
+//   phase (H0, k): GEMM of half 0, layer k   ||  epilogue of half 1, layer k - 1  (writes half 1's rows)
+//   phase (H1, k): GEMM of half 1, layer k   ||  epilogue of half 0, layer k      (writes half 0's rows)
+// A barrier separates a half's GEMM (which reads its rows) from the epilogue that rewrites them in place, and the
+// epilogue from the next GEMM that reads them.  Same MFMA order per accumulator and the same epilogue arithmetic as
+// sdf_trunk: bit-identical results (the density pass and the shading pass must agree on every sample).
+template <typename Tp, Tp V>
+struct PpConst {
+    static constexpr Tp value = V;
+};
+template <int NTH>
+__device__ __forceinline__ void sdf_trunk_pp(const SdfNet& net, const float* xin, float* act, int ld, int wave, int lane) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
     constexpr float amp = kActScale;
-    f16x8 ah[kSdfMT][8], al[kSdfMT][8];
-    // one buffer descriptor over the five split-packed layers (contiguous in the frame buffer, kSdfSplitLayerBytes apart):
-    // the lane's slot in the vector offset, layer and fragment in the scalar offset -- no address registers per fragment
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    const auto wsrd = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16x8*>(net.wps[0]), 0, 5 * kSdfSplitLayerBytes, 0x00020000);
-    const int voff = (mt0 * 8 * 2 * 64 + lane) * 16;
-    auto request = [&](int layer) {   // layer = 1..5: fragments of net.wps[layer - 1]
-        const int lbase = (layer - 1) * kSdfSplitLayerBytes;
-#pragma unroll
-        for (int m = 0; m < kSdfMT; ++m)
-#pragma unroll
-            for (int kc = 0; kc < 8; ++kc) {
-                ah[m][kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, voff, lbase + ((m * 8 + kc) * 2 + 0) * 1024, 0));
-                al[m][kc] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, voff, lbase + ((m * 8 + kc) * 2 + 1) * 1024, 0));
-            }
-    };
-    request(1);
-    {   // layer 1: K = 3 on the vector ALU (as sdf_trunk)
-        const f32x4 x = *reinterpret_cast<const f32x4*>(xin + j * 4);
+    constexpr int NT = 2 * NTH;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    {   // layer 1: K = 3 on the vector ALU, both halves (as sdf_trunk)
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
@@ -633,59 +624,117 @@ __device__ __forceinline__ void sdf_trunk_tile16(const SdfNet& net, const float*
             for (int r = 0; r < 4; ++r) w[r] = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
             const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
             const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
-            f32x4 v, h, d;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], w[r][0] * x[0]));
-            no_pack(v);
-            film_sine<false>(v, fw, pw, fw, amp, h, d);
-            store_split4(act, ld, 512, j, ch0, h);
+            for (int n = 0; n < NT; ++n) {
+                const f32x4 x = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
+                f32x4 v, h, d;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(w[r][2], x[2], fmaf(w[r][1], x[1], w[r][0] * x[0]));
+                no_pack(v);
+                film_sine<false>(v, fw, pw, zero4, amp, h, d);
+                store_split4(act, ld, 512, n * 16 + j, ch0, h);
+            }
         }
     }
     ARAH_SYNC();
-    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
+    f32x4 acc[2][kSdfMT][NTH];   // [half][m][n]
+    // one phase: acc[hg] = W_k * rows of half hg; EPI: the epilogue of layer ke on acc[he] -> rows of half he
+    auto phase = [&](auto hgc, int k, auto epic, int ke) {
+        constexpr int hg = decltype(hgc)::value, he = 1 - hg;
+        constexpr bool EPI = decltype(epic)::value;
+        const f16x8* wp = net.wps[k - 1];
+        const unsigned aoff = (unsigned)(mt0 * 8 * 2 * 64 + lane) * 16u;
+        auto lda = [&](int idx) { return ld_frag<f16x8>(wp, aoff, idx * 1024); };
+        const char* bptr = reinterpret_cast<const char*>(act) + (hg * NTH * 16 + j) * ld * 4 + split_slot(j, g) * 16;
+        f32x4 fwm[kSdfMT], pwm[kSdfMT];
+        if constexpr (EPI) {
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m) {
+                const int ch0 = (mt0 + m) * 16 + 4 * g;
+                fwm[m] = *reinterpret_cast<const f32x4*>(net.fws + ke * 256 + ch0);
+                pwm[m] = *reinterpret_cast<const f32x4*>(net.pw + ke * 256 + ch0);
+            }
+        }
+        f16x8 ah[kSdfMT], al[kSdfMT], ahn[kSdfMT], aln[kSdfMT];
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            ah[m] = lda((m * 8) * 2 + 0);
+            al[m] = lda((m * 8) * 2 + 1);
+        }
+#pragma unroll
+        for (int kc = 0; kc < 8; ++kc) {
+            const int kn = kc + 1 < 8 ? kc + 1 : kc;
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m) {
+                ahn[m] = lda((m * 8 + kn) * 2 + 0);
+                aln[m] = lda((m * 8 + kn) * 2 + 1);
+            }
+            f16x8 bh[NTH], bl[NTH];
+#pragma unroll
+            for (int n = 0; n < NTH; ++n) {
+                bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
+                bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + 512 + kc * 64);
+            }
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTH; ++n)
+                    acc[hg][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], kc == 0 ? zero4 : acc[hg][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTH; ++n)
+                    acc[hg][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[hg][m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTH; ++n)
+                    acc[hg][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[hg][m][n], 0, 0, 0);
+            if constexpr (EPI) {   // accumulator group kc of the other half: kSdfMT * NTH == 8 groups, one per chunk
+                static_assert(kSdfMT * NTH == 8, "one epilogue group per 32-chunk");
+                const int m = kc / NTH, n = kc % NTH;
+                f32x4 h, d;
+                film_sine<false>(acc[he][m][n], fwm[m], pwm[m], zero4, amp, h, d);
+                store_split4(act, ld, 512, (he * NTH + n) * 16 + j, (mt0 + m) * 16 + 4 * g, h);
+            }
+#pragma unroll
+            for (int m = 0; m < kSdfMT; ++m) {
+                ah[m] = ahn[m];
+                al[m] = aln[m];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // a chunk's requests stay in their chunk (registers)
+        }
+    };
+    typedef PpConst<int, 0> H0_;
+    typedef PpConst<int, 1> H1_;
+    typedef PpConst<bool, true> T_;
+    typedef PpConst<bool, false> F_;
+    phase(H0_{}, 1, F_{}, 0);
+    ARAH_SYNC();
 #pragma unroll 1
     for (int k = 1; k < 6; ++k) {
-        f32x4 acc[kSdfMT];
-#pragma unroll
-        for (int m = 0; m < kSdfMT; ++m) zero_acc(acc[m]);
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {   // B fragments in two batches of four chunks (registers)
-            f16x8 bh[4], bl[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                bh[c] = *reinterpret_cast<const f16x8*>(bptr + (half * 4 + c) * 64);
-                bl[c] = *reinterpret_cast<const f16x8*>(bptr + 512 + (half * 4 + c) * 64);
-            }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int kc = half * 4 + c;
-#pragma unroll
-                for (int m = 0; m < kSdfMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m][kc], bh[c], acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < kSdfMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kc], bl[c], acc[m], 0, 0, 0);
-#pragma unroll
-                for (int m = 0; m < kSdfMT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m][kc], bh[c], acc[m], 0, 0, 0);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);   // the requests below reuse the registers of the fragments just consumed
-        if (k < 5) request(k + 1);
-        f32x4 fwm[kSdfMT], pwm[kSdfMT];
-#pragma unroll
-        for (int m = 0; m < kSdfMT; ++m) {
-            const int ch0 = (mt0 + m) * 16 + 4 * g;
-            fwm[m] = *reinterpret_cast<const f32x4*>(net.fws + k * 256 + ch0);
-            pwm[m] = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
-        }
-        ARAH_SYNC();   // everyone is done reading the layer input
-#pragma unroll
-        for (int m = 0; m < kSdfMT; ++m) {
-            const int ch0 = (mt0 + m) * 16 + 4 * g;
-            f32x4 h, d;
-            film_sine<false>(acc[m], fwm[m], pwm[m], fwm[m], amp, h, d);
-            store_split4(act, ld, 512, j, ch0, h);
-        }
+        phase(H1_{}, k, T_{}, k);          // GEMM (H1, k) || epilogue (H0, k)
         ARAH_SYNC();
+        if (k < 5) {
+            phase(H0_{}, k + 1, T_{}, k);  // GEMM (H0, k + 1) || epilogue (H1, k)
+            ARAH_SYNC();
+        }
     }
+    {   // epilogue (H1, 5)
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+            const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fws + 5 * 256 + ch0);
+            const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + 5 * 256 + ch0);
+#pragma unroll
+            for (int n = 0; n < NTH; ++n) {
+                f32x4 h, d;
+                film_sine<false>(acc[1][m][n], fw, pw, zero4, amp, h, d);
+                store_split4(act, ld, 512, (NTH + n) * 16 + j, ch0, h);
+            }
+        }
+    }
+    ARAH_SYNC();
 }
 
 // split planes -> fp32 in place for the first n_pts rows (through registers: the fp32 row overlays both planes)
