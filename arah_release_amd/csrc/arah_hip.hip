@@ -2071,8 +2071,11 @@ __global__ __launch_bounds__(kThreads, NT > 4 ? 2 : 4) void k_density(FrameDev f
         }
         __syncthreads();
         if constexpr (SPLIT && NT == 8) {
-#ifndef ARAH_DENSITY_NO_PP
-            sdf_trunk_pp<4>(fr.sdf, xin, actA, kSdfLd, wave, lane);   // the two 64-point halves a phase apart
+#ifdef ARAH_DENSITY_PP
+            // the two 64-point halves a phase apart (mlp.hpp: sdf_trunk_pp).  Measured on the MI355X, same box, alternating
+            // runs: 12.94-12.98 ms per launch against 12.91-13.08 without -- the pass is not bound by the serialisation of
+            // GEMM and epilogue phases; the plain trunk stays the default, this is the reproducer
+            sdf_trunk_pp<4>(fr.sdf, xin, actA, kSdfLd, wave, lane);
 #else
             f32x4 dlast[kSdfMT][NT];
             sdf_trunk<false, NT, SPLIT>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
@@ -3442,6 +3445,59 @@ int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int
     if (n_rows == 0) return ARAH_OK;
     hipLaunchKernelGGL(k_gram_skinny, dim3(arah_gram_skinny_blocks(n_rows)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), a, lda, m, b, ldb, n, n_rows, partial);
+    return check_launch();
+}
+
+// ---- the wide output layers of the SDF hypernetwork (hyperlayers.py:418-465) ----------------------------
+// y[r] = W[r, :] . x + b0[r] (+ b1[r]): a 256 -> 65 792 linear layer per emitted 256 x 256 SDF layer, 67 MB of weights that
+// are read once per frame -- 337 MB for the five hidden layers, a pure HBM stream.  The GEMM library runs these batch-1
+// products at ~0.9 TB/s (76 us each, rocprofv3); here a wave owns rows: a row of 256 floats is ONE coalesced 1 KiB load
+// (float4 per lane), eight rows are in flight per wave, the row sums go through six xor-shuffles.
+constexpr int kGemvRows = 8;
+__global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ W, int n_rows, int n_cols,
+                                                    const float* __restrict__ x, const float* __restrict__ b0,
+                                                    const float* __restrict__ b1, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+    const int n4 = n_cols >> 2;                       // float4 per row
+    for (int r0 = wave * kGemvRows; r0 < n_rows; r0 += n_waves * kGemvRows) {
+        float acc[kGemvRows];
+#pragma unroll
+        for (int u = 0; u < kGemvRows; ++u) acc[u] = 0.f;
+        for (int c = lane; c < n4; c += 64) {
+            const f32x4 xv = reinterpret_cast<const f32x4*>(x)[c];
+            f32x4 wv[kGemvRows];
+#pragma unroll
+            for (int u = 0; u < kGemvRows; ++u) {
+                const int r = min(r0 + u, n_rows - 1);
+                wv[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(W + (size_t)r * n_cols) + c);
+            }
+#pragma unroll
+            for (int u = 0; u < kGemvRows; ++u)
+                acc[u] = fmaf(wv[u][3], xv[3], fmaf(wv[u][2], xv[2], fmaf(wv[u][1], xv[1], fmaf(wv[u][0], xv[0], acc[u]))));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < kGemvRows; ++u) acc[u] += __shfl_xor(acc[u], o);
+        if (lane < kGemvRows && r0 + lane < n_rows) {
+            float v = acc[0];
+#pragma unroll
+            for (int u = 1; u < kGemvRows; ++u) v = lane == u ? acc[u] : v;
+            const int r = r0 + lane;
+            y[r] = v + (b0 ? b0[r] : 0.f) + (b1 ? b1[r] : 0.f);
+        }
+    }
+}
+
+int arah_gemv_rows(const float* W, int32_t n_rows, int32_t n_cols, const float* x, const float* b0, const float* b1,
+                   float* y, void* stream) {
+    if (!W || !x || !y || n_rows < 1 || n_cols < 4 || (n_cols & 3)) return ARAH_E_BADARG;
+    if ((reinterpret_cast<uintptr_t>(W) | reinterpret_cast<uintptr_t>(x)) & 15) return ARAH_E_BADARG;
+    long long g = ((long long)n_rows + 4 * kGemvRows - 1) / (4 * kGemvRows);   // four waves per workgroup
+    if (g > 8 * num_cus()) g = 8 * num_cus();
+    hipLaunchKernelGGL(k_gemv_rows, dim3((int)g), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), W, n_rows, n_cols, x,
+                       b0, b1, y);
     return check_launch();
 }
 

@@ -92,7 +92,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "ar
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
+           "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events", "arah_set_canon_events"]
 
 _lib = None
@@ -366,6 +366,22 @@ def sdf_grid(frame, ws, n_side=256):
     _check(lib.arah_sdf_grid(C.byref(frame.handle), C.c_int32(int(n_side)), _ptr(out), _ptr(buf), C.c_size_t(buf.numel()),
                              _stream()), "arah_sdf_grid")
     return out
+
+
+def gemv_rows(weight, x, b0=None, b1=None):
+    """y = weight @ x + b0 + b1 for ONE vector x (the wide output layers of the hypernetwork, an HBM stream of `weight`);
+    no autograd.  weight (R, C) fp32 contiguous, C % 4 == 0."""
+    require_gpu()
+    lib = load_library()
+    w, xv = weight.detach(), _f32(x).reshape(-1)
+    if not (w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2 and w.shape[1] == xv.numel() and w.shape[1] % 4 == 0):
+        raise ValueError("gemv_rows: weight (R, C) fp32 contiguous with C % 4 == 0 and x of C elements")
+    with _on_device(w.device):
+        y = torch.empty(w.shape[0], device=w.device)
+        _check(lib.arah_gemv_rows(_ptr(w), C.c_int32(w.shape[0]), C.c_int32(w.shape[1]), _ptr(xv),
+                                  _ptr(None if b0 is None else _f32(b0).reshape(-1)),
+                                  _ptr(None if b1 is None else _f32(b1).reshape(-1)), _ptr(y), _stream()), "arah_gemv_rows")
+    return y
 
 
 def rasterize(tri_uvz, height, width, z_near=1e-4):

@@ -22,6 +22,8 @@ hyperlayers.py:270-285,497-510) or only export folded weight tensors.
 The torch ``forward`` of the per-sample networks is kept because the training
 path differentiates through them with autograd.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -108,7 +110,16 @@ class HyperLinear(nn.Module):
         self.hypo_params = _HyperHead(hyper_in_ch, hyper_hidden_ch, in_ch * out_ch + out_ch)
 
     def emit(self, cond):
-        p = self.hypo_params(cond) + self.hypo_params_init
+        head = self.hypo_params.net
+        if (not torch.is_grad_enabled() and cond.is_cuda and cond.numel() == cond.shape[-1] and head[2].out_features >= 4096
+                and os.environ.get("ARAH_HYPER_GEMV", "1") != "0"):
+            # inference, one condition vector: the 256 -> in*out + out layer is a stream of its 67 MB weight matrix --
+            # the HBM-bound row kernel of the C ABI instead of a batch-1 GEMM (same sums up to their order)
+            from . import hip
+            h = head[1](head[0](cond))
+            p = hip.gemv_rows(head[2].weight, h, head[2].bias, self.hypo_params_init).reshape(*cond.shape[:-1], -1)
+        else:
+            p = self.hypo_params(cond) + self.hypo_params_init
         nw = self.in_ch * self.out_ch
         w = p[..., :nw].reshape(*p.shape[:-1], self.out_ch, self.in_ch)
         b = p[..., nw:nw + self.out_ch].reshape(*p.shape[:-1], 1, self.out_ch)

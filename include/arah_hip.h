@@ -278,6 +278,13 @@ int arah_shade_train_backward(const ArahFrame* h_frame, const ArahTrainIn* h_in,
  * a[p*lda + i] * b[p*ldb + j], i < m <= 4, j < n; blk < arah_gram_skinny_blocks(n_rows).  The caller sums over blk.
  * (The reference leaves these to autograd's matmul backward: IDR:336-361 through torch.autograd.) */
 int32_t arah_gram_skinny_blocks(int32_t n_rows);
+
+/* y[r] = W[r, :] . x + b0[r] + b1[r]: the batch-1 output layers of the SDF hypernetwork (hyperlayers.py:418-465, 256 ->
+ * in*out + out per emitted layer; im2mesh/metaavatar/models/siren_modules.py:244-300 calls them once per frame), an HBM
+ * stream of the weight matrix.  W [n_rows][n_cols] row-major, 16-byte aligned, n_cols a multiple of 4; b0 / b1 [n_rows]
+ * or NULL (bias of the layer, hypo_params_init).  Inference only (no gradient). */
+int arah_gemv_rows(const float* W, int32_t n_rows, int32_t n_cols, const float* x, const float* b0, const float* b1,
+                   float* y, void* stream);
 int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int32_t ldb, int32_t n, int32_t n_rows,
                      float* partial, void* stream);
 

@@ -786,6 +786,31 @@ def test_shade_samples_op_against_autograd(scene, name, ray_augm):
 
 
 @gpu
+def test_gemv_rows_against_torch():
+    """arah_gemv_rows (the hypernetwork's wide output layers at inference) against F.linear, odd row counts included; and
+    the emitted SDF layers of a model are the same through either path."""
+    from arah_release_amd import hip
+    dev = torch.device("cuda:0")
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for rows, cols in ((65792, 256), (1024, 256), (257, 256), (7, 144)):
+        W = torch.randn(rows, cols, device=dev, generator=gen) * 0.05
+        x = torch.randn(cols, device=dev, generator=gen)
+        b0, b1 = torch.randn(rows, device=dev, generator=gen), torch.randn(rows, device=dev, generator=gen)
+        ref = (W.double() @ x.double() + b0.double() + b1.double()).float()
+        np.testing.assert_allclose(hip.gemv_rows(W, x, b0, b1).cpu().numpy(), ref.cpu().numpy(), rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(hip.gemv_rows(W, x).cpu().numpy(), (W.double() @ x.double()).float().cpu().numpy(), rtol=2e-6, atol=2e-6)
+    model, cfg = get_model("zju377_mono", dev)
+    layer = model.sdf_decoder.net.layers[2].hyper_linear
+    cond = torch.randn(1, 144, device=dev, generator=gen)
+    with torch.no_grad():
+        w_fast, b_fast = layer.emit(cond)
+    with torch.enable_grad():
+        w_ref, b_ref = layer.emit(cond)
+    np.testing.assert_allclose(w_fast.cpu().numpy(), w_ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(b_fast.cpu().numpy(), b_ref.detach().cpu().numpy(), rtol=1e-5, atol=1e-7)
+
+
+@gpu
 def test_gram_skinny_and_split_k_gram():
     """Weight-gradient products of the training step: the one-pass skinny kernel and the batched split-K product
     against a float64 matmul (column slices of wider streams, ragged row counts)."""
