@@ -30,7 +30,11 @@
 #include "pointwise.hpp"
 
 #ifndef ARAH_SYNC
+#ifdef ARAH_ABL_NO_BARRIER   // timing ablation: no workgroup barriers inside the MLPs (results are wrong)
+#define ARAH_SYNC() __builtin_amdgcn_wave_barrier()
+#else
 #define ARAH_SYNC() __syncthreads()
+#endif
 #endif
 
 namespace arah {
@@ -250,20 +254,34 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
             ah[m] = lda(((m * KC32) * 2 + 0));
             al[m] = lda(((m * KC32) * 2 + 1));
         }
+        // Timing ablations of the forward trunks (tools/ablate_density.sh; results are WRONG with any of them defined):
+        //   ARAH_ABL_A_FIXED  the A fragments of chunk 0 serve every chunk (no L2 fragment stream)
+        //   ARAH_ABL_B_FIXED  the B fragments of chunk 0 serve every chunk (no LDS fragment reads)
+        //   ARAH_ABL_ONE_MFMA only the hi x hi product (a third of the matrix-pipe work)
 #pragma unroll 1
         for (int kc = 0; kc < KC32; ++kc) {
+#ifdef ARAH_ABL_A_FIXED
+            const int kn = 0;
+#else
             const int kn = kc + 1 < KC32 ? kc + 1 : kc;
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 ahn[m] = lda(((m * KC32 + kn) * 2 + 0));
                 aln[m] = lda(((m * KC32 + kn) * 2 + 1));
             }
             f16x8 bh[NT], bl[NT];
+#ifdef ARAH_ABL_B_FIXED
+            const int kb = 0;
+#else
+            const int kb = kc;
+#endif
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
-                bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
-                bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + kc * 64);
+                bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kb * 64);
+                bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off + kb * 64);
             }
+#ifndef ARAH_ABL_ONE_MFMA
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -274,6 +292,7 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#endif
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -582,7 +601,12 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             for (int n = 0; n < NT; ++n) {
                 f32x4 h, d;
                 if constexpr (TAP::on) tap.aslab[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = acc[m][n];
+#ifdef ARAH_ABL_NO_EPI   //   ARAH_ABL_NO_EPI   no FiLM sine: the accumulators are stored as they are
+                h = acc[m][n] * 1e-6f;
+                d = zero4;
+#else
                 film_sine<GRAD>(acc[m][n], fw, pw, f, amp, h, d);
+#endif
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
                 if (GRAD) {

@@ -1,0 +1,7 @@
+#!/bin/bash
+# the ablation ladder of the forward SDF trunk on one box -> stdout (profiles/r03_trunk_ablation.txt)
+B=tools/ubench/bin
+python tools/ablate_trunk.py
+for v in NO_EPI NO_BARRIER A_FIXED B_FIXED AB_FIXED ONE_MFMA ALL; do
+  ARAH_LIB_PATH=$B/libarah_abl_$v.so python tools/ablate_trunk.py
+done
