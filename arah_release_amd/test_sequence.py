@@ -24,6 +24,9 @@ def build_parser():
     p.add_argument("--start-frame", type=int, default=0, help="Frame index to start rendering.")
     p.add_argument("--end-frame", type=int, default=0, help="Frame index to stop rendering.")
     p.add_argument("--low-vram", action="store_true", help="Accepted for compatibility; the workspace is 1 GB per frame.")
+    p.add_argument("--multi-gpu", action="store_true", help="Accepted for compatibility (test.py:30): frames are sharded over "
+                                                            "the ranks of torch.distributed.run whenever WORLD_SIZE > 1.")
+    p.add_argument("--num-workers", type=int, default=4, help="Accepted for compatibility: items are composed on the GPU.")
     p.add_argument("--default-config", type=str, default="configs/default.yaml")
     p.add_argument("--body-models", type=str, default="body_models/misc", help="Directory of the SMPL model files.")
     return p

@@ -196,16 +196,22 @@ def main(argv=None, body=None, faces=None, log=print):
     if rank == 0:
         os.makedirs(out_dir, exist_ok=True)
     d = cfg["data"]
-    if d["dataset"] != "zju_mocap":
-        raise ValueError('Invalid dataset "%s" (this build trains on the capture format zju_mocap)' % d["dataset"])
-    body = body if body is not None else smpl.BodyModel.from_files("neutral", args.body_models)
-    dataset = data.TrainingDataset(
-        d["path"], subjects=d["train_split"], mode="train", img_size=(1024, 1024) if d.get("high_res") else (512, 512),
+    # im2mesh/config.py:141-250: the three capture formats and their image-size rules (training mode)
+    high_res = bool(d.get("high_res"))
+    kinds = {"zju_mocap": (data.TrainingDataset, (1024, 1024) if high_res else (512, 512)),
+             "h36m": (data.H36MDataset, (1002, 1000)),
+             "people_snapshot": (data.PeopleSnapshotDataset, (1080, 1080) if high_res else (540, 540))}
+    if d["dataset"] not in kinds:
+        raise ValueError('Invalid dataset "%s"' % d["dataset"])
+    cls, img_size = kinds[d["dataset"]]
+    dataset = cls(
+        d["path"], subjects=d["train_split"], mode="train", img_size=img_size,
         num_fg_samples=d["num_fg_samples"], num_bg_samples=d["num_bg_samples"], sampling_rate=d["train_subsampling_rate"],
         start_frame=d["train_start_frame"], end_frame=d["train_end_frame"], views=d["train_views"],
         off_surface_thr=d["off_surface_thr"], inside_thr=d["inside_thr"], box_margin=d["box_margin"], sampling=d["sampling"],
         sample_reg_surface=d["sample_reg_surface"], sample_inside=t_cfg.get("inside_weight", 0) > 0, erode_mask=d["erode_mask"],
         body=body, faces=faces, body_models=args.body_models)
+    body = dataset.body   # the subject's gendered body model (People-Snapshot), the neutral one otherwise
     torch.manual_seed(0)
     lm = config.get_model(cfg, dataset=dataset, mode="train", body_model=body).to(device)
     lm.train()
