@@ -11,7 +11,9 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from arah_release_amd import config, hip, renderer, synthetic  # noqa: E402
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 7_300_000
+density = "--density" in sys.argv          # time k_density (the product's pass, ARAH_DENSITY_TILE = 128 | 64) instead of k_sdf_eval
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 7_300_000
 dev = torch.device("cuda:0")
 model, cfg = config.build_synthetic_model("zju377_mono", device=dev)
 scene = synthetic.SyntheticScene(0)
@@ -26,6 +28,30 @@ with torch.no_grad():
                                  inputs["coord_min"], inputs["coord_max"], inputs["center"])
 ws = hip.Workspace(dev)
 x = torch.rand(n, 3, device=dev, generator=torch.Generator(device=dev).manual_seed(0)) * 2 - 1
+if density:
+    S = 64
+    nr = n // S
+    samp = hip.Sampling(dev, S, 16, 16)
+    dirs = torch.zeros(nr, 3, device=dev)
+    dirs[:, 2] = 1.0
+    z = torch.linspace(1.0, 2.0, S, device=dev).repeat(nr, 1).contiguous()
+    pts = x[:nr * S].reshape(nr, S, 3).contiguous()
+    Tm = torch.eye(4, device=dev).repeat(nr, S, 1, 1).contiguous()
+    mask = torch.ones(nr, S, dtype=torch.uint8, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ts = []
+    for it in range(6):
+        hip.set_density_events(e0, e1)
+        hip.shade_composite(frame, ws, samp, dirs, z, pts, Tm, mask)
+        torch.cuda.synchronize()
+        hip.set_density_events(None, None)
+        if it:
+            ts.append(e0.elapsed_time(e1))
+    ms = sorted(ts)[len(ts) // 2]
+    print("%-28s k_density tile %-3s %8.3f ms  %7.1f algorithmic TFLOP/s" % (
+        os.path.basename(os.environ.get("ARAH_LIB_PATH", "libarah_hip.so")), os.environ.get("ARAH_DENSITY_TILE", "128"), ms,
+        nr * S * 657408 / ms / 1e9))
+    sys.exit(0)
 hip.sdf_eval(frame, ws, x)
 torch.cuda.synchronize()
 ts = []
