@@ -254,6 +254,14 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
             ah[m] = lda(((m * KC32) * 2 + 0));
             al[m] = lda(((m * KC32) * 2 + 1));
         }
+#ifdef ARAH_A_AHEAD2   // the A fragments TWO chunks ahead (tuning variant, tools/ablate_trunk.sh)
+        f16x8 ah2[MT], al2[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ahn[m] = lda(((m * KC32 + (KC32 > 1 ? 1 : 0)) * 2 + 0));
+            aln[m] = lda(((m * KC32 + (KC32 > 1 ? 1 : 0)) * 2 + 1));
+        }
+#endif
         // Timing ablations of the forward trunks (tools/ablate_density.sh; results are WRONG with any of them defined):
         //   ARAH_ABL_A_FIXED  the A fragments of chunk 0 serve every chunk (no L2 fragment stream)
         //   ARAH_ABL_B_FIXED  the B fragments of chunk 0 serve every chunk (no LDS fragment reads)
@@ -265,11 +273,20 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
 #else
             const int kn = kc + 1 < KC32 ? kc + 1 : kc;
 #endif
+#ifdef ARAH_A_AHEAD2
+            const int k2 = kc + 2 < KC32 ? kc + 2 : KC32 - 1;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah2[m] = lda(((m * KC32 + k2) * 2 + 0));
+                al2[m] = lda(((m * KC32 + k2) * 2 + 1));
+            }
+#else
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 ahn[m] = lda(((m * KC32 + kn) * 2 + 0));
                 aln[m] = lda(((m * KC32 + kn) * 2 + 1));
             }
+#endif
             f16x8 bh[NT], bl[NT];
 #ifdef ARAH_ABL_B_FIXED
             const int kb = 0;
@@ -302,6 +319,10 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
             for (int m = 0; m < MT; ++m) {
                 ah[m] = ahn[m];
                 al[m] = aln[m];
+#ifdef ARAH_A_AHEAD2
+                ahn[m] = ah2[m];
+                aln[m] = al2[m];
+#endif
             }
         }
     }
