@@ -866,6 +866,97 @@ __device__ __forceinline__ int nearest_vertex_wave(const KnnData& kd, const Grid
     return bi;
 }
 
+// SIXTEEN LANES per query, four queries per wave: a cluster's 28 slots are two rounds of 16 lanes instead of one
+// round that leaves 36 of 64 lanes idle, a cell's candidate list is tested 16 spheres at a time, and the serial
+// tail of a query (blend + inverse, one lane) is paid once per four queries.  Same result as the serial walk and the
+// one-wave walk (exact nearest vertex, lowest index on ties).  Every lane of the group holds the query and returns
+// the answer; control flow is uniform per group, so the shuffles below only read lanes of the own group.
+__device__ __forceinline__ void group16_argmin(float& d2, int& idx) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float od = __shfl_xor(d2, o);
+        const int oi = __shfl_xor(idx, o);
+        if (od < d2 || (od == d2 && oi < idx)) {
+            d2 = od;
+            idx = oi;
+        }
+    }
+}
+
+__device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const GridInfo& g, V3 p, float best, int bi,
+                                                      int lane) {
+    const int sub = lane & 15, gbase = lane & 48;
+    const float fx = (p.x - g.origin[0]) * g.inv_h, fy = (p.y - g.origin[1]) * g.inv_h, fz = (p.z - g.origin[2]) * g.inv_h;
+    const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
+    int cnt = 255;
+    const unsigned char* cl = nullptr;
+    if (fx >= 0.f && fy >= 0.f && fz >= 0.f && cx < g.dims[0] && cy < g.dims[1] && cz < g.dims[2]) {
+        cl = kd.cells + ((size_t)(cz * g.dims[1] + cy) * g.dims[0] + cx) * kCellBytes;
+        cnt = cl[0];
+    }
+    const bool all = cnt == 255;
+    const int total = all ? g.n_clusters : cnt;
+    // some vertex of cluster c is at most d(centre) + r away: the smallest such bound over the candidates prunes the
+    // list before the first scan (outside the grid every cluster is a candidate, in k-d order, not by distance)
+    float cap = best;
+    for (int b = 0; b < total; b += 16) {
+        const int k = b + sub;
+        if (k < total) {
+            const int c = all ? k : (int)cl[1 + k];
+            const f32x4 sp = reinterpret_cast<const f32x4*>(kd.spheres)[c];
+            const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
+            const float ub = sqrtf(dx * dx + dy * dy + dz * dz) + sp[3];
+            cap = fminf(cap, ub * ub * 1.00001f);
+        }
+        if (!all) break;   // inside the grid the lists are ordered by distance: the first 16 spheres are bound enough
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) cap = fminf(cap, __shfl_xor(cap, o));
+    for (int b = 0; b < total; b += 16) {
+        const int k = b + sub;
+        int c = -1;
+        float lb2 = 3.4e38f;
+        if (k < total) {
+            c = all ? k : (int)cl[1 + k];
+            const f32x4 sp = reinterpret_cast<const f32x4*>(kd.spheres)[c];
+            const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
+            const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - sp[3], 0.f);
+            lb2 = lb * lb;
+        }
+        const unsigned long long m = __ballot(c >= 0 && lb2 <= fminf(best, cap) * 1.00001f + 1e-12f);
+        unsigned live = (unsigned)(m >> gbase) & 0xffffu;
+        while (live) {
+            const int src = __ffs((int)live) - 1;
+            live &= live - 1;
+            const int cc = __shfl(c, gbase + src);
+            const float clb2 = __shfl(lb2, gbase + src);
+            if (clb2 > best * 1.00001f + 1e-12f) continue;   // uniform over the group
+            float d2 = 3.4e38f;
+            int vi = 0x7fffffff;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int v = sub + 16 * r;
+                if (v < kClusterSize) {
+                    const f32x4 q = reinterpret_cast<const f32x4*>(kd.sorted4)[cc * kClusterSize + v];
+                    const float dx = q[0] - p.x, dy = q[1] - p.y, dz = q[2] - p.z;
+                    const float e2 = dx * dx + dy * dy + dz * dz;
+                    const int ei = __float_as_int(q[3]);
+                    if (e2 < d2 || (e2 == d2 && ei < vi)) {
+                        d2 = e2;
+                        vi = ei;
+                    }
+                }
+            }
+            group16_argmin(d2, vi);
+            if (d2 < best || (d2 == best && vi < bi)) {
+                best = d2;
+                bi = vi;
+            }
+        }
+    }
+    return bi;
+}
+
 // SRC_POINTS : id = i, p = pts[i]                 -> x raw canonical
 // SRC_RAYS   : id = list[i] (ray), p = o + t[ray] d -> x NORMALISED (sphere tracing evaluates the SDF there)
 // SRC_SAMPLES: id = list[i] (q = ray*S + s), p = o + z[q] d -> x raw canonical
@@ -915,6 +1006,65 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
         }
         bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
         if (lane == 0) nearest_finish<SRC>(fr, bc, fr.bones, i, id, p, bi, idx_out, x_out, T_out, as_seed);
+    }
+}
+
+// the sphere-tracing lists (a few 1e2 .. 1.5e5 rays): four queries per wave straight from L2
+template <int SRC>
+__global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_group(FrameDev fr, KnnData kd, const float* pts, RaySet rs,
+                                                                    const float* depth, int n_steps, const int* list,
+                                                                    const int* count, int n_direct, int wave_below,
+                                                                    int* idx_out, float* x_out, float* T_out,
+                                                                    int as_seed, unsigned long long* ctr) {
+    const BodyConst bc = load_bc(fr);
+    const int n = (SRC == SRC_POINTS) ? n_direct : *count;
+    if (n >= wave_below) return;
+    const GridInfo g = *kd.grid;
+    if (blockIdx.x == 0 && threadIdx.x == 0) count_add(ctr, n);
+    const int lane = threadIdx.x & 63;
+    const int group_global = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, n_groups = (gridDim.x * blockDim.x) >> 4;
+    for (int i = group_global; i < n; i += n_groups) {
+        int id;
+        const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
+        float best = 3.4e38f;
+        int bi = 0x7fffffff;
+        if (SRC == SRC_RAYS && idx_out) {   // sphere tracing: the previous step's nearest vertex bounds the search
+            const int seed = idx_out[id];
+            if (seed >= 0) {
+                const float dx = fr.verts_raw[seed * 3] - p.x, dy = fr.verts_raw[seed * 3 + 1] - p.y,
+                            dz = fr.verts_raw[seed * 3 + 2] - p.z;
+                best = dx * dx + dy * dy + dz * dz;
+                bi = seed;
+            }
+        }
+        bi = nearest_vertex_group16(kd, g, p, best, bi, lane);
+        // blend over the group: lane e accumulates entry e of T over the 24 bones in the serial order of blend(); the
+        // entries then meet in every lane and lane 0 finishes the query
+        const int sub = lane & 15;
+        float te = 0.f;
+        {
+            const float* w = fr.vert_weights + (size_t)bi * 24;
+            f32x4 wq[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) wq[q] = reinterpret_cast<const f32x4*>(w)[q];
+#pragma unroll
+            for (int jn = 0; jn < 24; ++jn) te += wq[jn >> 2][jn & 3] * fr.bones[jn * 16 + sub];
+        }
+        float T[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) T[e] = __shfl(te, (lane & 48) + e);
+        if (sub == 0) {
+            V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
+            V3 xh = inverse_affine_apply(T, y);
+            if (SRC == SRC_RAYS) xh = normalize_pt(bc, xh);
+            if (idx_out) idx_out[id] = bi;
+            x_out[(size_t)id * 3 + 0] = xh.x;
+            x_out[(size_t)id * 3 + 1] = xh.y;
+            x_out[(size_t)id * 3 + 2] = xh.z;
+        }
+        if (SRC == SRC_SAMPLES && as_seed && sub >= 12 && sub < 15)
+            te = sub == 12 ? p.x - bc.trans[0] : sub == 13 ? p.y - bc.trans[1] : p.z - bc.trans[2];
+        T_out[(size_t)id * 16 + sub] = te;   // 64 contiguous bytes per query
     }
 }
 
@@ -2573,16 +2723,24 @@ void launch_nearest(hipStream_t s, const FrameDev& fd, long long n_max, const fl
     // list lengths below which one wave per query beats one thread per query (measured)
     // 512x512 frame: sphere-tracing lists (<= 1.5e5 rays, shrinking) 68.0 -> 65.4 ms per frame with the wave kernel below
     // 16k..64k entries; the 8.6e6-sample list of loop C wants the LDS table (86 ms when forced onto the wave kernel)
-    static const int below[3] = {env_int("ARAH_KNN_WAVE_POINTS", 4096), env_int("ARAH_KNN_WAVE_RAYS", 32768),
+    // round 3: the sixteen-lane kernel takes the ray lists at every length (47.2 vs 48.0 ms per frame against handing
+    // lists above 32k rays to the LDS-table kernel, gpurun_out r3n), so sphere tracing launches one search kernel per step
+    static const int group = env_int("ARAH_KNN_GROUP", 1);
+    static const int below[3] = {env_int("ARAH_KNN_WAVE_POINTS", 4096), env_int("ARAH_KNN_WAVE_RAYS", group ? (1 << 30) : 32768),
                                  env_int("ARAH_KNN_WAVE_SAMPLES", 32768)};
     const int wave_below = below[SRC];
     long long gw = (n_max * 64 + kKnnWaveThreads - 1) / kKnnWaveThreads;
     if (gw > 4096) gw = 4096;
     if (gw < 1) gw = 1;
-    if (n_max >= 0 && (SRC != SRC_POINTS || n_direct < wave_below))
+    if (group && SRC != SRC_SAMPLES && n_max >= 0 && (SRC != SRC_POINTS || n_direct < wave_below)) {
+        long long gg = (n_max * 16 + kKnnWaveThreads - 1) / kKnnWaveThreads;
+        gg = gg > 4096 ? 4096 : gg < 1 ? 1 : gg;
+        hipLaunchKernelGGL(k_nearest_group<SRC>, dim3((int)gg), dim3(kKnnWaveThreads), 0, s, fd, knn_of(fd), pts, rs, depth,
+                           n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out, as_seed, ctr);
+    } else if (n_max >= 0 && (SRC != SRC_POINTS || n_direct < wave_below))
         hipLaunchKernelGGL(k_nearest_wave<SRC>, dim3((int)gw), dim3(kKnnWaveThreads), 0, s, fd, knn_of(fd), pts, rs, depth,
                            n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out, as_seed, ctr);
-    if (SRC != SRC_POINTS || n_direct >= wave_below)
+    if (SRC == SRC_POINTS ? n_direct >= wave_below : n_max >= wave_below)
         hipLaunchKernelGGL(k_nearest_invlbs<SRC>, dim3(SRC == SRC_SAMPLES ? grid_for(n_max, kKnnThreads) : min(256, grid_for(n_max, 64))),
                            dim3(kKnnThreads), kLdsKnn, s, fd,
                            knn_of(fd), pts, rs, depth, n_steps, list, count, n_direct, wave_below, idx_out, x_out, T_out,

@@ -77,20 +77,6 @@ __host__ __device__ constexpr CwParts cw_parts(int NT, int L, int kc, int mp) {
 #endif
 constexpr int kCwLoDist = CW_LO_DIST, kCwHiDist = CW_HI_DIST;
 
-// compile-time loop: the body sees its index as a constant expression (register arrays are indexed statically whatever
-// the unroller's thresholds say)
-template <int I>
-struct IC {
-    static constexpr int value = I;
-};
-template <int I, int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) {
-        f(IC<I>{});
-        static_for<I + 1, N>(f);
-    }
-}
-
 template <bool HI_LDS, bool SCALED>
 __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
                                                               int* queue_head, CanonOut outp, unsigned long long* ctr,

@@ -328,6 +328,107 @@ __device__ __forceinline__ void gemm_acc_split(const f16x8* __restrict__ wp, int
     }
 }
 
+// compile-time loop: the body sees its index as a constant expression (register arrays are indexed statically whatever
+// the unroller's thresholds say)
+template <int I>
+struct IC {
+    static constexpr int value = I;
+};
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// The same product as gemm_acc_split<.., DEEP = false>, as an explicit software pipeline for kernels that run TWO waves
+// per SIMD (k_density's 128-point tiles): the rolled form leaves the order to the scheduler, which sinks every A load next
+// to its first use (ISA of round 3: global_load -> s_waitcnt vmcnt(0) -> v_mfma on the same registers, an L2 round trip
+// exposed three times per chunk) and reads all sixteen B fragments of a chunk before its first MFMA.  Here a STAGE is
+// 1/H of a chunk's N-tiles (3 MT NT/H MFMAs); while it runs, the B fragments of the next stage (2 NT/H ds_read_b128) and,
+// in a chunk's first stage, the A fragments of the next chunk (2 MT global loads) are in flight, and
+// sched_group_barrier pins the interleaving: one memory instruction between every two MFMAs.  Registers: two stages of B
+// (4 NT/H quads) + two chunks of A (4 MT quads) next to the MT NT accumulators.
+template <int KC32, int MT, int NT, int H>
+__device__ __forceinline__ void gemm_acc_split_pipe(const f16x8* __restrict__ wp, int mt0, const float* act, int ld,
+                                                    int lo_off, f32x4 (&acc)[MT][NT], int lane) {
+    constexpr int NH = NT / H, S = KC32 * H;
+    const int j = lane & 15, g = lane >> 4;
+    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
+    const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
+    auto lda = [&](int idx) { return ld_frag<f16x8>(wp, aoff, idx * 1024); };
+    f16x8 ah[2][MT], al[2][MT], bh[2][NH], bl[2][NH];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ah[0][m] = lda((m * KC32) * 2 + 0);
+        al[0][m] = lda((m * KC32) * 2 + 1);
+    }
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+        bh[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4);
+        bl[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<0, S>([&](auto Sc) {
+        constexpr int s = decltype(Sc)::value, kc = s / H, h = s % H, cb = s & 1, ca = kc & 1;
+        constexpr bool more_b = s + 1 < S, more_a = h == 0 && kc + 1 < KC32;
+#ifdef ARAH_ABL_A_FIXED   // timing ablations, as in gemm_acc_split (results are wrong with them)
+        constexpr int kA = 0;
+#else
+        constexpr int kA = kc + 1;
+#endif
+        if constexpr (more_a) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[ca ^ 1][m] = lda((m * KC32 + kA) * 2 + 0);
+                al[ca ^ 1][m] = lda((m * KC32 + kA) * 2 + 1);
+            }
+        }
+        if constexpr (more_b) {
+#ifdef ARAH_ABL_B_FIXED
+            constexpr int k1 = 0, h1 = (s + 1) % H;
+#else
+            constexpr int k1 = (s + 1) / H, h1 = (s + 1) % H;
+#endif
+#pragma unroll
+            for (int n = 0; n < NH; ++n) {
+                bh[cb ^ 1][n] = *reinterpret_cast<const f16x8*>(bptr + (h1 * NH + n) * 16 * ld * 4 + k1 * 64);
+                bl[cb ^ 1][n] = *reinterpret_cast<const f16x8*>(bptr + (h1 * NH + n) * 16 * ld * 4 + lo_off + k1 * 64);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)   // small terms first
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ca][m], bh[cb][n], acc[m][h * NH + n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ca][m], bl[cb][n], acc[m][h * NH + n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NH; ++n)
+                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ca][m], bh[cb][n], acc[m][h * NH + n], 0, 0, 0);
+        // order inside the stage: MFMA, load, MFMA, MFMA, load, ... (0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
+        constexpr int n_vm = more_a ? 2 * MT : 0, n_ds = more_b ? 2 * NH : 0, n_mf = 3 * MT * NH;
+        constexpr int per = (n_vm + n_ds) > 0 ? (n_mf - 2) / (n_vm + n_ds) : n_mf;   // MFMAs between two loads
+        constexpr int lead = per >= 2 ? 2 : 1;
+        static_for<0, n_vm>([&](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, lead > per ? per : (per >= 1 ? per : 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        });
+        static_for<0, n_ds>([&](auto) {
+            __builtin_amdgcn_sched_group_barrier(0x008, per >= 1 ? per : 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        });
+        __builtin_amdgcn_sched_group_barrier(0x008, n_mf, 0);   // whatever is left
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // 4 consecutive channels of one point, already multiplied by kActScale -> hi/lo planes
 // hi = f16(h) (round to nearest even), lo = f16(h - hi).  The residual is one mixed-precision FMA per channel that
 // reads its f16 operand straight out of the packed hi register and writes the f16 result into its half of the packed
@@ -592,6 +693,10 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
 #pragma unroll
             for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
         if constexpr (TAP::on) stream_rows(act, ld, 256, tap.h[k], tap.row0, tap.rows, wave * 64 + lane);   // h_k: read only
+#ifndef ARAH_TRUNK_ROLLED   // 128-point tiles (two waves per SIMD): the explicit pipeline, 12.3 vs 13.1 ms for k_density (r3o)
+        if constexpr (SPLIT && !GRAD && NT == 8) gemm_acc_split_pipe<8, kSdfMT, NT, 2>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+        else
+#endif
         if (SPLIT) gemm_acc_split<8, kSdfMT, NT, GRAD>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);   // GRAD kernels: 2 waves/SIMD
         else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
         // forward-only kernels: the epilogue's per-channel constants travel (L2 latency) while the workgroup gathers at the
@@ -700,55 +805,89 @@ __device__ __forceinline__ void sdf_trunk_pp(const SdfNet& net, const float* xin
                 pwm[m] = *reinterpret_cast<const f32x4*>(net.pw + ke * 256 + ch0);
             }
         }
-        f16x8 ah[kSdfMT], al[kSdfMT], ahn[kSdfMT], aln[kSdfMT];
+        // explicit pipeline as in gemm_acc_split_pipe, a stage = half a 32-chunk's N-tiles (3 kSdfMT NTH / 2 MFMAs): the
+        // next stage's B fragments and (first half) the next chunk's A fragments are requested while the stage's MFMAs
+        // run, and the epilogue group of the other half-tile rides between them: FiLM sine in a chunk's first stage,
+        // hi/lo split and the two LDS stores in its second
+        constexpr int NQ = NTH / 2;
+        f16x8 ah[2][kSdfMT], al[2][kSdfMT], bh[2][NQ], bl[2][NQ];
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
-            ah[m] = lda((m * 8) * 2 + 0);
-            al[m] = lda((m * 8) * 2 + 1);
+            ah[0][m] = lda((m * 8) * 2 + 0);
+            al[0][m] = lda((m * 8) * 2 + 1);
         }
 #pragma unroll
-        for (int kc = 0; kc < 8; ++kc) {
-            const int kn = kc + 1 < 8 ? kc + 1 : kc;
+        for (int n = 0; n < NQ; ++n) {
+            bh[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4);
+            bl[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 hcur = zero4;
+        static_for<0, 16>([&](auto Sc) {
+            constexpr int st = decltype(Sc)::value, kc = st >> 1, hh = st & 1, cb = st & 1, ca = kc & 1;
+            constexpr bool more_b = st + 1 < 16, more_a = hh == 0 && kc + 1 < 8;
+            if constexpr (more_a) {
 #pragma unroll
-            for (int m = 0; m < kSdfMT; ++m) {
-                ahn[m] = lda((m * 8 + kn) * 2 + 0);
-                aln[m] = lda((m * 8 + kn) * 2 + 1);
+                for (int m = 0; m < kSdfMT; ++m) {
+                    ah[ca ^ 1][m] = lda((m * 8 + kc + 1) * 2 + 0);
+                    al[ca ^ 1][m] = lda((m * 8 + kc + 1) * 2 + 1);
+                }
             }
-            f16x8 bh[NTH], bl[NTH];
+            if constexpr (more_b) {
+                constexpr int k1 = (st + 1) >> 1, h1 = (st + 1) & 1;
 #pragma unroll
-            for (int n = 0; n < NTH; ++n) {
-                bh[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
-                bl[n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + 512 + kc * 64);
+                for (int n = 0; n < NQ; ++n) {
+                    bh[cb ^ 1][n] = *reinterpret_cast<const f16x8*>(bptr + (h1 * NQ + n) * 16 * ld * 4 + k1 * 64);
+                    bl[cb ^ 1][n] = *reinterpret_cast<const f16x8*>(bptr + (h1 * NQ + n) * 16 * ld * 4 + 512 + k1 * 64);
+                }
             }
 #pragma unroll
             for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
-                for (int n = 0; n < NTH; ++n)
-                    acc[hg][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[n], kc == 0 ? zero4 : acc[hg][m][n], 0, 0, 0);
+                for (int n = 0; n < NQ; ++n)
+                    acc[hg][m][hh * NQ + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ca][m], bh[cb][n], kc == 0 ? zero4 : acc[hg][m][hh * NQ + n], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
-                for (int n = 0; n < NTH; ++n)
-                    acc[hg][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[n], acc[hg][m][n], 0, 0, 0);
+                for (int n = 0; n < NQ; ++n)
+                    acc[hg][m][hh * NQ + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ca][m], bl[cb][n], acc[hg][m][hh * NQ + n], 0, 0, 0);
 #pragma unroll
             for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
-                for (int n = 0; n < NTH; ++n)
-                    acc[hg][m][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[n], acc[hg][m][n], 0, 0, 0);
+                for (int n = 0; n < NQ; ++n)
+                    acc[hg][m][hh * NQ + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ca][m], bh[cb][n], acc[hg][m][hh * NQ + n], 0, 0, 0);
             if constexpr (EPI) {   // accumulator group kc of the other half: kSdfMT * NTH == 8 groups, one per chunk
                 static_assert(kSdfMT * NTH == 8, "one epilogue group per 32-chunk");
-                const int m = kc / NTH, n = kc % NTH;
-                f32x4 h, d;
-                film_sine<false>(acc[he][m][n], fwm[m], pwm[m], zero4, amp, h, d);
-                store_split4(act, ld, 512, (he * NTH + n) * 16 + j, (mt0 + m) * 16 + 4 * g, h);
+                constexpr int m = kc / NTH, n = kc % NTH;
+                if constexpr (hh == 0) {
+                    f32x4 d;
+                    film_sine<false>(acc[he][m][n], fwm[m], pwm[m], zero4, amp, hcur, d);
+                } else {
+                    store_split4(act, ld, 512, (he * NTH + n) * 16 + j, (mt0 + m) * 16 + 4 * g, hcur);
+                }
             }
-#pragma unroll
-            for (int m = 0; m < kSdfMT; ++m) {
-                ah[m] = ahn[m];
-                al[m] = aln[m];
+            // 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write
+            constexpr int n_vm = more_a ? 2 * kSdfMT : 0, n_ds = more_b ? 2 * NQ : 0, n_mf = 3 * kSdfMT * NQ;
+            static_for<0, n_vm>([&](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            });
+            static_for<0, n_ds>([&](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            });
+            static_for<0, n_mf - n_vm - n_ds>([&](auto) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if constexpr (EPI) __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            });
+            if constexpr (EPI) {
+                __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);   // a chunk's requests stay in their chunk (registers)
-        }
+            __builtin_amdgcn_sched_barrier(0);
+        });
     };
     typedef PpConst<int, 0> H0_;
     typedef PpConst<int, 1> H1_;
