@@ -883,8 +883,9 @@ __device__ __forceinline__ void group16_argmin(float& d2, int& idx) {
     }
 }
 
-__device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const GridInfo& g, V3 p, float best, int bi,
-                                                      int lane) {
+template <int STRIDE>
+__device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const float* sv, const float* ssph, const GridInfo& g,
+                                                      V3 p, float best, int bi, int lane) {
     const int sub = lane & 15, gbase = lane & 48;
     const float fx = (p.x - g.origin[0]) * g.inv_h, fy = (p.y - g.origin[1]) * g.inv_h, fz = (p.z - g.origin[2]) * g.inv_h;
     const int cx = (int)floorf(fx), cy = (int)floorf(fy), cz = (int)floorf(fz);
@@ -903,7 +904,7 @@ __device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const G
         const int k = b + sub;
         if (k < total) {
             const int c = all ? k : (int)cl[1 + k];
-            const f32x4 sp = reinterpret_cast<const f32x4*>(kd.spheres)[c];
+            const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c];
             const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
             const float ub = sqrtf(dx * dx + dy * dy + dz * dz) + sp[3];
             cap = fminf(cap, ub * ub * 1.00001f);
@@ -918,7 +919,7 @@ __device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const G
         float lb2 = 3.4e38f;
         if (k < total) {
             c = all ? k : (int)cl[1 + k];
-            const f32x4 sp = reinterpret_cast<const f32x4*>(kd.spheres)[c];
+            const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c];
             const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
             const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - sp[3], 0.f);
             lb2 = lb * lb;
@@ -937,7 +938,7 @@ __device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const G
             for (int r = 0; r < 2; ++r) {
                 const int v = sub + 16 * r;
                 if (v < kClusterSize) {
-                    const f32x4 q = reinterpret_cast<const f32x4*>(kd.sorted4)[cc * kClusterSize + v];
+                    const f32x4 q = reinterpret_cast<const f32x4*>(sv)[cc * STRIDE + v];
                     const float dx = q[0] - p.x, dy = q[1] - p.y, dz = q[2] - p.z;
                     const float e2 = dx * dx + dy * dy + dz * dz;
                     const int ei = __float_as_int(q[3]);
@@ -1009,6 +1010,38 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
     }
 }
 
+// nearest_finish over a group of sixteen lanes: lane e accumulates entry e of T over the 24 bones in the serial order of
+// blend(); the entries then meet in every lane and lane 0 finishes the query
+template <int SRC>
+__device__ __forceinline__ void nearest_finish_group16(const FrameDev& fr, const BodyConst& bc, const float* sb, int id, V3 p, int bi,
+                                                       int lane, int* idx_out, float* x_out, float* T_out, int as_seed) {
+    const int sub = lane & 15;
+    float te = 0.f;
+    {
+        const float* w = fr.vert_weights + (size_t)bi * 24;
+        f32x4 wq[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q) wq[q] = reinterpret_cast<const f32x4*>(w)[q];
+#pragma unroll
+        for (int jn = 0; jn < 24; ++jn) te += wq[jn >> 2][jn & 3] * sb[jn * 16 + sub];
+    }
+    float T[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) T[e] = __shfl(te, (lane & 48) + e);
+    if (sub == 0) {
+        V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
+        V3 xh = inverse_affine_apply(T, y);
+        if (SRC == SRC_RAYS) xh = normalize_pt(bc, xh);
+        if (idx_out) idx_out[id] = bi;
+        x_out[(size_t)id * 3 + 0] = xh.x;
+        x_out[(size_t)id * 3 + 1] = xh.y;
+        x_out[(size_t)id * 3 + 2] = xh.z;
+    }
+    if (SRC == SRC_SAMPLES && as_seed && sub >= 12 && sub < 15)
+        te = sub == 12 ? p.x - bc.trans[0] : sub == 13 ? p.y - bc.trans[1] : p.z - bc.trans[2];
+    T_out[(size_t)id * 16 + sub] = te;   // 64 contiguous bytes per query
+}
+
 // the sphere-tracing lists (a few 1e2 .. 1.5e5 rays): four queries per wave straight from L2
 template <int SRC>
 __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_group(FrameDev fr, KnnData kd, const float* pts, RaySet rs,
@@ -1037,34 +1070,8 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_group(FrameDev fr, 
                 bi = seed;
             }
         }
-        bi = nearest_vertex_group16(kd, g, p, best, bi, lane);
-        // blend over the group: lane e accumulates entry e of T over the 24 bones in the serial order of blend(); the
-        // entries then meet in every lane and lane 0 finishes the query
-        const int sub = lane & 15;
-        float te = 0.f;
-        {
-            const float* w = fr.vert_weights + (size_t)bi * 24;
-            f32x4 wq[6];
-#pragma unroll
-            for (int q = 0; q < 6; ++q) wq[q] = reinterpret_cast<const f32x4*>(w)[q];
-#pragma unroll
-            for (int jn = 0; jn < 24; ++jn) te += wq[jn >> 2][jn & 3] * fr.bones[jn * 16 + sub];
-        }
-        float T[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) T[e] = __shfl(te, (lane & 48) + e);
-        if (sub == 0) {
-            V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
-            V3 xh = inverse_affine_apply(T, y);
-            if (SRC == SRC_RAYS) xh = normalize_pt(bc, xh);
-            if (idx_out) idx_out[id] = bi;
-            x_out[(size_t)id * 3 + 0] = xh.x;
-            x_out[(size_t)id * 3 + 1] = xh.y;
-            x_out[(size_t)id * 3 + 2] = xh.z;
-        }
-        if (SRC == SRC_SAMPLES && as_seed && sub >= 12 && sub < 15)
-            te = sub == 12 ? p.x - bc.trans[0] : sub == 13 ? p.y - bc.trans[1] : p.z - bc.trans[2];
-        T_out[(size_t)id * 16 + sub] = te;   // 64 contiguous bytes per query
+        bi = nearest_vertex_group16<kClusterSize>(kd, kd.sorted4, kd.spheres, g, p, best, bi, lane);
+        nearest_finish_group16<SRC>(fr, bc, fr.bones, id, p, bi, lane, idx_out, x_out, T_out, as_seed);
     }
 }
 
@@ -1106,6 +1113,8 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         }
         return;
     }
+    // (sixteen lanes per query against this table: 5.2 ms for the 8.6e6-sample list, against 2.6 ms with a thread per query --
+    // neighbouring samples walk the same clusters, so the serial walk's LDS reads are broadcasts; gpurun_out r3q)
     const int slot = (t & ~511) + ((t >> 3) & 7) * 64 + ((t >> 6) & 7) * 8 + (t & 7);
     for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
         const int i = i0 + slot;
