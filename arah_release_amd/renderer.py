@@ -226,13 +226,14 @@ class IDHRNetwork(nn.Module):
                 ray_augm = True
             else:
                 dirs_in = ray_dirs + vn
+        vb, vr = vol_mask.nonzero(as_tuple=True)   # one compaction for the seven gathers and the two scatters
         rgb_hit, w_hit = training.shade_composite_train(
-            self, sdf_network, s_pts[vol_mask], s_z[vol_mask], s_T[vol_mask], s_mask[vol_mask], dirs_in[vol_mask],
-            ray_dirs[vol_mask], pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
+            self, sdf_network, s_pts[vb, vr], s_z[vb, vr], s_T[vb, vr], s_mask[vb, vr], dirs_in[vb, vr],
+            ray_dirs[vb, vr], pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
             self.ray_tracer.n_steps, ray_augm=ray_augm, frame=frame if use_hip_shading else None,
             ws=self.ray_tracer.workspace(dev) if frame is not None else None)
-        rgb = torch.zeros_like(xn).masked_scatter(vol_mask.unsqueeze(-1), rgb_hit)
-        acc = torch.zeros(B, N, device=dev).masked_scatter(vol_mask, w_hit)
+        rgb = torch.zeros(B * N, 3, device=dev, dtype=xn.dtype).index_copy(0, vb * N + vr, rgb_hit).reshape(B, N, 3)
+        acc = torch.zeros(B * N, device=dev).index_copy(0, vb * N + vr, w_hit.reshape(-1)).reshape(B, N)
         out = {"rgb_values": rgb, "sdf_output": acc, "network_body_mask": vol_mask, "body_mask": input["body_mask"],
                "off_surface_mask": vol_mask, "off_surface_sdf": uniform_sdf, "grad_theta": grad_eik,
                "surface_normals": None}

@@ -15,6 +15,8 @@ HIP kernels unchanged.  What carries gradients is
 These are kept on autograd, as SURVEY 7 step 7 plans for a first cut; a hand-written backward of
 loop D is the follow-up.  Everything here is plain torch on whatever device the tensors live on.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -36,31 +38,51 @@ def unnormalize_canonical_points(pts, coord_min, coord_max, center):
     return (pts / 2.0 + 0.5) * 1.1 * span + coord_min - span * 0.05 + center
 
 
-def hierarchical_softmax(x):
-    """(..., 25) logits -> (..., 24) weights along the SMPL kinematic tree (utils/utils.py:138-181)."""
-    lead = x.shape[:-1]
-    x = x.reshape(-1, 25)
-    gate = torch.sigmoid(x)
-    keep = 1.0 - gate
+def _hsoftmax_paths():
+    """The factors each of the 24 weights is a product of, found by running the reference's recursion
+    (utils/utils.py:138-181) on index lists: columns of F = [gate(25) | 1 - gate(25) | softmax(x[1:4]) | softmax(x[12:15]) | 1]."""
+    G, K, HIPS, CHEST, ONE = 0, 25, 50, 53, 56
     w = [None] * 24
-    hips = torch.softmax(x[:, 1:4], dim=-1)
-    w[0] = keep[:, 0]
+    w[0] = [K + 0]
     for k in range(3):
-        w[1 + k] = gate[:, 0] * hips[:, k]
+        w[1 + k] = [G + 0, HIPS + k]
 
     def hand_down(parent, child, g):
-        w[child] = w[parent] * gate[:, g]
-        w[parent] = w[parent] * keep[:, g]
+        w[child] = w[parent] + [G + g]
+        w[parent] = w[parent] + [K + g]
 
     for parent, child in ((1, 4), (2, 5), (3, 6), (4, 7), (5, 8), (6, 9), (7, 10), (8, 11)):
         hand_down(parent, child, child)
-    chest = torch.softmax(x[:, 12:15], dim=-1)
     for k in range(3):
-        w[12 + k] = w[9] * gate[:, 24] * chest[:, k]
-    w[9] = w[9] * keep[:, 24]
+        w[12 + k] = w[9] + [G + 24, CHEST + k]
+    w[9] = w[9] + [K + 24]
     for parent, child in ((12, 15), (13, 16), (14, 17), (16, 18), (17, 19), (18, 20), (19, 21), (20, 22), (21, 23)):
         hand_down(parent, child, child)
-    return torch.stack(w, dim=-1).reshape(*lead, 24)
+    depth = max(len(p) for p in w)
+    return [p + [ONE] * (depth - len(p)) for p in w]
+
+
+_HSOFTMAX_PATHS = {}
+
+
+def hierarchical_softmax(x):
+    """(..., 25) logits -> (..., 24) weights along the SMPL kinematic tree (utils/utils.py:138-181).
+    The reference hands weight down the tree joint by joint (some eighty element-wise launches, two hundred in backward);
+    every weight is a fixed product of gates / complements / softmax entries, so here it is one gather and one product."""
+    lead = x.shape[:-1]
+    x = x.reshape(-1, 25)
+    gate = torch.sigmoid(x)
+    F_ = torch.cat([gate, 1.0 - gate, torch.softmax(x[:, 1:4], dim=-1), torch.softmax(x[:, 12:15], dim=-1),
+                    torch.ones_like(x[:, :1])], dim=-1)
+    key = str(x.device)
+    if key not in _HSOFTMAX_PATHS:
+        _HSOFTMAX_PATHS[key] = torch.tensor(_hsoftmax_paths(), dtype=torch.long, device=x.device)
+    paths = _HSOFTMAX_PATHS[key]                                   # (24, depth)
+    cols = F_[:, paths.t().reshape(-1)].reshape(-1, paths.shape[1], 24).unbind(1)   # one backward node for all of them
+    out = cols[0]
+    for c in cols[1:]:                                             # left to right, the order the recursion multiplies in
+        out = out * c
+    return out.reshape(*lead, 24)
 
 
 def query_weights(x_hat, coord_min, coord_max, center, skinning_model):
@@ -195,10 +217,14 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
     dev = points.device
     lengths = converge_mask.sum(-1)
     slot = torch.arange(S, device=dev)[None, :] < lengths[:, None]          # left-packed valid slots
-    pts = points[converge_mask]
-    Tf = transforms_fwd[converge_mask]
-    vd = view_dirs[:, None, :].expand(n_rays, S, 3)[converge_mask]
-    vd0 = view_dirs_orig[:, None, :].expand(n_rays, S, 3)[converge_mask]
+    # ONE compaction (a device -> host round trip for the count) serves every per-sample gather below and the scatter back
+    # into left-packed [ray, slot] form; the reference indexes with the boolean mask each time (same elements, same order)
+    ridx, sidx = converge_mask.nonzero(as_tuple=True)
+    flat = ridx * S + (converge_mask.cumsum(-1) - 1)[ridx, sidx]             # k-th valid sample of a ray -> slot k
+    pts = points[ridx, sidx]
+    Tf = transforms_fwd[ridx, sidx]
+    vd = view_dirs[ridx]
+    vd0 = view_dirs_orig[ridx]
     if idhr.cano_view_dirs:
         Rb = torch.linalg.inv(Tf).detach()[:, :3, :3]
         vin = mv3(Rb, -vd)
@@ -253,9 +279,9 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
     beta = idhr.deviation_network(sdf_v).clip(1e-6, 1e6)
     inv_beta = torch.reciprocal(beta)
     dens_v = F.relu(inv_beta * (0.5 + 0.5 * torch.sign(-sdf_v) * (1 - torch.exp(-sdf_v.abs() * inv_beta))))
-    rgb = torch.zeros(n_rays, S, 3, device=dev).masked_scatter(slot.unsqueeze(-1), rgb_v)
-    dens = torch.zeros(n_rays, S, device=dev).masked_scatter(slot, dens_v.squeeze(-1))
-    zp = torch.full((n_rays, S), 1e10, device=dev).masked_scatter(slot, z_vals[converge_mask])
+    rgb = torch.zeros(n_rays * S, 3, device=dev).index_copy(0, flat, rgb_v).reshape(n_rays, S, 3)
+    dens = torch.zeros(n_rays * S, device=dev).index_copy(0, flat, dens_v.squeeze(-1)).reshape(n_rays, S)
+    zp = torch.full((n_rays * S,), 1e10, device=dev).index_copy(0, flat, z_vals[ridx, sidx]).reshape(n_rays, S)
     delta = zp[:, 1:] - zp[:, :-1]
     if idhr.render_last_pt:
         delta = torch.cat([delta, torch.full((n_rays, 1), 1e10, device=dev)], dim=-1)
@@ -316,13 +342,18 @@ class IDHRLoss(nn.Module):
         n_px = float(body.numel())
         terms = {k: zero() for k in self.TERMS}
         if self.weights["rgb"] > 0:
-            m = hit
-            if m.sum() == 0:
-                terms["rgb"] = torch.tensor(0.0, device=dev)
+            # the reference compacts the hit pixels (boolean indexing: a device -> host round trip each) and sums the
+            # element-wise loss over them; the same sum with the mask as a factor needs no round trip.  Patch sampling marks
+            # boundary pixels with 100 (body.max() > 1 there); without such pixels the second factor is all ones.
+            m = (hit & (body != 100)).unsqueeze(-1).to(out["rgb_values"].dtype)
+            a, b = out["rgb_values"][:, :2048], gt["rgb"][:, :2048]
+            if isinstance(self.pixel_loss, nn.L1Loss):
+                per = (a - b).abs()
+            elif isinstance(self.pixel_loss, nn.MSELoss):
+                per = (a - b) ** 2
             else:
-                if body.max() > 1:          # patch sampling marks boundary pixels with 100
-                    m = m & (body != 100)
-                terms["rgb"] = self.pixel_loss(out["rgb_values"][:, :2048][m], gt["rgb"][:, :2048][m]) / float(m.numel())
+                per = F.smooth_l1_loss(a, b, reduction="none", beta=1e-1)
+            terms["rgb"] = (per * m).sum() / float(hit.numel())
         if self.weights["perceptual"] > 0:
             if self.p_loss is None:
                 raise ValueError("perceptual_weight > 0 needs a perceptual_loss_fn (e.g. LPIPS)")
@@ -330,10 +361,15 @@ class IDHRLoss(nn.Module):
             ref = gt["rgb"][:, 2048:].reshape(-1, 48, 48, 3).permute(0, 3, 1, 2)
             terms["perceptual"] = self.p_loss(pred, ref, normalize=True).mean() if hit.sum() > 0 else torch.tensor(0.0, device=dev)
         if self.weights["mask"] > 0:
-            if off.sum() == 0:
+            # the L2 norm of the residual vector over the off-surface pixels (torch.norm over the last dim of a 1-D tensor);
+            # masked-out entries contribute zeros, an empty mask gives 0 with a zero gradient -- no host round trip
+            acc = out["sdf_output"]
+            if acc.dim() == body.dim():
+                terms["mask"] = torch.norm((acc[:, :off.shape[1]] - body.float()) * off) / n_px
+            elif off.sum() == 0:
                 terms["mask"] = torch.tensor(0.0, device=dev)
-            else:
-                terms["mask"] = torch.norm(out["sdf_output"][off] - body[off].float(), dim=-1).sum() / n_px
+            else:   # a trailing singleton axis broadcasts against the mask values (n, 1) - (n,): the reference's arithmetic
+                terms["mask"] = torch.norm(acc[off] - body[off].float(), dim=-1).sum() / n_px
         if self.weights["eikonal"] > 0:
             g = out["grad_theta"]
             terms["eikonal"] = (torch.abs(g.norm(2, dim=-1) - 1).sum() / n_px) if g.shape[0] else torch.tensor(0.0, device=dev)
@@ -378,7 +414,10 @@ def configure_optimizers(model, cfg):
         groups.append({"params": model.smpl_parameters(), "lr": 1e-4})                        # :442-448
     if m.get("color_pose_encoder") in ("hybrid", "latent") or m.get("geo_pose_encoder") in ("latent",):
         groups.append({"params": model.latent.parameters(), "lr": 1e-4, "weight_decay": 0.05})   # :450-457
-    return torch.optim.Adam(params=groups)
+    # fused: one multi-tensor kernel per group for the whole update instead of torch's foreach chain (~80 launches over the
+    # 87 M parameters); same update rule, same state-dict keys.  CUDA parameters only.
+    fused = all(p.is_cuda for p in model.parameters()) and os.environ.get("ARAH_FUSED_ADAM", "1") != "0"
+    return torch.optim.Adam(params=groups, fused=True) if fused else torch.optim.Adam(params=groups)
 
 
 def training_step(model, criteria, inputs):

@@ -26,3 +26,44 @@ def test_idhr_loss_against_reference(case):
                                    rtol=1e-6, atol=1e-9, err_msg=k)
     with pytest.raises(ValueError):
         training.IDHRLoss(1, 0, 0, 0, 0, 0, 0, 0, rgb_loss_type="huber")
+
+
+def test_hierarchical_softmax_is_the_recursion():
+    """training.hierarchical_softmax gathers each weight's factors and multiplies them in the order the reference's
+    recursion does (utils/utils.py:138-181): the golden vectors of F2 bit for bit, and the same gradient."""
+    from arah_release_amd import training
+    from oracle import arah_oracle as O
+    g = golden("f2_pointwise.npz")
+    x = torch.from_numpy(g["logits"])
+    w = training.hierarchical_softmax(x)
+    np.testing.assert_allclose(w.numpy(), g["hsoftmax"], rtol=1e-6, atol=1e-7)
+    assert torch.equal(w, O.hierarchical_softmax(x))
+    xs = (torch.randn(257, 25, generator=torch.Generator().manual_seed(3)) * 4).requires_grad_(True)
+    ga = torch.autograd.grad((training.hierarchical_softmax(xs) ** 2).sum(), xs)[0]
+    gb = torch.autograd.grad((O.hierarchical_softmax(xs) ** 2).sum(), xs)[0]
+    np.testing.assert_allclose(ga.numpy(), gb.numpy(), rtol=1e-5, atol=1e-6)
+    paths = training._hsoftmax_paths()
+    assert len(paths) == 24 and len({len(p) for p in paths}) == 1
+
+
+@pytest.mark.parametrize("rel", [False, True])
+def test_pose_encoder_levels_against_joint_by_joint(rel):
+    """The level-batched HierarchicalPoseEncoder (training) against the joint-by-joint form (siren_modules.py:196-244):
+    outputs and every parameter gradient; inference (no_grad) stays on the joint-by-joint order."""
+    from arah_release_amd import nets
+    torch.manual_seed(1)
+    enc = nets.HierarchicalPoseEncoder(rel_joints=rel)
+    rots, J = torch.randn(2, 24, 9), torch.randn(2, 24, 3)
+    enc.batched_levels = True
+    a = enc(rots, J)
+    ga = torch.autograd.grad((a ** 2).sum(), list(enc.parameters()))
+    with torch.no_grad():
+        a_inf = enc(rots, J)
+    enc.batched_levels = False
+    b = enc(rots, J)
+    gb = torch.autograd.grad((b ** 2).sum(), list(enc.parameters()))
+    assert torch.equal(a_inf, b)
+    np.testing.assert_allclose(a.detach().numpy(), b.detach().numpy(), rtol=1e-5, atol=1e-6)
+    for x, y in zip(ga, gb):
+        np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-4, atol=1e-5)
+    assert [len(l) for l in enc._levels()] == [1, 3, 3, 3, 5, 3, 2, 2, 2]
