@@ -2848,12 +2848,52 @@ ColSegs one_seg(int len) {
     return s;
 }
 
+// the nearest-vertex tables of one posed body, in a buffer of their own (arah_body_bytes) or inside the frame buffer
+struct BodyTables {
+    float* verts4 = nullptr;
+    float* spheres = nullptr;
+    GridInfo* grid = nullptr;
+    unsigned char* cells = nullptr;
+};
+constexpr size_t kBodyOffSpheres = (size_t)kMaxClusters * kClusterSize * 16;
+constexpr size_t kBodyOffGrid = kBodyOffSpheres + (size_t)kMaxClusters * 16;
+constexpr size_t kBodyOffCells = kBodyOffGrid + ((sizeof(GridInfo) + 255) / 256) * 256;
+constexpr size_t kBodyBytes = kBodyOffCells + (size_t)kMaxCells * kCellBytes;
+
+BodyTables body_tables(void* buf) {
+    char* b = reinterpret_cast<char*>(buf);
+    BodyTables t;
+    t.verts4 = reinterpret_cast<float*>(b);
+    t.spheres = reinterpret_cast<float*>(b + kBodyOffSpheres);
+    t.grid = reinterpret_cast<GridInfo*>(b + kBodyOffGrid);
+    t.cells = reinterpret_cast<unsigned char*>(b + kBodyOffCells);
+    return t;
+}
+
+void launch_body_tables(const float* verts, int n_verts, const BodyTables& t, hipStream_t s) {
+    hipLaunchKernelGGL(k_sort_verts, dim3(1), dim3(1024), 0, s, verts, n_verts, t.verts4, t.grid);
+    hipLaunchKernelGGL(k_cluster_spheres, dim3(1), dim3(256), 0, s, (const float*)t.verts4, t.spheres);
+    hipLaunchKernelGGL(k_cell_clusters, dim3(kMaxCells / kCellThreads), dim3(kCellThreads), 0, s, (const GridInfo*)t.grid,
+                       (const float*)t.spheres, t.cells);
+}
+
 }  // namespace
 
 // =============================================================================================
 // C ABI
 // =============================================================================================
 extern "C" {
+
+size_t arah_body_bytes(void) { return kBodyBytes; }
+
+int arah_prepare_body(const float* verts, int32_t n_verts, void* body_buf, size_t body_bytes, void* stream) {
+    if (!verts || !body_buf || (reinterpret_cast<uintptr_t>(body_buf) & 255) != 0) return ARAH_E_BADARG;
+    if (n_verts <= 0 || n_verts > kMaxVerts) return ARAH_E_SHAPE;
+    if (body_bytes < kBodyBytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    launch_body_tables(verts, n_verts, body_tables(body_buf), reinterpret_cast<hipStream_t>(stream));
+    return check_launch();
+}
 
 const char* arah_dominant_kernel(void) { return "k_canon_wave"; }   // largest single launch of the default path (loop C)
 
@@ -2991,13 +3031,19 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     if (!body->trans || !body->center || !body->coord_min || !body->coord_max) return ARAH_E_BADARG;
     hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, s, P(L.scalars), body->trans, body->center, body->coord_min,
                        body->coord_max, nets->beta);
-    // ---- body: Morton-sorted vertices, cluster spheres, per-cell candidate clusters (exact 1-NN acceleration)
-    hipLaunchKernelGGL(k_sort_verts, dim3(1), dim3(1024), 0, s, body->verts, body->n_verts, P(L.verts4),
-                       reinterpret_cast<GridInfo*>(base + L.knn_grid));
-    hipLaunchKernelGGL(k_cluster_spheres, dim3(1), dim3(256), 0, s, (const float*)P(L.verts4), P(L.knn_spheres));
-    hipLaunchKernelGGL(k_cell_clusters, dim3(kMaxCells / kCellThreads), dim3(kCellThreads), 0, s,
-                       (const GridInfo*)(base + L.knn_grid), (const float*)P(L.knn_spheres),
-                       reinterpret_cast<unsigned char*>(base + L.knn_cells));
+    // ---- body: k-d clustered vertices, cluster spheres, per-cell candidate clusters (exact 1-NN acceleration).  A caller
+    // that has the posed vertices before the networks (SMPL runs first) can have built the tables already with
+    // arah_prepare_body, on another stream next to the hypernetwork; it orders that stream before this one itself.
+    BodyTables bt;
+    if (body->prepared) {
+        bt = body_tables(const_cast<void*>(body->prepared));
+    } else {
+        bt.verts4 = P(L.verts4);
+        bt.spheres = P(L.knn_spheres);
+        bt.grid = reinterpret_cast<GridInfo*>(base + L.knn_grid);
+        bt.cells = reinterpret_cast<unsigned char*>(base + L.knn_cells);
+        launch_body_tables(body->verts, body->n_verts, bt, s);
+    }
     memset(out, 0, sizeof(*out));
     out->sdf_w0 = P(L.sdf_w0);
     for (int i = 0; i < 5; ++i) {
@@ -3035,10 +3081,10 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->col_w3apT = P(L.col_w3apT);
     out->col_w3bpT = P(L.col_w3bpT);
     out->col_w4pT = P(L.col_w4pT);
-    out->verts4 = P(L.verts4);
-    out->knn_spheres = P(L.knn_spheres);
-    out->knn_grid = base + L.knn_grid;
-    out->knn_cells = base + L.knn_cells;
+    out->verts4 = bt.verts4;
+    out->knn_spheres = bt.spheres;
+    out->knn_grid = bt.grid;
+    out->knn_cells = bt.cells;
     out->verts = body->verts;
     out->vert_weights = body->vert_weights;
     out->bones = body->bones;

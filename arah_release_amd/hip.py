@@ -44,7 +44,7 @@ class ArahNets(C.Structure):
 
 class ArahBody(C.Structure):
     _fields_ = [("verts", _fp), ("vert_weights", _fp), ("bones", _fp), ("trans", _fp), ("center", _fp),
-                ("coord_min", _fp), ("coord_max", _fp), ("n_verts", C.c_int32)]
+                ("coord_min", _fp), ("coord_max", _fp), ("n_verts", C.c_int32), ("prepared", C.c_void_p)]
 
 
 class ArahSampling(C.Structure):
@@ -88,7 +88,7 @@ class ArahCounters(C.Structure):
 
 COUNTER_BYTES = C.sizeof(ArahCounters)
 
-EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_workspace_bytes", "arah_counters_reset",
+EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_prepare_body", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
@@ -108,6 +108,7 @@ def load_library():
                            "g.build()'` -- there is no CPU fallback for the hot path" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
     lib.arah_frame_bytes.restype = C.c_size_t
+    lib.arah_body_bytes.restype = C.c_size_t
     lib.arah_workspace_bytes.restype = C.c_size_t
     lib.arah_workspace_bytes.argtypes = [C.c_int32, C.c_int32]
     lib.arah_dominant_kernel.restype = C.c_char_p
@@ -244,11 +245,43 @@ class Workspace:
                                                    "n_density", "n_canon", "n_split_nonfinite")}
 
 
+_side_streams = {}
+
+
+class BodyTables:
+    """The nearest-vertex tables of one posed body (k-d clustered vertices, cluster spheres, per-cell candidate lists),
+    built by arah_prepare_body on a SIDE stream: the 1.4 ms of a one-workgroup sort and a 512-workgroup pass then run next to
+    whatever the caller's stream does in the meantime (the pose encoder and the hypernetwork: the posed vertices are
+    known before them).  Frame(..., body_tables=...) orders the side stream before its own and keeps this object alive."""
+
+    def __init__(self, verts):
+        require_gpu()
+        lib = load_library()
+        dev = verts.device
+        self.verts = _f32(verts)
+        if self.verts.dim() != 2 or self.verts.shape[1] != 3:
+            raise ValueError("verts must be (V, 3)")
+        cur = torch.cuda.current_stream(dev)
+        side = _side_streams.get(dev.index)
+        if side is None:
+            side = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+        with _on_device(dev):
+            self.buf = torch.empty(int(lib.arah_body_bytes()), dtype=torch.uint8, device=dev)
+            side.wait_stream(cur)                       # the vertices (and the recycled buffer) are the caller's stream's
+            self.buf.record_stream(side)
+            self.verts.record_stream(side)
+            _check(lib.arah_prepare_body(_ptr(self.verts), C.c_int32(int(self.verts.shape[0])), _ptr(self.buf),
+                                         C.c_size_t(self.buf.numel()), C.c_void_p(side.cuda_stream)), "arah_prepare_body")
+            self.done = torch.cuda.Event()
+            self.done.record(side)
+        self.device = dev
+
+
 class Frame:
     """Packed per-frame state on the device (MFMA-ordered weights, padded vertices)."""
 
     def __init__(self, sdf_layers, film_freq, film_phase, skin_layers, color_layers, color_mode, pose_vec, beta,
-                 verts, vert_weights, bones, trans, center, coord_min, coord_max, precision=None):
+                 verts, vert_weights, bones, trans, center, coord_min, coord_max, precision=None, body_tables=None):
         require_gpu()
         lib = load_library()
         dev = verts.device
@@ -307,6 +340,12 @@ class Frame:
         body.trans, body.center = _ptr(own(scalar_tensor(trans, 3))), _ptr(own(scalar_tensor(center, 3)))
         body.coord_min, body.coord_max = _ptr(own(scalar_tensor(coord_min, 1))), _ptr(own(scalar_tensor(coord_max, 1)))
         body.n_verts = int(verts.shape[0])
+        self.body_tables = body_tables
+        if body_tables is not None:
+            if body_tables.device != dev or tuple(body_tables.verts.shape) != tuple(self.verts.shape):
+                raise ValueError("body_tables were built for another body / device")
+            torch.cuda.current_stream(dev).wait_event(body_tables.done)
+            body.prepared = body_tables.buf.data_ptr()
         _same_device(*keep)
         nbytes = lib.arah_frame_bytes(C.byref(nets), C.byref(body))
         self.handle = ArahFrame()

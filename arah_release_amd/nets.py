@@ -241,15 +241,18 @@ class HierarchicalPoseEncoder(nn.Module):
         W2 = torch.stack([self.layers[j][2].weight for j in range(Jn)])        # (J, 6, 19)
         b2 = torch.stack([self.layers[j][2].bias for j in range(Jn)]).unsqueeze(1)
         feats = [None] * Jn
-        for level in self._levels():
-            assert level == list(range(level[0], level[-1] + 1))               # SMPL numbers its joints level by level
-            sl = slice(level[0], level[-1] + 1)
+        levels = self._levels()
+        sizes = [len(l) for l in levels]
+        assert [j for l in levels for j in l] == list(range(Jn))               # SMPL numbers its joints level by level
+        parts = [t.split(sizes) for t in (own, W1, b1, W2, b2)]                # one backward node per stacked tensor
+        for li, level in enumerate(levels):
+            own_l, W1_l, b1_l, W2_l, b2_l = (p[li] for p in parts)
             up = torch.stack([glob if self.parents[j] < 0 else feats[self.parents[j]] for j in level])   # (k, B, 6)
-            x = torch.cat([own[sl], up], dim=-1)                               # (k, B, 19)
-            h = torch.relu(torch.baddbmm(b1[sl], x, W1[sl].transpose(1, 2)))
-            f = torch.baddbmm(b2[sl], h, W2[sl].transpose(1, 2))               # (k, B, 6)
-            for n, j in enumerate(level):
-                feats[j] = f[n]
+            x = torch.cat([own_l, up], dim=-1)                                 # (k, B, 19)
+            h = torch.relu(torch.baddbmm(b1_l, x, W1_l.transpose(1, 2)))
+            f = torch.baddbmm(b2_l, h, W2_l.transpose(1, 2))                   # (k, B, 6)
+            for j, fj in zip(level, f.unbind(0)):
+                feats[j] = fj
         return torch.cat(feats, dim=-1)
 
     def _levels(self):

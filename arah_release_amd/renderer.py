@@ -51,7 +51,7 @@ def _mlp_layers(module):
 
 
 def build_frame(sdf_network, skinning_model, rendering_network, deviation_network, pose_cond, smpl_verts,
-                skinning_weights, bone_transforms, trans, coord_min, coord_max, center, precision=None):
+                skinning_weights, bone_transforms, trans, coord_min, coord_max, center, precision=None, body_tables=None):
     """Pack one temporal frame for the kernels (weights emitted by the hypernetwork + body).
     precision: hip.PRECISION_SPLIT_F16 / hip.PRECISION_FP32; None = env ARAH_PRECISION (default split)."""
     with torch.no_grad():
@@ -79,7 +79,7 @@ def build_frame(sdf_network, skinning_model, rendering_network, deviation_networ
         return hip.Frame(sdf_layers, freq, phase, skin_layers, color_layers, mode, pose_vec, beta,
                          smpl_verts[0], skinning_weights[0], bone_transforms[0], trans.reshape(-1)[:3],
                          center.reshape(-1)[:3], coord_min.reshape(-1)[:1], coord_max.reshape(-1)[:1],
-                         precision=precision)
+                         precision=precision, body_tables=body_tables)
 
 
 class BodyRayTracing(nn.Module):
@@ -198,7 +198,7 @@ class IDHRNetwork(nn.Module):
         if ray_dirs.is_cuda:   # (CPU: only reachable with a stubbed ray tracer, e.g. the gloo DDP test; autograd loop D)
             frame = build_frame(sdf_network, self.skinning_model, self.rendering_network, self.deviation_network,
                                 pose_cond, input["smpl_verts"], input["skinning_weights"], input["bone_transforms"],
-                                input["trans"], cmin, cmax, center)
+                                input["trans"], cmin, cmax, center, body_tables=input.get("_body_tables"))
         with torch.no_grad():
             xn, _, _, s_pts, s_z, s_T, s_mask = self.ray_tracer(
                 sdf_network, self.skinning_model, cam_loc=cam_loc, ray_directions=ray_dirs,
@@ -286,7 +286,8 @@ class IDHRNetwork(nn.Module):
         frame = build_frame(input["sdf_network"], self.skinning_model, self.rendering_network,
                             self.deviation_network, input["pose_cond"], input["smpl_verts"],
                             input["skinning_weights"], input["bone_transforms"], input["trans"],
-                            input["coord_min"], input["coord_max"], input["center"], precision=self._precision)
+                            input["coord_min"], input["coord_max"], input["center"], precision=self._precision,
+                            body_tables=input.get("_body_tables"))
         self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
         ws = self.ray_tracer.workspace(dev)
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
@@ -390,6 +391,10 @@ class MetaAvatarRender(nn.Module):
                          "rots": rots[0].unsqueeze(0), "Jtrs": Jtrs[0].unsqueeze(0)}
         if "geo_latent_code_idx" in inputs:
             decoder_input["latent"] = self.latent(inputs["geo_latent_code_idx"])
+        if dev.type == "cuda" and os.environ.get("ARAH_EARLY_BODY_TABLES", "1") != "0":
+            # the nearest-vertex tables need only the posed body: build them now, on a side stream, next to the pose
+            # encoder and the hypernetwork (hip.BodyTables)
+            inputs["_body_tables"] = hip.BodyTables(inputs["smpl_verts"][0])
         if (self.pose_input_noise or self.view_input_noise) and not eval:
             if np.random.uniform() <= 0.5:   # models/__init__.py:157-174
                 if self.pose_input_noise:

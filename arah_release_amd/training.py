@@ -78,7 +78,8 @@ def hierarchical_softmax(x):
     if key not in _HSOFTMAX_PATHS:
         _HSOFTMAX_PATHS[key] = torch.tensor(_hsoftmax_paths(), dtype=torch.long, device=x.device)
     paths = _HSOFTMAX_PATHS[key]                                   # (24, depth)
-    cols = F_[:, paths.t().reshape(-1)].reshape(-1, paths.shape[1], 24).unbind(1)   # one backward node for all of them
+    # index_select: its backward is one index_add (advanced indexing would sort 240 indices per row of a 1e5-row matrix)
+    cols = F_.index_select(1, paths.t().reshape(-1)).reshape(-1, paths.shape[1], 24).unbind(1)
     out = cols[0]
     for c in cols[1:]:                                             # left to right, the order the recursion multiplies in
         out = out * c

@@ -106,6 +106,9 @@ typedef struct ArahBody {
     const float* coord_min;     /* [1] */
     const float* coord_max;     /* [1] */
     int32_t n_verts;            /* <= 6912 */
+    const void* prepared;       /* NULL, or a buffer filled by arah_prepare_body for these verts: arah_prepare_frame then
+                                   skips the nearest-vertex tables (its kernels read them from here; keep it alive with the
+                                   frame, and order the stream that built it before the frame's stream) */
 } ArahBody;
 
 typedef struct ArahSampling {
@@ -183,6 +186,12 @@ typedef struct ArahCounters {
 } ArahCounters;
 
 /* ---- frame preparation ------------------------------------------------------------------ */
+/* Optional early half: the nearest-vertex tables of a posed body (what ray_tracing.py:382-400 asks pytorch3d's
+ * knn_points for, per call) depend on the vertices only.  arah_prepare_body builds them into a caller buffer of
+ * arah_body_bytes() bytes (256-byte aligned) on `stream` -- typically a side stream, while the caller's stream runs the
+ * pose encoder and the hypernetwork; pass the buffer as ArahBody.prepared to arah_prepare_frame. */
+size_t arah_body_bytes(void);
+int arah_prepare_body(const float* verts, int32_t n_verts, void* body_buf, size_t body_bytes, void* stream);
 size_t arah_frame_bytes(const ArahNets* h_nets, const ArahBody* h_body);
 int arah_prepare_frame(const ArahNets* h_nets, const ArahBody* h_body, void* frame_buf, size_t frame_bytes,
                        ArahFrame* h_frame_out, void* stream);

@@ -53,7 +53,7 @@ def test_struct_sizes_match_header():
     from arah_release_amd import hip
     # pointers ..., col_mode, n_pose (8 bytes), beta (device pointer), precision (+ 4 bytes of tail padding)
     assert C.sizeof(hip.ArahNets) == 8 * (7 + 7 + 2 + 5 + 5 + 6 + 6 + 1) + 8 + 8 + 8
-    assert C.sizeof(hip.ArahBody) == 8 * 7 + 8   # seven device pointers, n_verts (+ padding)
+    assert C.sizeof(hip.ArahBody) == 8 * 7 + 8 + 8   # seven device pointers, n_verts (+ padding), prepared tables
     n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 2 + 8 + 6 + 4 + 3 + 1   # sdf, skin (+2: point-owning-wave operands), colour (+6 transposed), knn, body, scalars
     assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * 3 + 4   # three ints (+ padding)
     assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
@@ -256,6 +256,47 @@ def test_nearest_inverse_lbs(ctx, scene):
     idx_wave, x_wave, T_wave = hip.nearest_inverse_lbs(ctx["frame"], ctx["ws"], far.to(ctx["dev"]))
     assert torch.equal(idx_wave, idx_bulk[:1500]) and torch.equal(x_wave, x_bulk[:1500]) and torch.equal(T_wave, T_bulk[:1500])
     assert (idx_wave.cpu().long() == O.nearest_vertex(fr, far)).float().mean() >= 0.999
+
+
+@gpu
+def test_body_tables_built_early_are_the_inline_ones(ctx, scene):
+    """arah_prepare_body on a side stream (hip.BodyTables, what the model entry does before the hypernetwork) against the
+    tables arah_prepare_frame builds itself: the same nearest vertices / inverse-LBS transforms bit for bit, and the same
+    rendered frame through the model entry with the early build switched off."""
+    import os
+    from arah_release_amd import hip, renderer
+    dev, model = ctx["dev"], ctx["model"]
+    inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
+    tables = hip.BodyTables(inputs["smpl_verts"][0])
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder, model.deviation_decoder,
+                                     pose_cond, inputs["smpl_verts"], inputs["skinning_weights"], inputs["bone_transforms"],
+                                     inputs["trans"], inputs["coord_min"], inputs["coord_max"], inputs["center"],
+                                     body_tables=tables)
+    gen = torch.Generator().manual_seed(11)
+    pts = (inputs["smpl_verts"][0].cpu()[torch.randint(0, 6890, (3000,), generator=gen)]
+           + torch.randn(3000, 3, generator=gen) * 0.05).to(dev)
+    a = hip.nearest_inverse_lbs(frame, ctx["ws"], pts)
+    b = hip.nearest_inverse_lbs(ctx["frame"], ctx["ws"], pts)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    with pytest.raises(ValueError):
+        renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder, model.deviation_decoder, pose_cond,
+                             inputs["smpl_verts"][:, :100], inputs["skinning_weights"][:, :100], inputs["bone_transforms"],
+                             inputs["trans"], inputs["coord_min"], inputs["coord_max"], inputs["center"], body_tables=tables)
+    model.eval()
+    with torch.no_grad():
+        early = model(scene.make_inputs(32, 32, frame_idx=1, device=dev), eval=True)["rgb_values"]
+        os.environ["ARAH_EARLY_BODY_TABLES"] = "0"
+        try:
+            inline = model(scene.make_inputs(32, 32, frame_idx=1, device=dev), eval=True)["rgb_values"]
+        finally:
+            del os.environ["ARAH_EARLY_BODY_TABLES"]
+    assert torch.equal(early, inline)
 
 
 @gpu

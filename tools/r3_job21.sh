@@ -1,0 +1,12 @@
+#!/bin/bash
+TAG=${1:-r3x}
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
+timeout 1500 python -m pytest tests -m gpu -x -q --timeout=300 > $OUT/tests_gpu.log 2>&1
+echo "gpu tests rc=$?"; tail -4 $OUT/tests_gpu.log
+timeout 900 python tools/abn.py --rounds 2 base=- inline=-,ARAH_EARLY_BODY_TABLES=0 2>&1 | tee $OUT/abn.txt
+timeout 300 python tools/train_bench.py --steps 8 --warmup 2 2>&1 | tail -1 | tee $OUT/train_bench.json
+ARAH_EARLY_BODY_TABLES=0 timeout 300 python tools/train_bench.py --steps 8 --warmup 2 2>&1 | tail -1 | tee $OUT/train_bench_inline.json
