@@ -441,18 +441,20 @@ def _walk_tensors(obj):
             yield from _walk_tensors(v)
 
 
-def render_sequence(model, frames, n_streams=1, **forward_kwargs):
-    """Render independent frames (a test sequence, reference test.py / lightning_model.py:320).  DEFAULT: one frame at a time
-    on the caller's stream.  n_streams > 1 is OPT-IN: the HIP runtime has stopped accepting launches once in about twenty
-    multi-stream bench.py passes on the MI355X box (host blocked inside hipLaunchKernel, nothing wrong on the device; DESIGN.md
-    section 4) and a product API must not deadlock -- until that is understood the pipelined form is for measurements only.
-    With `n_streams` frames
-    in flight, frame k runs on HIP stream k mod n_streams with its own scratch, so that the latency-bound stretches of one
+def render_sequence(model, frames, n_streams=3, **forward_kwargs):
+    """Render independent frames (a test sequence, reference test.py / lightning_model.py:320) with `n_streams` of them in
+    flight: frame k runs on HIP stream k mod n_streams with its own scratch, so that the latency-bound stretches of one
     frame (the tails of sphere tracing and of the joint root find: a few hundred live rays, ~60 us of kernel latency per
     step) run under the other frames' wide kernels.  Per-frame results are bit-identical to one-at-a-time rendering
-    (tests/test_zz_render_sequence.py); 56 -> 49 ms per 512x512 frame on one
-    MI355X.  frames: iterable of input dicts (resident on one GPU); returns the list of output dicts, usable on the
-    caller's current stream.  The caller's stream is synchronised once at the start (see below).  model(inputs, **forward_kwargs) is called under torch.no_grad()."""
+    (tests/test_zz_render_sequence.py); ~46 -> ~40 ms per 512x512 frame on one MI355X.  n_streams=1: one frame at a time
+    on the caller's stream.
+    Round 2 saw the HIP runtime of this image (ROCm 7.2) stop accepting launches with a thousand launches queued behind
+    a cross-stream wait; the loop below never lets that state arise (the caller's stream is drained once at the start,
+    a stream takes its next frame only when its previous one has finished: at most n_streams frames, ~450 launches
+    each, are ever queued), and three frames in flight became the default after 200 consecutive eight-frame passes
+    (1600 frames, bit-identical images) came back clean (tools/stress_streams.py, profiles/r03_streams_soak.txt).
+    frames: iterable of input dicts (resident on one GPU); returns the list of output dicts, usable on the caller's
+    current stream.  model(inputs, **forward_kwargs) is called under torch.no_grad()."""
     frames = list(frames)
     if not frames:
         return []

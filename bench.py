@@ -127,12 +127,14 @@ def main():
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=3,
                     help="frames in flight in the timed region of every pass (renderer.render_sequence: frame k on HIP stream "
-                         "k mod N, own scratch each); default 1 = strictly one frame after the other")
-    ap.add_argument("--pipelined-streams", type=int, default=3,
-                    help="N == 1 only: after everything else, the default path once more with this many frames in flight, "
-                         "under a watchdog (object 'frames_in_flight'); 0 = skip")
+                         "k mod N, own scratch each) -- the product's default since the 200-pass soak of round 3 "
+                         "(profiles/r03_streams_soak.txt); 1 = strictly one frame after the other (also measured, first, "
+                         "and reported as 'one_frame_at_a_time')")
+    ap.add_argument("--pipelined-streams", type=int, default=0,
+                    help="with --streams 1 only: after everything else, the default path once more with this many frames in "
+                         "flight, under a watchdog (object 'frames_in_flight'); 0 = skip")
     ap.add_argument("--beta", type=float, default=None,
                     help="override the VolSDF beta of the synthetic subject (|deviation_decoder.variance|, default 1e-3 = the "
                          "reference's initial value): the share of samples with density > 0, hence what exact lazy shading "
@@ -375,19 +377,24 @@ def run(args, rt):
     default_engine = os.environ.get("ARAH_PRECISION", "split")
     split = rt.split_engine()
     with torch.no_grad():
-        elapsed, counters, dens_ms = timed_pass(False, default_engine)          # the product's default path
-        if world == 1:   # what the watchdog of main() prints if a LATER pass never returns (secondary lines only)
+        elapsed_one = None
+        if args.streams > 1:                                    # the same frames strictly one after the other, FIRST:
+            elapsed_one, _, _ = timed_pass(False, default_engine, n_streams=1)   # it is what the watchdog falls back on
+        first = elapsed_one
+        if first is None:
+            elapsed, counters, dens_ms = timed_pass(False, default_engine)      # the product's default path
+            first = elapsed
+        if world == 1:   # what the watchdog of main() prints if a LATER pass never returns
             rt.partial_line = {
-                "metric": "rendered rays/sec", "value": n_rays_local / elapsed, "unit": "rays/s", "n_gpus": 1,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+                "metric": "rendered rays/sec", "value": n_rays_local / first, "unit": "rays/s", "n_gpus": 1,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * first / max(args.steps, 1),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": WORKLOAD_NAMES.get(args.config, args.config) + " test.py inference, %dx%d, %d samples/ray"
                                        % (args.size, args.size, args.n_steps), "config": args.config},
-                "note": "PARTIAL LINE: a pass after the default one did not return (watchdog); roofline / cpu_baseline objects "
-                        "were not reached"}
-        elapsed_one = None
-        if args.streams > 1:                                    # the same frames strictly one after the other
-            elapsed_one, _, _ = timed_pass(False, default_engine, n_streams=1)
+                "note": "PARTIAL LINE: a pass after the first one did not return (watchdog); roofline / cpu_baseline objects "
+                        "were not reached" + ("; value = one frame at a time" if elapsed_one else "")}
+        if elapsed_one is not None:
+            elapsed, counters, dens_ms = timed_pass(False, default_engine)      # the product's default path: frames in flight
         elapsed_full = elapsed_exact = elapsed_strict = None
         if args.passes == "all":
             elapsed_full, counters_full, shade_ms = timed_pass(True, default_engine)  # shade every valid sample, like the reference

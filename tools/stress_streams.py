@@ -1,0 +1,60 @@
+"""Frames-in-flight soak:  python tools/stress_streams.py [--runs 200] [--frames 8] [--streams 3] [--size 512]
+`runs` consecutive renderer.render_sequence passes of `frames` independent frames with `streams` of them in flight, each
+pass under a watchdog (a pass that does not come back within --limit seconds is a stall: the process reports how far it
+got and exits 3).  Prints one line per 10 passes and a JSON summary; profiles/r03_streams_soak.txt is its output."""
+import argparse, json, os, sys, threading, time
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--runs", type=int, default=200)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=3)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--limit", type=float, default=60.0)
+    args = ap.parse_args()
+    import __graft_entry__
+    __graft_entry__.build()
+    from arah_release_amd import config, renderer, synthetic
+    dev = torch.device("cuda", 0)
+    model, cfg = config.build_synthetic_model("zju377_mono", 64, 16, 16, device=dev)
+    model.eval()
+    scene = synthetic.SyntheticScene(0)
+    frames = [scene.make_inputs(args.size, args.size, frame_idx=k, device=dev) for k in range(args.frames)]
+    state = {"run": -1, "t0": time.time()}
+
+    def stalled():
+        print(json.dumps({"clean_runs": state["run"], "stalled_in_run": state["run"] + 1, "runs": args.runs,
+                          "streams": args.streams, "frames_per_run": args.frames}), flush=True)
+        os._exit(3)
+
+    ref = None
+    t_all = time.time()
+    for r in range(args.runs):
+        dog = threading.Timer(args.limit, stalled)
+        dog.daemon = True
+        dog.start()
+        t0 = time.perf_counter()
+        outs = renderer.render_sequence(model, [dict(f) for f in frames], n_streams=args.streams, eval=True)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        dog.cancel()
+        state["run"] = r
+        img = outs[-1]["rgb_values"]
+        if ref is None:
+            ref = img.clone()
+        elif not torch.equal(ref, img):
+            print("run %d: last frame differs from run 0" % r, flush=True)
+            sys.exit(4)
+        if r % 10 == 9:
+            print("runs %3d-%3d clean, last pass %.1f ms per frame" % (r - 9, r, 1e3 * dt / args.frames), flush=True)
+    print(json.dumps({"clean_runs": args.runs, "runs": args.runs, "streams": args.streams, "frames_per_run": args.frames,
+                      "size": args.size, "seconds": round(time.time() - t_all, 1), "bit_identical_across_runs": True}))
+
+
+if __name__ == "__main__":
+    main()
