@@ -2267,12 +2267,13 @@ __global__ __launch_bounds__(kThreads, NT > 4 ? 2 : 4) void k_density(FrameDev f
 // loop D: SDF value + normal (reverse sweep) + colour MLP + VolSDF density per valid sample
 // (IDR:291-368), then per-ray compositing (IDR:370-394)
 // ------------------------------------------------------------------------------------------
-template <bool IDR, bool SPLIT>
+// B3 (with SPLIT): the normal sweep and the colour MLP on the bf16 x 3 engine instead of the fp32 MFMA (mlp.hpp)
+template <bool IDR, bool SPLIT, bool B3 = false>
 __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano_view_dirs, const float* dirs,
                                                      const float* pts, const float* T, const int* list,
                                                      const int* count, int n_direct, f32x4* shaded,
                                                      f32x4* spill_all, unsigned long long* ctr_fwd,
-                                                     unsigned long long* ctr_grad, unsigned long long* ctr_col) {
+                                                     unsigned long long* ctr_grad, unsigned long long* ctr_col, B3Nets b3) {
     const BodyConst bc = load_bc(fr);
     typedef ColDims<IDR> D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2302,7 +2303,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
         sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, D::kLdA, spill, dlast, wave, lane);
         sdf_head<SPLIT>(fr.sdf, actA, D::kLdA, outv, 4, tid);
         if (SPLIT) unsplit_rows(actA, D::kLdA, tid);   // the colour MLP (exact engine) reads the feature as fp32
-        sdf_backward(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
+        sdf_backward<B3>(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid, &b3);
         __syncthreads();
         if (tid < kTile) {   // colour-input extras behind the feature: x(3), n(3), [PE4(view) 27], zero pad
             const int id = ids[tid];
@@ -2360,7 +2361,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
             for (; k < D::kInPad - 256; ++k) e[k] = 0.f;
         }
         __syncthreads();
-        color_mlp<IDR>(fr.col, actA, actB, rgbv, 4, wave, lane, tid);
+        color_mlp<IDR, B3>(fr.col, actA, actB, rgbv, 4, wave, lane, tid, nullptr, &b3);
         __syncthreads();
         if (tid == 0) {
             const int cnt = min(kTile, n - tile * kTile);
@@ -2705,12 +2706,18 @@ int setup_attributes() {
     allow_lds(k_shade<false, true>, lds_shade<false>());
     allow_lds(k_shade<true, false>, lds_shade<true>());
     allow_lds(k_shade<true, true>, lds_shade<true>());
+    allow_lds((k_shade<false, true, true>), lds_shade<false>());
+    allow_lds((k_shade<true, true, true>), lds_shade<true>());
     allow_lds(k_color_eval<false>, lds_color<false>());
     allow_lds(k_color_eval<true>, lds_color<true>());
-    allow_lds(k_shade_train<false, false>, lds_shade_train<false>());
-    allow_lds(k_shade_train<false, true>, lds_shade_train<false>());
-    allow_lds(k_shade_train<true, false>, lds_shade_train<true>());
-    allow_lds(k_shade_train<true, true>, lds_shade_train<true>());
+    allow_lds(k_shade_train<false, false, false>, lds_shade_train<false>());
+    allow_lds(k_shade_train<false, true, false>, lds_shade_train<false>());
+    allow_lds(k_shade_train<true, false, false>, lds_shade_train<true>());
+    allow_lds(k_shade_train<true, true, false>, lds_shade_train<true>());
+    allow_lds(k_shade_train<false, false, true>, lds_shade_train<false>());
+    allow_lds(k_shade_train<false, true, true>, lds_shade_train<false>());
+    allow_lds(k_shade_train<true, false, true>, lds_shade_train<true>());
+    allow_lds(k_shade_train<true, true, true>, lds_shade_train<true>());
     if (g_attr_failed) return ARAH_E_LAUNCH;
     done[dev] = true;
     return ARAH_OK;
@@ -2765,12 +2772,58 @@ RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
 }
 
 // ---- frame buffer layout -----------------------------------------------------------------
+// ---- bf16 x 3 operands of the training kernels: made from the fp32 packings (any orientation / column permutation) ----
+constexpr int kB3Count = 22;
+struct B3Src {
+    int m_tiles, kc16;
+};
+// 0..4 sdf_wp, 5..9 sdf_wpT, 10..15 colour w0p w1p w2p w3ap w3bp w4p, 16..21 colour w0pT w1pT w2pT w3apT w3bpT w4pT
+inline B3Src b3_source(int i, int kc0) {
+    if (i < 10) return B3Src{16, 16};
+    switch (i) {
+    case 10: return B3Src{16, kc0};
+    case 11: return B3Src{16, 16};
+    case 12: return B3Src{8, 16};
+    case 13: return B3Src{16, kc0};
+    case 14: return B3Src{16, 8};
+    case 15: return B3Src{16, 16};
+    case 16: return B3Src{kc0, 16};
+    case 17: return B3Src{16, 16};
+    case 18: return B3Src{16, 8};
+    case 19: return B3Src{kc0, 16};
+    case 20: return B3Src{8, 16};
+    default: return B3Src{16, 16};
+    }
+}
+
+// packed fp32 (k_pack: dst[((mt*KC16 + kc)*64 + lane)] = W[mt*16 + (lane&15)][kc*16 + 4 (lane>>4) + 0..3])
+//   -> bf16 fragments dst[((mt*KC32 + kc)*2 + s)*64 + lane], lane (j, g) holds W[mt*16 + j][kc*32 + 8g .. +7], zero beyond K
+__global__ void k_b3_from_packed(bf16x8* __restrict__ dst, const float* __restrict__ packed, int m_tiles, int KC16) {
+    const int KC32 = (KC16 + 1) / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m_tiles * KC32 * 64) return;
+    const int lane = idx & 63, tile = idx >> 6, kc = tile % KC32, mt = tile / KC32;
+    const int j = lane & 15, g = lane >> 4;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = kc * 32 + 8 * g + e, kc16 = col >> 4, gg = (col & 15) >> 2, r = col & 3;
+        const float w = kc16 < KC16 ? packed[((size_t)(mt * KC16 + kc16) * 64 + gg * 16 + j) * 4 + r] : 0.f;
+        const __bf16 h = (__bf16)w;
+        hi[e] = h;
+        lo[e] = (__bf16)(w - (float)h);
+    }
+    dst[(size_t)(tile * 2 + 0) * 64 + lane] = hi;
+    dst[(size_t)(tile * 2 + 1) * 64 + lane] = lo;
+}
+
 struct FrameLayout {
     size_t sdf_w0, sdf_wp[5], sdf_wpT[5], sdf_w6, sdf_b6, sdf_bias, sdf_freq, sdf_phase;
     size_t sdf_wps[5], sdf_fw, sdf_pw, sdf_fws, sdf_amax;
     size_t skin_w0, skin_wp[3], skin_w4p, skin_bias, skin_wps[4], skin_scales, skin_amax, skin_wpr, skin_wconsts;
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
     size_t col_w0pT, col_w1pT, col_w2pT, col_w3apT, col_w3bpT, col_w4pT;   // transposed packings (training backward)
+    size_t b3[kB3Count];   // bf16 hi/lo fragments of 22 of the packed matrices (training: gemm_acc_b3), order of B3Src
     size_t verts4, knn_spheres, knn_grid, knn_cells, scalars;
     size_t bytes;
 };
@@ -2822,6 +2875,10 @@ FrameLayout frame_layout(int col_mode) {
     L.col_w3apT = take((size_t)kin_pad * 256);
     L.col_w3bpT = take(128 * 256);
     L.col_w4pT = take(256 * 256);
+    for (int i = 0; i < kB3Count; ++i) {
+        const B3Src e = b3_source(i, kin_pad / 16);
+        L.b3[i] = take((size_t)e.m_tiles * ((e.kc16 + 1) / 2) * 512);
+    }
     L.verts4 = take((size_t)kMaxClusters * kClusterSize * 4);
     L.knn_spheres = take((size_t)kMaxClusters * 4);
     L.knn_grid = take(sizeof(GridInfo) / 4);
@@ -2878,6 +2935,29 @@ void launch_body_tables(const float* verts, int n_verts, const BodyTables& t, hi
 }
 
 }  // namespace
+
+static B3Nets b3_of(const ArahFrame& f) {
+    B3Nets b;
+    for (int i = 0; i < 5; ++i) {
+        b.sdf_wp[i] = reinterpret_cast<const bf16x8*>(f.b3[i]);
+        b.sdf_wpT[i] = reinterpret_cast<const bf16x8*>(f.b3[5 + i]);
+    }
+    for (int i = 0; i < 6; ++i) {
+        b.col[i] = reinterpret_cast<const bf16x8*>(f.b3[10 + i]);
+        b.colT[i] = reinterpret_cast<const bf16x8*>(f.b3[16 + i]);
+    }
+    return b;
+}
+
+// ARAH_SHADE_ENGINE=fp32: normal sweep and colour MLP of loop D on the fp32 MFMA (rounds 1-2); default: bf16 x 3 for
+// frames prepared for the split engine (ARAH_PRECISION_FP32 frames are fp32 throughout)
+static bool shade_b3() {
+    static const bool on = [] {
+        const char* e = getenv("ARAH_SHADE_ENGINE");
+        return !(e && strcmp(e, "fp32") == 0);
+    }();
+    return on;
+}
 
 // =============================================================================================
 // C ABI
@@ -3027,6 +3107,19 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, cb + 896, nets->col_b[4], 256, 256);
         hipLaunchKernelGGL(k_copy, dim3(1), dim3(4), 0, s, cb + 1152, nets->col_b[5], 3, 4);
     }
+    // ---- bf16 hi/lo fragments for loop D's normal sweep (W^T of the trunk) and colour MLP: eleven small launches
+    if (nets->precision == ARAH_PRECISION_SPLIT_F16 && shade_b3()) {
+        const size_t src[kB3Count] = {L.sdf_wp[0], L.sdf_wp[1], L.sdf_wp[2], L.sdf_wp[3], L.sdf_wp[4],
+                                      L.sdf_wpT[0], L.sdf_wpT[1], L.sdf_wpT[2], L.sdf_wpT[3], L.sdf_wpT[4],
+                                      L.col_w0p, L.col_w1p, L.col_w2p, L.col_w3ap, L.col_w3bp, L.col_w4p,
+                                      L.col_w0pT, L.col_w1pT, L.col_w2pT, L.col_w3apT, L.col_w3bpT, L.col_w4pT};
+        for (int i = 5; i < 16; ++i) {
+            const B3Src e = b3_source(i, kc0);
+            const int total = e.m_tiles * ((e.kc16 + 1) / 2) * 64;
+            hipLaunchKernelGGL(k_b3_from_packed, dim3((total + 255) / 256), dim3(256), 0, s,
+                               reinterpret_cast<bf16x8*>(base + L.b3[i]), (const float*)P(src[i]), e.m_tiles, e.kc16);
+        }
+    }
     // ---- body
     if (!body->trans || !body->center || !body->coord_min || !body->coord_max) return ARAH_E_BADARG;
     hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, s, P(L.scalars), body->trans, body->center, body->coord_min,
@@ -3081,6 +3174,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->col_w3apT = P(L.col_w3apT);
     out->col_w3bpT = P(L.col_w3bpT);
     out->col_w4pT = P(L.col_w4pT);
+    for (int i = 0; i < kB3Count; ++i) out->b3[i] = base + L.b3[i];
     out->verts4 = bt.verts4;
     out->knn_spheres = bt.spheres;
     out->knn_grid = bt.grid;
@@ -3530,14 +3624,24 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
         scount = &w.counts[1];
     }
     if (g_shade_ev0) hipEventRecord(g_shade_ev0, s);
-    if (f->col_mode == ARAH_COLOR_IDR)
+    const B3Nets b3 = b3_of(*f);
+    if (fd.split && shade_b3()) {
+        if (f->col_mode == ARAH_COLOR_IDR)
+            hipLaunchKernelGGL((k_shade<true, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade<true>()), s, fd, S,
+                               cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
+                               &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
+        else
+            hipLaunchKernelGGL((k_shade<false, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade<false>()), s, fd, S,
+                               cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
+                               &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
+    } else if (f->col_mode == ARAH_COLOR_IDR)
         LAUNCH_ENGINE(fd.split, (k_shade<true, true>), (k_shade<true, false>), dim3(g), dim3(kThreads), lds_shade<true>(),
                       s, fd, S, cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
-                      &w.ctr->n_sdf_grad, &w.ctr->n_col);
+                      &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
     else
         LAUNCH_ENGINE(fd.split, (k_shade<false, true>), (k_shade<false, false>), dim3(g), dim3(kThreads),
                       lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill,
-                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col);
+                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
     if (g_shade_ev1) hipEventRecord(g_shade_ev1, s);
     hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);
@@ -3562,6 +3666,15 @@ static ColNetT colT_of(const ArahFrame& f) {
     return ColNetT{f.col_w0pT, f.col_w1pT, f.col_w2pT, f.col_w3apT, f.col_w3bpT, f.col_w4pT};
 }
 
+// ARAH_TRAIN_ENGINE=fp32: every product of the training kernels on the fp32 MFMA (round 2); default: bf16 x 3
+static bool train_b3() {
+    static const bool on = [] {
+        const char* e = getenv("ARAH_TRAIN_ENGINE");
+        return !(e && strcmp(e, "fp32") == 0);
+    }();
+    return on;
+}
+
 size_t arah_shade_train_slab_bytes(void) { return (size_t)kMaxGrid / 2 * kTrainSlabPerWg * sizeof(f32x4); }
 
 int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* sdf, float* rgb4, void* workspace,
@@ -3580,12 +3693,17 @@ int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* s
     to.sdf = sdf;
     to.rgb = rgb4;
     const int g = min(grid_for(in->n, kTile), kMaxGrid / 2);   // one workgroup per CU (140 KB of LDS)
-    if (f->col_mode == ARAH_COLOR_IDR)
-        hipLaunchKernelGGL((k_shade_train<true, false>), dim3(g), dim3(kThreads), lds_shade_train<true>(), s, fd,
-                           colT_of(*f), ti, to, w.spill, (f32x4*)nullptr);
-    else
-        hipLaunchKernelGGL((k_shade_train<false, false>), dim3(g), dim3(kThreads), lds_shade_train<false>(), s, fd,
-                           colT_of(*f), ti, to, w.spill, (f32x4*)nullptr);
+    const bool idr = f->col_mode == ARAH_COLOR_IDR;
+#define ARAH_LAUNCH_TRAIN(IDR_, BWD_, B3_, SLAB_)                                                                        \
+    hipLaunchKernelGGL((k_shade_train<IDR_, BWD_, B3_>), dim3(g), dim3(kThreads), lds_shade_train<IDR_>(), s, fd,        \
+                       colT_of(*f), b3_of(*f), ti, to, w.spill, SLAB_)
+    if (train_b3()) {
+        if (idr) ARAH_LAUNCH_TRAIN(true, false, true, (f32x4*)nullptr);
+        else ARAH_LAUNCH_TRAIN(false, false, true, (f32x4*)nullptr);
+    } else {
+        if (idr) ARAH_LAUNCH_TRAIN(true, false, false, (f32x4*)nullptr);
+        else ARAH_LAUNCH_TRAIN(false, false, false, (f32x4*)nullptr);
+    }
     return check_launch();
 }
 
@@ -3620,12 +3738,30 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
     if (hipMemsetAsync(gr->film_freq, 0, 6 * 256 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
     if (hipMemsetAsync(gr->film_phase, 0, 6 * 256 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
     const int g = min(grid_for(in->n, kTile), kMaxGrid / 2);
-    if (f->col_mode == ARAH_COLOR_IDR)
-        hipLaunchKernelGGL((k_shade_train<true, true>), dim3(g), dim3(kThreads), lds_shade_train<true>(), s, fd,
-                           colT_of(*f), ti, to, w.spill, reinterpret_cast<f32x4*>(slab));
-    else
-        hipLaunchKernelGGL((k_shade_train<false, true>), dim3(g), dim3(kThreads), lds_shade_train<false>(), s, fd,
-                           colT_of(*f), ti, to, w.spill, reinterpret_cast<f32x4*>(slab));
+    const bool idr = f->col_mode == ARAH_COLOR_IDR;
+    f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
+    if (train_b3()) {
+        // bf16 hi/lo fragments of the matrices of the backward-direction products (W and W^T of the SDF trunk, W^T of the
+        // colour MLP), made here from the frame's fp32 packings: sixteen small launches per training step, none in inference
+        const int kc0 = (idr ? ColDims<true>::kInPad : ColDims<false>::kInPad) / 16;
+        const float* src[kB3Count] = {f->sdf_wp[0], f->sdf_wp[1], f->sdf_wp[2], f->sdf_wp[3], f->sdf_wp[4],
+                                      f->sdf_wpT[0], f->sdf_wpT[1], f->sdf_wpT[2], f->sdf_wpT[3], f->sdf_wpT[4],
+                                      f->col_w0p, f->col_w1p, f->col_w2p, f->col_w3ap, f->col_w3bp, f->col_w4p,
+                                      f->col_w0pT, f->col_w1pT, f->col_w2pT, f->col_w3apT, f->col_w3bpT, f->col_w4pT};
+        for (int i = 0; i < kB3Count; ++i) {
+            if (i >= 10 && i < 16) continue;   // forward colour products stay on the fp32 MFMA (train.hpp)
+            const B3Src e = b3_source(i, kc0);
+            const int total = e.m_tiles * ((e.kc16 + 1) / 2) * 64;
+            hipLaunchKernelGGL(k_b3_from_packed, dim3((total + 255) / 256), dim3(256), 0, s,
+                               reinterpret_cast<bf16x8*>(const_cast<void*>(f->b3[i])), src[i], e.m_tiles, e.kc16);
+        }
+        if (idr) ARAH_LAUNCH_TRAIN(true, true, true, slab4);
+        else ARAH_LAUNCH_TRAIN(false, true, true, slab4);
+    } else {
+        if (idr) ARAH_LAUNCH_TRAIN(true, true, false, slab4);
+        else ARAH_LAUNCH_TRAIN(false, true, false, slab4);
+    }
+#undef ARAH_LAUNCH_TRAIN
     return check_launch();
 }
 

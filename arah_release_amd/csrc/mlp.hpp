@@ -429,6 +429,96 @@ __device__ __forceinline__ void gemm_acc_split_pipe(const f16x8* __restrict__ wp
     });
 }
 
+// ---- bf16 x 3 engine (training backward, round 3) ---------------------------------------------------------------
+// The third way to multiply fp32 operands on the matrix pipe: both operands as bf16 hi + bf16 lo, three
+// v_mfma_f32_16x16x32_bf16 (lo x hi, hi x lo, hi x hi).  16 mantissa bits per operand (relative error 2^-16 per product,
+// against 2^-22 for the f16 split) but the exponent range of fp32: no operand scaling, which is what the adjoints and
+// deltas of a backward sweep need (their magnitudes are set by the loss, 1e-7 .. 1e+3 in one step).  The activations stay
+// fp32 in LDS exactly where the fp32 engine reads them; a lane converts its eight consecutive k of a point as it loads them
+// (three vector instructions per element), so a call site only swaps gemm_acc for gemm_any<true, ..>.  Rate: 3 x 16
+// cycles per 16x16x32 product against 8 x 32 on the fp32 MFMA.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct B3Nets {                 // bf16 hi/lo fragments of the packed matrices (k_b3_from_packed), same M-tile / K order
+    const bf16x8* sdf_wp[5];    // W_2..W_6 (tangent pass)
+    const bf16x8* sdf_wpT[5];   // their transposes (reverse sweeps)
+    const bf16x8* col[6];       // colour MLP forward: w0p, w1p, w2p, w3ap, w3bp, w4p
+    const bf16x8* colT[6];      // transposed: w0pT, w1pT, w2pT, w3apT, w3bpT, w4pT
+};
+
+__device__ __forceinline__ void bsplit8(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x0 = i < 2 ? a[2 * i] : b[2 * i - 4], x1 = i < 2 ? a[2 * i + 1] : b[2 * i - 3];
+        const bf16x2 h = __builtin_convertvector(f32x2{x0, x1}, bf16x2);
+        const bf16x2 l = __builtin_convertvector(f32x2{x0 - (float)h[0], x1 - (float)h[1]}, bf16x2);
+        hi[2 * i] = h[0];
+        hi[2 * i + 1] = h[1];
+        lo[2 * i] = l[0];
+        lo[2 * i + 1] = l[1];
+    }
+}
+
+// acc[m][n] += W(M-tiles mt0.., K = 16 KC16) * act(16 NT points), act fp32 rows of ld floats in LDS.
+//   weights : wp[((mt*KC32 + kc)*2 + s)*64 + lane]  (s = 0 hi, 1 lo), lane (j, g) holds W[mt*16 + j][kc*32 + 8g .. +7],
+//             KC32 = ceil(KC16 / 2), zero beyond K
+template <int KC16, int MT, int NT = kNT>
+__device__ __forceinline__ void gemm_acc_b3(const bf16x8* __restrict__ wp, int mt0, const float* act, int ld,
+                                            f32x4 (&acc)[MT][NT], int lane) {
+    constexpr int KC32 = (KC16 + 1) / 2;
+    const int j = lane & 15, g = lane >> 4;
+    const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
+    auto lda = [&](int idx) { return ld_frag<bf16x8>(wp, aoff, idx * 1024); };
+    const bool tail_ok = (KC16 & 1) == 0 || g < 2;   // odd KC16: the last 32-chunk holds 16 columns
+    const float* brow = act + j * ld;
+    bf16x8 ah[MT], al[MT], ahn[MT], aln[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ah[m] = lda((m * KC32) * 2 + 0);
+        al[m] = lda((m * KC32) * 2 + 1);
+    }
+#pragma unroll 2
+    for (int kc = 0; kc < KC32; ++kc) {
+        const int kn = kc + 1 < KC32 ? kc + 1 : kc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ahn[m] = lda((m * KC32 + kn) * 2 + 0);
+            aln[m] = lda((m * KC32 + kn) * 2 + 1);
+        }
+        const bool ok = kc + 1 < KC32 || tail_ok;
+        const float* bp = brow + (ok ? kc * 32 + 8 * g : 0);   // never read past the row
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            f32x4 x0 = *reinterpret_cast<const f32x4*>(bp + n * 16 * ld);
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(bp + n * 16 * ld + 4);
+            if (!ok) x0 = x1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            bf16x8 bh, bl;
+            bsplit8(x0, x1, bh, bl);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {   // small terms first
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl, acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh, acc[m][n], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[m] = ahn[m];
+            al[m] = aln[m];
+        }
+    }
+}
+
+// one call site, two engines
+template <bool B3, int KC16, int MT, int NT = kNT>
+__device__ __forceinline__ void gemm_any(const float* __restrict__ wp, const bf16x8* __restrict__ wpb, int mt0, const float* act,
+                                         int ld, f32x4 (&acc)[MT][NT], int lane) {
+    if constexpr (B3) gemm_acc_b3<KC16, MT, NT>(wpb, mt0, act, ld, acc, lane);
+    else gemm_acc<KC16, MT, NT>(wp, mt0, act, ld, acc, lane);
+}
+
 // 4 consecutive channels of one point, already multiplied by kActScale -> hi/lo planes
 // hi = f16(h) (round to nearest even), lo = f16(h - hi).  The residual is one mixed-precision FMA per channel that
 // reads its f16 operand straight out of the packed hi register and writes the f16 result into its half of the packed
@@ -958,9 +1048,10 @@ __device__ __forceinline__ void sdf_head(const SdfNet& net, const float* act, in
 
 // Reverse sweep for d sdf / d x on the tile (needs sdf_trunk<true> first).
 // bwd: LDS [64][ld] scratch (must not alias the feature buffer).  grad -> out[pt*ostride + 1..3].
+template <bool B3 = false>
 __device__ __forceinline__ void sdf_backward(const SdfNet& net, float* bwd, int ld, const f32x4* spill,
                                              const f32x4 (&dlast)[kSdfMT][kNT], float* out, int ostride, int wave,
-                                             int lane, int tid) {
+                                             int lane, int tid, const B3Nets* b3 = nullptr) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
 #pragma unroll
@@ -978,7 +1069,7 @@ __device__ __forceinline__ void sdf_backward(const SdfNet& net, float* bwd, int 
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<16, kSdfMT>(net.wpT[k], mt0, bwd, ld, acc, lane);
+        gemm_any<B3, 16, kSdfMT>(net.wpT[k], B3 ? b3->sdf_wpT[k] : nullptr, mt0, bwd, ld, acc, lane);
         ARAH_SYNC();
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
@@ -1229,9 +1320,9 @@ struct ColTap {         // training: the colour MLP's input and hidden activatio
 // A: LDS [64][kLdA] full input (feature in cols 0..255, extras after, zero padded); B: LDS [64][260].
 // rgb (after sigmoid) -> out[pt*ostride + 0..2].  Needs a barrier between the writers of A and the call.
 // tap != nullptr (training): A and every hidden activation are streamed out; B holds c5 on return.
-template <bool IDR>
+template <bool IDR, bool B3 = false>
 __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, float* B, float* out, int ostride,
-                                          int wave, int lane, int tid, const ColTap* tap = nullptr) {
+                                          int wave, int lane, int tid, const ColTap* tap = nullptr, const B3Nets* b3 = nullptr) {
     typedef ColDims<IDR> D;
     constexpr int ldB = kSdfLd;
     {
@@ -1240,7 +1331,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<D::kKC0, 2>(net.w0p, wave * 2, A, D::kLdA, acc, lane);
+        gemm_any<B3, D::kKC0, 2>(net.w0p, B3 ? b3->col[0] : nullptr, wave * 2, A, D::kLdA, acc, lane);
         relu_store<2>(acc, net.bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
     }
     ARAH_SYNC();
@@ -1254,7 +1345,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<16, 2>(net.w1p, wave * 2, B, ldB, acc, lane);
+        gemm_any<B3, 16, 2>(net.w1p, B3 ? b3->col[1] : nullptr, wave * 2, B, ldB, acc, lane);
         ARAH_SYNC();
         relu_store<2>(acc, net.bias + 256, B, ldB, wave * 2, lane);
     }
@@ -1264,7 +1355,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         f32x4 acc[1][kNT];
 #pragma unroll
         for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
-        gemm_acc<16, 1>(net.w2p, wave, B, ldB, acc, lane);
+        gemm_any<B3, 16, 1>(net.w2p, B3 ? b3->col[2] : nullptr, wave, B, ldB, acc, lane);
         ARAH_SYNC();
         relu_store<1>(acc, net.bias + 512, B, ldB, wave, lane);   // cols 0..127
     }
@@ -1276,8 +1367,8 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<D::kKC0, 2>(net.w3ap, wave * 2, A, D::kLdA, acc, lane);
-        gemm_acc<8, 2>(net.w3bp, wave * 2, B, ldB, acc, lane);
+        gemm_any<B3, D::kKC0, 2>(net.w3ap, B3 ? b3->col[3] : nullptr, wave * 2, A, D::kLdA, acc, lane);
+        gemm_any<B3, 8, 2>(net.w3bp, B3 ? b3->col[4] : nullptr, wave * 2, B, ldB, acc, lane);
         ARAH_SYNC();
         relu_store<2>(acc, net.bias + 640, B, ldB, wave * 2, lane);
     }
@@ -1289,7 +1380,7 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
-        gemm_acc<16, 2>(net.w4p, wave * 2, B, ldB, acc, lane);
+        gemm_any<B3, 16, 2>(net.w4p, B3 ? b3->col[5] : nullptr, wave * 2, B, ldB, acc, lane);
         ARAH_SYNC();
         relu_store<2>(acc, net.bias + 896, B, ldB, wave * 2, lane);
     }

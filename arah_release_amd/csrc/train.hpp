@@ -98,8 +98,10 @@ __device__ __forceinline__ void reduce_channels(const float (&p)[kSdfMT][4], flo
         }
 }
 
-template <bool IDR, bool BWD>
-__global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT ct, TrainIn in, TrainOut out,
+// B3: the backward-direction products (colour reverse sweep, tangent pass, both adjoint sweeps: 21 of the 34 layer products
+// of the backward kernel) run on the bf16 x 3 engine (mlp.hpp: gemm_acc_b3); false: everything on the fp32 MFMA
+template <bool IDR, bool BWD, bool B3>
+__global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT ct, B3Nets b3, TrainIn in, TrainOut out,
                                                           f32x4* spill_all, f32x4* slab_all) {
     typedef ColDims<IDR> D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -148,7 +150,10 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             sdf_trunk<true, kNT, false>(net, xin, A, ldA, spill, dlast, wave, lane);
         }
         sdf_head<false>(net, A, ldA, outv, 4, tid);
-        sdf_backward(net, B, ldB, spill, dlast, outv, 4, wave, lane, tid);
+        // forward-direction products stay on the fp32 MFMA: their results pass ReLU gates (the colour MLP) and a 2^-16 error
+        // flips a gate for ~1e-5 of the activations -- gradients off by whole samples (measured: one bias gradient of
+        // test_shade_samples_op_against_autograd 10 % off); the reverse sweeps and the tangent pass have no gates
+        sdf_backward<false>(net, B, ldB, spill, dlast, outv, 4, wave, lane, tid);
         __syncthreads();
         // ---- colour input extras behind the feature: x(3), n(3) (rotated), [PE4(view) 27], zero pad
         if (tid < kTile) {
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             ctap.row0 = row0;
             ctap.rows = rows;
         }
-        color_mlp<IDR>(fr.col, A, B, rgbv, 4, wave, lane, tid, BWD ? &ctap : nullptr);
+        color_mlp<IDR, false>(fr.col, A, B, rgbv, 4, wave, lane, tid, BWD ? &ctap : nullptr);
         __syncthreads();
         if (tid < rows) {
             const long long p = row0 + tid;
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
-                gemm_acc<16, 2>(ct.w4pT, mt0, B, ldB, acc, lane);
+                gemm_any<B3, 16, 2>(ct.w4pT, b3.colT[5], mt0, B, ldB, acc, lane);
                 __syncthreads();
                 mask_store(acc, out.c[3], 256);
             }
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     f32x4 acc[1][kNT];
 #pragma unroll
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[0][nn]);
-                    gemm_acc<16, 1>(ct.w3apT, mt, B, ldB, acc, lane);
+                    gemm_any<B3, 16, 1>(ct.w3apT, b3.colT[3], mt, B, ldB, acc, lane);
                     const int ch0 = mt * 16 + 4 * g;
 #pragma unroll
                     for (int nn = 0; nn < kNT; ++nn) *reinterpret_cast<f32x4*>(A + (nn * 16 + j) * ldA + ch0) = acc[0][nn];
@@ -294,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 f32x4 acc3[1][kNT];
 #pragma unroll
                 for (int nn = 0; nn < kNT; ++nn) zero_acc(acc3[0][nn]);
-                gemm_acc<16, 1>(ct.w3bpT, wave, B, ldB, acc3, lane);
+                gemm_any<B3, 16, 1>(ct.w3bpT, b3.colT[4], wave, B, ldB, acc3, lane);
                 __syncthreads();   // every wave is done reading delta_3
                 const int ch0 = wave * 16 + 4 * g;
 #pragma unroll
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
-                gemm_acc<8, 2>(ct.w2pT, mt0, B, ldB, acc, lane);
+                gemm_any<B3, 8, 2>(ct.w2pT, b3.colT[2], mt0, B, ldB, acc, lane);
                 __syncthreads();
                 mask_store(acc, out.c[1], 256);
             }
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
-                gemm_acc<16, 2>(ct.w1pT, mt0, B, ldB, acc, lane);
+                gemm_any<B3, 16, 2>(ct.w1pT, b3.colT[1], mt0, B, ldB, acc, lane);
                 __syncthreads();
                 mask_store(acc, out.c[0], 256);
             }
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 const int ch0 = mt * 16 + 4 * g;
 #pragma unroll
                 for (int nn = 0; nn < kNT; ++nn) acc[0][nn] = *reinterpret_cast<const f32x4*>(A + (nn * 16 + j) * ldA + ch0);
-                gemm_acc<16, 1>(ct.w0pT, mt, B, ldB, acc, lane);
+                gemm_any<B3, 16, 1>(ct.w0pT, b3.colT[0], mt, B, ldB, acc, lane);
 #pragma unroll
                 for (int nn = 0; nn < kNT; ++nn) *reinterpret_cast<f32x4*>(A + (nn * 16 + j) * ldA + ch0) = acc[0][nn];
             }
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
-                gemm_acc<16, kSdfMT, kNT>(net.wp[k - 1], mt0, B, ldB, acc, lane);
+                gemm_any<B3, 16, kSdfMT, kNT>(net.wp[k - 1], b3.sdf_wp[k - 1], mt0, B, ldB, acc, lane);
                 __syncthreads();
 #pragma unroll
                 for (int m = 0; m < kSdfMT; ++m) {
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
                             for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
-                        gemm_acc<16, kSdfMT>(net.wpT[k - 1], mt0, buf, ld, acc, lane);
+                        gemm_any<B3, 16, kSdfMT>(net.wpT[k - 1], b3.sdf_wpT[k - 1], mt0, buf, ld, acc, lane);
                         __syncthreads();
 #pragma unroll
                         for (int m = 0; m < kSdfMT; ++m) {

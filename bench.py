@@ -185,6 +185,7 @@ def main():
     line = run(args, rt)
     if world == 1:
         global_dog.cancel()
+        global_dog.join()   # the timer thread holds the runtime (model, tensors): it must be gone before the interpreter winds down
     if rank == 0 and world == 1 and args.pipelined_streams > 1 and args.streams == 1:
         line = pipelined_extra(args, rt, line)
     if rank == 0:
@@ -319,6 +320,7 @@ def pipelined_extra(args, rt, line, limit_s=90.0):
         rt.device_sync()
         dt = time.perf_counter() - t0
     dog.cancel()
+    dog.join()
     line["frames_in_flight"] = {"note": "same frames, same path, %d frames of the sequence in flight on %d HIP streams "
                                         "(renderer.render_sequence; per-frame results bit-identical)" % (n, n),
                                 "streams": n, "value": rays / dt, "unit": "rays/s",

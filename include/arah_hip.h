@@ -162,6 +162,8 @@ typedef struct ArahFrame {
     const float* col_w3apT;
     const float* col_w3bpT;
     const float* col_w4pT;
+    const void* b3[22];         /* bf16 hi/lo fragments of the SDF (W, W^T) and colour (W, W^T) matrices: operands of the
+                                   training kernels' bf16 x 3 products (arah_shade_train_forward / _backward) */
     const float* verts4;        /* [256][28][4] k-d clustered vertices (x, y, z, original index) */
     const float* knn_spheres;   /* [256][4] bounding spheres of the clusters */
     const void* knn_grid;       /* grid geometry (device) */

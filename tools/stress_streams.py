@@ -43,6 +43,8 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         dog.cancel()
+        dog.join()
+    dog.join()
         state["run"] = r
         img = outs[-1]["rgb_values"]
         if ref is None:
