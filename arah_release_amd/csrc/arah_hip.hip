@@ -3483,7 +3483,12 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     const int gm = grid_for(n, kTile);
     // every step as launches over the compacted list; ARAH_TRACE_BULK_STEPS = k < 50 hands the list to the resident finisher
     // after k steps (measured slower: finish.hpp)
-    static const int bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 50)));
+    // Short ray lists (a training view: 2048 rays) never fill a launch: there every step is two kernel latencies, and the
+    // finisher (one launch, sixteen lanes per nearest-vertex search) takes the whole loop (ARAH_TRACE_SMALL: below how
+    // many rays; 0 = never)
+    static const int bulk_env = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 50)));
+    static const int small = env_int("ARAH_TRACE_SMALL", 4096);
+    const int bulk = (bulk_env == kSphereIters && n <= small) ? 0 : bulk_env;
     for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;

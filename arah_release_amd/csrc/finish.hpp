@@ -62,15 +62,12 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
             }
             __syncthreads();
             if (!*s_live) break;
-            // nearest vertex + inverse LBS: wave w searches for slots 2 w and 2 w + 1, lanes 0 / 1 finish them
-            {
-                int mybi = -1;
-                V3 myp = V3{0.f, 0.f, 0.f};
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int s = wave * 2 + k;
-                    const int id = ids[s];
-                    if (id < 0) continue;   // wave-uniform
+            // nearest vertex + inverse LBS: sixteen lanes per slot (nearest_vertex_group16), waves 0..3 take four slots each
+            // in one pass; the first lane of a group finishes its slot
+            if (wave < 4) {
+                const int s = wave * 4 + (lane >> 4);
+                const int id = ids[s];
+                if (id >= 0) {   // uniform over the group
                     const V3 p = ray_point(rs, id, tl[s]);
                     float best = 3.4e38f;
                     int bi = 0x7fffffff;
@@ -81,25 +78,18 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
                         best = dx * dx + dy * dy + dz * dz;
                         bi = seed;
                     }
-                    bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
-                    if (lane == k) {
-                        mybi = bi;
-                        myp = p;
-                    }
-                }
-                if (lane < 2) {
-                    const int s = wave * 2 + lane;
-                    f32x4 xn = {0.f, 0.f, 0.f, 0.f};
-                    if (ids[s] >= 0) {
+                    bi = nearest_vertex_group16<kClusterSize>(kd, kd.sorted4, kd.spheres, g, p, best, bi, lane);
+                    if ((lane & 15) == 0) {
                         float T[16];
-                        blend(fr.vert_weights + (size_t)mybi * 24, sbones, T);
-                        const V3 y = V3{myp.x - bc.trans[0], myp.y - bc.trans[1], myp.z - bc.trans[2]};
+                        blend(fr.vert_weights + (size_t)bi * 24, sbones, T);
+                        const V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
                         const V3 xh = normalize_pt(bc, inverse_affine_apply(T, y));
-                        xn = f32x4{xh.x, xh.y, xh.z, 0.f};
                         store_T(Tl + s * 16, T);
-                        nnl[s] = mybi;
+                        nnl[s] = bi;
+                        reinterpret_cast<f32x4*>(xin)[s] = f32x4{xh.x, xh.y, xh.z, 0.f};
                     }
-                    reinterpret_cast<f32x4*>(xin)[s] = xn;
+                } else if ((lane & 15) == 0) {
+                    reinterpret_cast<f32x4*>(xin)[s] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
             }
             __syncthreads();

@@ -437,11 +437,15 @@ def run(args, rt):
         canon_traffic, canon_src = pmc_traffic(canon_kernel + "<")
         shade_traffic, shade_src = pmc_traffic("k_shade<%s, %s>" % (tf[mode == "idr"], tf[split]), full_shading=True)
         peak_fwd = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
-        # k_shade: forward trunk on the default engine, reverse sweep and colour MLP on the exact engine
-        peak_shade = mixed_peak([(F_SDF, peak_fwd), (F_SDF_GRAD + F_COL[mode], PEAK_F32_MFMA_TFLOPS)])
+        # k_shade: forward trunk on the default engine; reverse sweep and colour MLP on the bf16 x 3 engine (three bf16
+        # MFMAs per fp32 product: the same rate as the f16 split) unless ARAH_SHADE_ENGINE=fp32 / the exact engine
+        shade_b3 = split and os.environ.get("ARAH_SHADE_ENGINE", "b3") != "fp32"
+        peak_shade = mixed_peak([(F_SDF, peak_fwd), (F_SDF_GRAD + F_COL[mode], peak_fwd if shade_b3 else PEAK_F32_MFMA_TFLOPS)])
         engine = ("fp32 operands as hi+lo f16 pairs, 3 x v_mfma_f32_16x16x32_f16 per product, fp32 accumulate "
-                  "(forward SDF trunks, loop-C skinning MLP); v_mfma_f32_16x16x4_f32 for reverse sweeps and the "
-                  "colour MLP" if split else "v_mfma_f32_16x16x4_f32 everywhere")
+                  "(forward SDF trunks, loop-C skinning MLP); " +
+                  ("hi+lo bf16 pairs, 3 x v_mfma_f32_16x16x32_bf16 (2^-16 per product) for loop D's normal sweep and "
+                   "colour MLP" if shade_b3 else "v_mfma_f32_16x16x4_f32 for reverse sweeps and the colour MLP")
+                  if split else "v_mfma_f32_16x16x4_f32 everywhere")
         line = {
             "metric": "rendered rays/sec", "value": total_rays / t_max, "unit": "rays/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * t_max / max(args.steps, 1),
@@ -485,7 +489,7 @@ def run(args, rt):
                                            "ms_per_step": 1e3 * t_max_one / max(args.steps, 1)}
         if t_max_full:
             # dominant kernel of the shade-everything path: k_shade (forward trunk on the default engine, reverse sweep
-            # and colour MLP on the exact engine)
+            # and colour MLP on the bf16 x 3 engine)
             n_l = max(len(shade_ms), 1)
             samples_per_launch = counters_full["n_col"] / n_l
             avg_ms = sum(shade_ms) / n_l
