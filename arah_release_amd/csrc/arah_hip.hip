@@ -2281,8 +2281,12 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
     float* outv = xin + 64 * 4;               // [64][4] sdf, grad
     float* rgbv = outv + 64 * 4;              // [64][4]
     int* ids = reinterpret_cast<int*>(rgbv + 64 * 4);
-    float* actA = reinterpret_cast<float*>(ids + 64);   // [64][kLdA]
-    float* actB = actA + 64 * D::kLdA;                  // [64][260]
+    // B3: every activation of the normal sweep and of the colour MLP as bf16 hi / lo planes (mlp.hpp); the colour input
+    // then needs ceil(kInPad / 32) 64-byte chunks per plane, i.e. rows of kInPad + 24 floats (8 x odd dwords apart mod 64)
+    constexpr int ldA = B3 ? D::kInPad + 24 : D::kLdA;
+    constexpr int loA = ((D::kInPad + 31) / 32) * 64;   // byte offset of the lo plane of A
+    float* actA = reinterpret_cast<float*>(ids + 64);   // [64][ldA]
+    float* actB = actA + 64 * ldA;                      // [64][kSdfLd]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int n = list ? *count : n_direct;
     f32x4* spill = spill_all + (size_t)blockIdx.x * kSpillPerWg;
@@ -2300,14 +2304,20 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, D::kLdA, spill, dlast, wave, lane);
-        sdf_head<SPLIT>(fr.sdf, actA, D::kLdA, outv, 4, tid);
-        if (SPLIT) unsplit_rows(actA, D::kLdA, tid);   // the colour MLP (exact engine) reads the feature as fp32
-        sdf_backward<B3>(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid, &b3);
+        sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane);
+        sdf_head<SPLIT>(fr.sdf, actA, ldA, outv, 4, tid);
+        if constexpr (B3) {
+            resplit_rows_bf16(actA, ldA, loA, tid);   // the feature: f16 split planes -> bf16 planes
+            sdf_backward_bp(fr.sdf, b3, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
+        } else {
+            if (SPLIT) unsplit_rows(actA, ldA, tid);   // the colour MLP (exact engine) reads the feature as fp32
+            sdf_backward(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
+        }
         __syncthreads();
         if (tid < kTile) {   // colour-input extras behind the feature: x(3), n(3), [PE4(view) 27], zero pad
             const int id = ids[tid];
-            float* e = actA + tid * D::kLdA + 256;
+            float ebuf[64];   // B3: staged here, written as planes below
+            float* e = B3 ? ebuf : actA + tid * ldA + 256;
             float nx = outv[tid * 4 + 1], ny = outv[tid * 4 + 2], nz = outv[tid * 4 + 3];
             float vx = 0.f, vy = 0.f, vz = 0.f;
             if (id >= 0) {
@@ -2359,9 +2369,15 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
                 }
             }
             for (; k < D::kInPad - 256; ++k) e[k] = 0.f;
+            if constexpr (B3) {
+                constexpr int n_extra = ((D::kInPad + 31) / 32) * 32 - 256;   // up to the end of the last 32-chunk
+#pragma unroll
+                for (int q = 0; q < n_extra; ++q) store_bsplit1(actA, ldA, loA, tid, 256 + q, q < D::kInPad - 256 ? ebuf[q] : 0.f);
+            }
         }
         __syncthreads();
-        color_mlp<IDR, B3>(fr.col, actA, actB, rgbv, 4, wave, lane, tid, nullptr, &b3);
+        if constexpr (B3) color_mlp_bp<IDR>(fr.col, b3, actA, ldA, loA, actB, rgbv, 4, wave, lane, tid);
+        else color_mlp<IDR>(fr.col, actA, actB, rgbv, 4, wave, lane, tid);
         __syncthreads();
         if (tid == 0) {
             const int cnt = min(kTile, n - tile * kTile);
@@ -2634,6 +2650,10 @@ constexpr size_t lds_shade() {
     return (64 * 4 * 3 + 64) * 4 + (size_t)64 * ColDims<IDR>::kLdA * 4 + (size_t)64 * kSdfLd * 4;
 }
 template <bool IDR>
+constexpr size_t lds_shade_b3() {
+    return (64 * 4 * 3 + 64) * 4 + (size_t)64 * (ColDims<IDR>::kInPad + 24) * 4 + (size_t)64 * kSdfLd * 4;
+}
+template <bool IDR>
 constexpr size_t lds_color() {
     return (64 * 4) * 4 + (size_t)64 * ColDims<IDR>::kLdA * 4 + (size_t)64 * kSdfLd * 4;
 }
@@ -2706,8 +2726,8 @@ int setup_attributes() {
     allow_lds(k_shade<false, true>, lds_shade<false>());
     allow_lds(k_shade<true, false>, lds_shade<true>());
     allow_lds(k_shade<true, true>, lds_shade<true>());
-    allow_lds((k_shade<false, true, true>), lds_shade<false>());
-    allow_lds((k_shade<true, true, true>), lds_shade<true>());
+    allow_lds((k_shade<false, true, true>), lds_shade_b3<false>());
+    allow_lds((k_shade<true, true, true>), lds_shade_b3<true>());
     allow_lds(k_color_eval<false>, lds_color<false>());
     allow_lds(k_color_eval<true>, lds_color<true>());
     allow_lds(k_shade_train<false, false, false>, lds_shade_train<false>());
@@ -3632,11 +3652,11 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     const B3Nets b3 = b3_of(*f);
     if (fd.split && shade_b3()) {
         if (f->col_mode == ARAH_COLOR_IDR)
-            hipLaunchKernelGGL((k_shade<true, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade<true>()), s, fd, S,
+            hipLaunchKernelGGL((k_shade<true, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade_b3<true>()), s, fd, S,
                                cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
                                &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
         else
-            hipLaunchKernelGGL((k_shade<false, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade<false>()), s, fd, S,
+            hipLaunchKernelGGL((k_shade<false, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade_b3<false>()), s, fd, S,
                                cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
                                &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
     } else if (f->col_mode == ARAH_COLOR_IDR)

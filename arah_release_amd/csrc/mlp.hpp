@@ -519,6 +519,86 @@ __device__ __forceinline__ void gemm_any(const float* __restrict__ wp, const bf1
     else gemm_acc<KC16, MT, NT>(wp, mt0, act, ld, acc, lane);
 }
 
+// ---- bf16 x 3 with the activations as bf16 hi / lo PLANES in LDS (loop D, round 3) ------------------------------------
+// gemm_acc_b3 converts a wave's B fragments as it loads them -- eight waves convert the same tile, and the conversion (three
+// vector instructions per element) then costs as much as the MFMAs.  Here the producer's epilogue writes the two bf16
+// planes once (the layout of the f16 split: 64-byte chunks of 32 channels, slots permuted by the point, lo plane at
+// lo_off bytes) and the product is MFMAs and LDS reads only.
+__device__ __forceinline__ void store_bsplit4(float* act, int ld, int lo_off, int pt, int ch0, const f32x4 v) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 hi, lo;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const bf16x2 h = __builtin_convertvector(f32x2{v[2 * p], v[2 * p + 1]}, bf16x2);
+        const bf16x2 l = __builtin_convertvector(f32x2{v[2 * p] - (float)h[0], v[2 * p + 1] - (float)h[1]}, bf16x2);
+        hi[p] = __builtin_bit_cast(unsigned, h);
+        lo[p] = __builtin_bit_cast(unsigned, l);
+    }
+    char* row = reinterpret_cast<char*>(act) + pt * ld * 4 + split_byte(pt, ch0);
+    *reinterpret_cast<u32x2*>(row) = hi;
+    *reinterpret_cast<u32x2*>(row + lo_off) = lo;
+}
+__device__ __forceinline__ void store_bsplit1(float* act, int ld, int lo_off, int pt, int ch, float v) {
+    const __bf16 h = (__bf16)v;
+    char* row = reinterpret_cast<char*>(act) + pt * ld * 4 + split_byte(pt, ch);
+    *reinterpret_cast<__bf16*>(row) = h;
+    *reinterpret_cast<__bf16*>(row + lo_off) = (__bf16)(v - (float)h);
+}
+__device__ __forceinline__ float load_bsplit(const float* act, int ld, int lo_off, int pt, int ch) {
+    const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4 + split_byte(pt, ch);
+    return (float)*reinterpret_cast<const __bf16*>(row) + (float)*reinterpret_cast<const __bf16*>(row + lo_off);
+}
+
+// acc[m][n] += W(M-tiles mt0.., KC32 32-chunks) * planes(16 NT points): A one chunk ahead, B at the top of the chunk
+template <int KC32, int MT, int NT = kNT>
+__device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, int mt0, const float* act, int ld, int lo_off,
+                                                f32x4 (&acc)[MT][NT], int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
+    const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
+    auto lda = [&](int idx) { return ld_frag<bf16x8>(wp, aoff, idx * 1024); };
+    bf16x8 ah[MT], al[MT], ahn[MT], aln[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ah[m] = lda((m * KC32) * 2 + 0);
+        al[m] = lda((m * KC32) * 2 + 1);
+    }
+#pragma unroll 2
+    for (int kc = 0; kc < KC32; ++kc) {
+        const int kn = kc + 1 < KC32 ? kc + 1 : kc;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ahn[m] = lda((m * KC32 + kn) * 2 + 0);
+            aln[m] = lda((m * KC32 + kn) * 2 + 1);
+        }
+        bf16x8 bh[NT], bl[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            bh[n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + kc * 64);
+            bl[n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + lo_off + kc * 64);
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)   // small terms first
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            ah[m] = ahn[m];
+            al[m] = aln[m];
+        }
+    }
+}
+
 // 4 consecutive channels of one point, already multiplied by kActScale -> hi/lo planes
 // hi = f16(h) (round to nearest even), lo = f16(h - hi).  The residual is one mixed-precision FMA per channel that
 // reads its f16 operand straight out of the packed hi register and writes the f16 result into its half of the packed
@@ -1317,6 +1397,82 @@ struct ColTap {         // training: the colour MLP's input and hidden activatio
     int rows;
 };
 
+// f16 split planes of the trunk's h6 (hi at byte 0, lo at 512, scaled by kActScale) -> bf16 planes (lo at lo_off) in place,
+// through registers: 64 points x 256 channels
+__device__ __forceinline__ void resplit_rows_bf16(float* act, int ld, int lo_off, int tid) {
+    f32x4 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + i * kThreads, pt = e >> 6, ch0 = (e & 63) * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = load_split(act, ld, 512, pt, ch0 + r);
+    }
+    ARAH_SYNC();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int e = tid + i * kThreads;
+        store_bsplit4(act, ld, lo_off, e >> 6, (e & 63) * 4, v[i]);
+    }
+}
+
+// sdf_backward with the sweep's activations as bf16 planes in `bwd` (rows of ld floats, lo plane at byte 512)
+__device__ __forceinline__ void sdf_backward_bp(const SdfNet& net, const B3Nets& b3, float* bwd, int ld, const f32x4* spill,
+                                                const f32x4 (&dlast)[kSdfMT][kNT], float* out, int ostride, int wave,
+                                                int lane, int tid) {
+    const int j = lane & 15, g = lane >> 4;
+    const int mt0 = wave * kSdfMT;
+#pragma unroll
+    for (int m = 0; m < kSdfMT; ++m) {
+        const int ch0 = (mt0 + m) * 16 + 4 * g;
+        const f32x4 w = *reinterpret_cast<const f32x4*>(net.w6 + ch0);
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) store_bsplit4(bwd, ld, 512, n * 16 + j, ch0, dlast[m][n] * w);
+    }
+    ARAH_SYNC();
+#pragma unroll 1
+    for (int k = 4; k >= 0; --k) {
+        f32x4 acc[kSdfMT][kNT];
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc_bsplit<8, kSdfMT>(b3.sdf_wpT[k], mt0, bwd, ld, 512, acc, lane);
+        ARAH_SYNC();
+#pragma unroll
+        for (int m = 0; m < kSdfMT; ++m) {
+            const int ch0 = (mt0 + m) * 16 + 4 * g;
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) {
+                const f32x4 d = spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane];
+                store_bsplit4(bwd, ld, 512, n * 16 + j, ch0, acc[m][n] * d);
+            }
+        }
+        ARAH_SYNC();
+    }
+    const int pt = tid >> 3, part = tid & 7;
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int ch = part + 8 * i;
+        const float u = load_bsplit(bwd, ld, 512, pt, ch);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(net.w0 + ch * 4);
+        gx += w[0] * u;
+        gy += w[1] * u;
+        gz += w[2] * u;
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        gx += __shfl_xor(gx, o);
+        gy += __shfl_xor(gy, o);
+        gz += __shfl_xor(gz, o);
+    }
+    if (part == 0) {
+        out[pt * ostride + 1] = gx;
+        out[pt * ostride + 2] = gy;
+        out[pt * ostride + 3] = gz;
+    }
+}
+
 // A: LDS [64][kLdA] full input (feature in cols 0..255, extras after, zero padded); B: LDS [64][260].
 // rgb (after sigmoid) -> out[pt*ostride + 0..2].  Needs a barrier between the writers of A and the call.
 // tap != nullptr (training): A and every hidden activation are streamed out; B holds c5 on return.
@@ -1393,6 +1549,111 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
         for (int i = 0; i < 32; ++i) {
             const int ch = part + 8 * i;
             const float h = B[pt * ldB + ch];
+            c0 += net.w5[ch] * h;
+            c1 += net.w5[256 + ch] * h;
+            c2 += net.w5[512 + ch] * h;
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            c0 += __shfl_xor(c0, o);
+            c1 += __shfl_xor(c1, o);
+            c2 += __shfl_xor(c2, o);
+        }
+        if (part == 0) {
+            out[pt * ostride + 0] = 1.0f / (1.0f + expf(-(c0 + net.bias[1152 + 0])));
+            out[pt * ostride + 1] = 1.0f / (1.0f + expf(-(c1 + net.bias[1152 + 1])));
+            out[pt * ostride + 2] = 1.0f / (1.0f + expf(-(c2 + net.bias[1152 + 2])));
+        }
+    }
+}
+
+// The colour MLP on the bf16 x 3 engine with every activation as bf16 planes.
+// A: planes of the full input, rows of ldA floats, lo plane at byte loA, ceil(kInPad / 32) chunks of which the channels
+// beyond kIn are zero; B: planes of the hidden activations, rows of kSdfLd floats, lo plane at byte 512.
+template <int MT>
+__device__ __forceinline__ void relu_store_bp(const f32x4 (&acc)[MT][kNT], const float* bias, float* dst, int ld,
+                                              int mt0, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        const int ch0 = (mt0 + m) * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) {
+            f32x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[m][n][r] + b[r], 0.f);
+            store_bsplit4(dst, ld, 512, n * 16 + j, ch0, h);
+        }
+    }
+}
+
+template <bool IDR>
+__device__ __forceinline__ void color_mlp_bp(const ColNet& net, const B3Nets& b3, const float* A, int ldA, int loA, float* B,
+                                             float* out, int ostride, int wave, int lane, int tid) {
+    typedef ColDims<IDR> D;
+    constexpr int ldB = kSdfLd;
+    constexpr int KCA = (D::kKC0 + 1) / 2;
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc_bsplit<KCA, 2>(b3.col[0], wave * 2, A, ldA, loA, acc, lane);
+        relu_store_bp<2>(acc, net.bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
+    }
+    ARAH_SYNC();
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc_bsplit<8, 2>(b3.col[1], wave * 2, B, ldB, 512, acc, lane);
+        ARAH_SYNC();
+        relu_store_bp<2>(acc, net.bias + 256, B, ldB, wave * 2, lane);
+    }
+    ARAH_SYNC();
+    {
+        f32x4 acc[1][kNT];
+#pragma unroll
+        for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
+        gemm_acc_bsplit<8, 1>(b3.col[2], wave, B, ldB, 512, acc, lane);
+        ARAH_SYNC();
+        relu_store_bp<1>(acc, net.bias + 512, B, ldB, wave, lane);   // channels 0..127
+    }
+    ARAH_SYNC();
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc_bsplit<KCA, 2>(b3.col[3], wave * 2, A, ldA, loA, acc, lane);
+        gemm_acc_bsplit<4, 2>(b3.col[4], wave * 2, B, ldB, 512, acc, lane);
+        ARAH_SYNC();
+        relu_store_bp<2>(acc, net.bias + 640, B, ldB, wave * 2, lane);
+    }
+    ARAH_SYNC();
+    {
+        f32x4 acc[2][kNT];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        gemm_acc_bsplit<8, 2>(b3.col[5], wave * 2, B, ldB, 512, acc, lane);
+        ARAH_SYNC();
+        relu_store_bp<2>(acc, net.bias + 896, B, ldB, wave * 2, lane);
+    }
+    ARAH_SYNC();
+    {
+        const int pt = tid >> 3, part = tid & 7;
+        float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll 8
+        for (int i = 0; i < 32; ++i) {
+            const int ch = part + 8 * i;
+            const float h = load_bsplit(B, ldB, 512, pt, ch);
             c0 += net.w5[ch] * h;
             c1 += net.w5[256 + ch] * h;
             c2 += net.w5[512 + ch] * h;
