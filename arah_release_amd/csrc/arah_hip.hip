@@ -239,6 +239,7 @@ __global__ void k_fold_film(const float* __restrict__ freq, const float* __restr
     pw[i] = (float)((f * (double)bias[i] + (double)phase[i]) * c);
     const float inv = k == 0 ? 1.0f : 1.0f / (split_weight_scale(amax[k - 1]) * kActScale);
     fws[i] = (float)(f * c) * inv;
+    if ((i & 255) == 0) fws[6 * 256 + k] = inv;   // accumulator -> pre-activation of layer k (training taps)
 }
 
 // Largest hidden activation of the skinning MLP (Softplus: h >= 0) per layer over a 9^3 lattice of the normalised
@@ -2869,7 +2870,7 @@ FrameLayout frame_layout(int col_mode) {
     for (int i = 0; i < 5; ++i) L.sdf_wps[i] = take(256 * 256);   // hi + lo halves = 4 bytes per weight
     L.sdf_fw = take(6 * 256);
     L.sdf_pw = take(6 * 256);
-    L.sdf_fws = take(6 * 256);
+    L.sdf_fws = take(6 * 256 + 64);   // + per-layer inverse operand scales
     L.sdf_amax = take(64);
     L.skin_w0 = take(128 * 4);
     for (int i = 0; i < 3; ++i) L.skin_wp[i] = take(128 * 128);

@@ -813,6 +813,17 @@ __device__ __forceinline__ void stream_rows(const float* lds, int ld, int width,
     }
 }
 
+// the same from split planes (hi at byte 0, lo at byte 512, 256 channels)
+__device__ __forceinline__ void stream_rows_split(const float* lds, int ld, float* dst, long long row0, int rows, int tid) {
+    for (int e = tid; e < rows * 64; e += kThreads) {
+        const int r = e >> 6, c4 = e & 63;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = load_split(lds, ld, 512, r, c4 * 4 + q);
+        reinterpret_cast<f32x4*>(dst + (row0 + r) * 256)[c4] = v;
+    }
+}
+
 // Forward trunk on a tile of 16 NT points.  xin: LDS [16 NT][4] normalised coords.  act: LDS rows of ld floats,
 // receives h6 -- as fp32 [256] (exact engine) or as split planes (hi at byte 0, lo at byte 512; SPLIT).
 // GRAD: dact factors of layers 1..5 go to `spill` (global, this workgroup's private slab of
@@ -862,7 +873,10 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
             for (int n = 0; n < NT; ++n) zero_acc(acc[m][n]);
-        if constexpr (TAP::on) stream_rows(act, ld, 256, tap.h[k], tap.row0, tap.rows, wave * 64 + lane);   // h_k: read only
+        if constexpr (TAP::on) {   // h_k: read only
+            if (SPLIT) stream_rows_split(act, ld, tap.h[k], tap.row0, tap.rows, wave * 64 + lane);
+            else stream_rows(act, ld, 256, tap.h[k], tap.row0, tap.rows, wave * 64 + lane);
+        }
 #ifndef ARAH_TRUNK_ROLLED   // 128-point tiles (two waves per SIMD): the explicit pipeline, 12.3 vs 13.1 ms for k_density (r3o)
         if constexpr (SPLIT && !GRAD && NT == 8) gemm_acc_split_pipe<8, kSdfMT, NT, 2>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
         else
@@ -896,7 +910,9 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
                 f32x4 h, d;
-                if constexpr (TAP::on) tap.aslab[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = acc[m][n];
+                if constexpr (TAP::on)   // the pre-activation v_k itself: the split engine's accumulator carries the operand scales
+                    tap.aslab[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] =
+                        SPLIT ? acc[m][n] * net.fws[6 * 256 + k] : acc[m][n];
 #ifdef ARAH_ABL_NO_EPI   //   ARAH_ABL_NO_EPI   no FiLM sine: the accumulators are stored as they are
                 h = acc[m][n] * 1e-6f;
                 d = zero4;

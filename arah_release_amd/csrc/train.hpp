@@ -145,11 +145,14 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             for (int k = 0; k < 6; ++k) tap.h[k] = out.h[k];
             tap.row0 = row0;
             tap.rows = rows;
-            sdf_trunk<true, kNT, false, TrainTap>(net, xin, A, ldA, spill, dlast, wave, lane, tap);
+            sdf_trunk<true, kNT, B3, TrainTap>(net, xin, A, ldA, spill, dlast, wave, lane, tap);
         } else {
-            sdf_trunk<true, kNT, false>(net, xin, A, ldA, spill, dlast, wave, lane);
+            sdf_trunk<true, kNT, B3>(net, xin, A, ldA, spill, dlast, wave, lane);
         }
-        sdf_head<false>(net, A, ldA, outv, 4, tid);
+        // B3 builds: the forward trunk on the f16 split engine (2^-22 per product, what inference runs); its feature planes
+        // become fp32 rows for the stages behind it
+        sdf_head<B3>(net, A, ldA, outv, 4, tid);
+        if constexpr (B3) unsplit_rows(A, ldA, tid);
         // forward-direction products stay on the fp32 MFMA: their results pass ReLU gates (the colour MLP) and a 2^-16 error
         // flips a gate for ~1e-5 of the activations -- gradients off by whole samples (measured: one bias gradient of
         // test_shade_samples_op_against_autograd 10 % off); the reverse sweeps and the tangent pass have no gates
