@@ -3502,14 +3502,17 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
                        w.listA, &cntA[0]);
     TraceState ts{w.t, w.far, w.xcur, w.diverged};
     const int gm = grid_for(n, kTile);
-    // every step as launches over the compacted list; ARAH_TRACE_BULK_STEPS = k < 50 hands the list to the resident finisher
-    // after k steps (measured slower: finish.hpp)
+    // the first steps as launches over the compacted list; after ARAH_TRACE_BULK_STEPS of them the resident finisher takes the
+    // list (finish.hpp; 50 = never)
     // Short ray lists (a training view: 2048 rays) never fill a launch: there every step is two kernel latencies, and the
     // finisher (one launch, sixteen lanes per nearest-vertex search) takes the whole loop (ARAH_TRACE_SMALL: below how
     // many rays; 0 = never)
-    static const int bulk_env = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 50)));
+    // Full frames: 24 wide steps, then the finisher adopts the stragglers (a few thousand rays: 52 launches of tens of
+    // microseconds each become one; 43.15 -> 42.75 ms per frame one at a time, 41.7 -> 41.0 with three in flight; handing
+    // over after 8 or 12 steps loses: too many rays left for sixteen-ray tiles -- profiles/r03_ab_trace_finish.txt)
+    static const int bulk_env = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 24)));
     static const int small = env_int("ARAH_TRACE_SMALL", 4096);
-    const int bulk = (bulk_env == kSphereIters && n <= small) ? 0 : bulk_env;
+    const int bulk = n <= small ? 0 : bulk_env;
     for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
