@@ -74,12 +74,16 @@ def hierarchical_softmax(x):
     gate = torch.sigmoid(x)
     F_ = torch.cat([gate, 1.0 - gate, torch.softmax(x[:, 1:4], dim=-1), torch.softmax(x[:, 12:15], dim=-1),
                     torch.ones_like(x[:, :1])], dim=-1)
-    key = str(x.device)
+    key = (str(x.device), x.dtype)
     if key not in _HSOFTMAX_PATHS:
-        _HSOFTMAX_PATHS[key] = torch.tensor(_hsoftmax_paths(), dtype=torch.long, device=x.device)
-    paths = _HSOFTMAX_PATHS[key]                                   # (24, depth)
-    # index_select: its backward is one index_add (advanced indexing would sort 240 indices per row of a 1e5-row matrix)
-    cols = F_.index_select(1, paths.t().reshape(-1)).reshape(-1, paths.shape[1], 24).unbind(1)
+        paths = torch.tensor(_hsoftmax_paths(), dtype=torch.long)              # (24, depth)
+        sel = torch.zeros(F_.shape[1], paths.numel(), dtype=x.dtype)
+        sel[paths.t().reshape(-1), torch.arange(paths.numel())] = 1.0           # column c of the product = column idx[c] of F
+        _HSOFTMAX_PATHS[key] = (sel.to(x.device), paths.shape[1])
+    sel, depth = _HSOFTMAX_PATHS[key]
+    # the gather as a product with a one-hot matrix: exact (every sum has one non-zero term), and its backward is a GEMM --
+    # index_select's is an atomic index_add (1.4 ms per step on the 1.3e5-row call), advanced indexing's a sort (0.9 ms)
+    cols = torch.matmul(F_, sel).reshape(-1, depth, 24).unbind(1)
     out = cols[0]
     for c in cols[1:]:                                             # left to right, the order the recursion multiplies in
         out = out * c
