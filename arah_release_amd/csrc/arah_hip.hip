@@ -3717,6 +3717,12 @@ int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* s
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev fd = to_dev(*f);
     TrainIn ti{in->n, in->x, in->T, in->view, in->view_orig, in->rotate_normal, in->ray_augm, nullptr, nullptr};
+    ti.tap_cin = in->tap_cin;
+    for (int l = 0; l < 5; ++l) {
+        if (in->tap_cin && !in->tap_c[l]) return ARAH_E_BADARG;
+        ti.tap_c[l] = in->tap_cin ? in->tap_c[l] : nullptr;
+    }
+    ti.fwd_rgb = nullptr;
     TrainOut to;
     memset(&to, 0, sizeof(to));
     to.sdf = sdf;
@@ -3749,6 +3755,16 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev fd = to_dev(*f);
     TrainIn ti{in->n, in->x, in->T, in->view, in->view_orig, in->rotate_normal, in->ray_augm, in->g_s, in->g_rgb};
+    // hand-over from the forward call: its streams must be the ones the weight-gradient GEMMs will read
+    const bool handed = in->tap_cin && in->fwd_rgb4;
+    if (handed) {
+        if (in->tap_cin != gr->cin) return ARAH_E_BADARG;
+        for (int l = 0; l < 5; ++l)
+            if (!in->tap_c[l] || in->tap_c[l] != gr->c[l]) return ARAH_E_BADARG;
+    }
+    ti.tap_cin = handed ? in->tap_cin : nullptr;
+    for (int l = 0; l < 5; ++l) ti.tap_c[l] = handed ? in->tap_c[l] : nullptr;
+    ti.fwd_rgb = handed ? in->fwd_rgb4 : nullptr;
     TrainOut to;
     to.sdf = gr->sdf;
     to.rgb = gr->rgb4;

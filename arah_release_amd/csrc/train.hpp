@@ -43,6 +43,9 @@ struct TrainIn {
     int ray_augm;             // IDR:342-350
     const float* g_s;         // [P]    dL/ds     (backward only)
     const float* g_rgb;       // [P][3] dL/drgb   (backward only)
+    float* tap_cin;           // forward: colour input stream out (or null); backward with fwd_rgb: the same, read only
+    float* tap_c[5];
+    const float* fwd_rgb;     // [P][4] the forward call's rgb: the backward then skips the normal sweep and the colour MLP
 };
 
 struct TrainOut {
@@ -137,8 +140,31 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             reinterpret_cast<f32x4*>(gin)[tid] = gi;
         }
         __syncthreads();
-        // ---- 1. forward: SDF trunk (+ taps), value, normal
         f32x4 dlast[kSdfMT][kNT];
+        const bool handed = BWD && in.fwd_rgb != nullptr;   // the forward call left cin, c1..c5 and rgb: nothing behind the
+        if (handed) {                                       // trunk is recomputed (wave-uniform)
+            if constexpr (BWD) {
+                TrainTap tap;
+                tap.aslab = vslab;
+                for (int k = 0; k < 6; ++k) tap.h[k] = out.h[k];
+                tap.row0 = row0;
+                tap.rows = rows;
+                sdf_trunk<false, kNT, B3, TrainTap>(net, xin, A, ldA, nullptr, dlast, wave, lane, tap);   // v_k, h_k only
+                for (int e = tid; e < kTile * 64; e += kThreads) {   // B <- c5
+                    const int r = e >> 6, c4 = e & 63;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (r < rows) v = reinterpret_cast<const f32x4*>(in.tap_c[4] + (row0 + r) * 256)[c4];
+                    *reinterpret_cast<f32x4*>(B + r * ldB + c4 * 4) = v;
+                }
+                if (tid < kTile) {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                    if (tid < rows) v = reinterpret_cast<const f32x4*>(in.fwd_rgb)[row0 + tid];
+                    reinterpret_cast<f32x4*>(rgbv)[tid] = v;
+                }
+                __syncthreads();
+            }
+        } else {
+        // ---- 1. forward: SDF trunk (+ taps), value, normal
         if constexpr (BWD) {
             TrainTap tap;
             tap.aslab = vslab;
@@ -213,19 +239,21 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         }
         __syncthreads();
         ColTap ctap;
-        if (BWD) {
-            ctap.cin = out.cin;
-            for (int l = 0; l < 5; ++l) ctap.c[l] = out.c[l];
+        const bool taps = BWD || in.tap_cin != nullptr;
+        if (taps) {
+            ctap.cin = BWD ? out.cin : in.tap_cin;
+            for (int l = 0; l < 5; ++l) ctap.c[l] = BWD ? out.c[l] : in.tap_c[l];
             ctap.row0 = row0;
             ctap.rows = rows;
         }
-        color_mlp<IDR, false>(fr.col, A, B, rgbv, 4, wave, lane, tid, BWD ? &ctap : nullptr);
+        color_mlp<IDR, false>(fr.col, A, B, rgbv, 4, wave, lane, tid, taps ? &ctap : nullptr);
         __syncthreads();
         if (tid < rows) {
             const long long p = row0 + tid;
             out.sdf[p] = outv[tid * 4];
             reinterpret_cast<f32x4*>(out.rgb)[p] = f32x4{rgbv[tid * 4], rgbv[tid * 4 + 1], rgbv[tid * 4 + 2], 0.f};
         }
+        }   // !handed
         if constexpr (BWD) {
             // =========================================================== 2. colour MLP backward
             // B holds c5.  delta_5 = g_rgb * rgb (1 - rgb)

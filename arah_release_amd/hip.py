@@ -71,7 +71,8 @@ class ArahFrame(C.Structure):
 
 class ArahTrainIn(C.Structure):
     _fields_ = [("n", C.c_int32), ("rotate_normal", C.c_int32), ("ray_augm", C.c_int32), ("pad", C.c_int32),
-                ("x", _fp), ("T", _fp), ("view", _fp), ("view_orig", _fp), ("g_s", _fp), ("g_rgb", _fp)]
+                ("x", _fp), ("T", _fp), ("view", _fp), ("view_orig", _fp), ("g_s", _fp), ("g_rgb", _fp),
+                ("tap_cin", _fp), ("tap_c", _fp * 5), ("fwd_rgb4", _fp)]
 
 
 class ArahTrainGrads(C.Structure):
@@ -601,8 +602,10 @@ def _train_in(x, T, view, view_orig, rotate_normal, ray_augm, g_s=None, g_rgb=No
 
 
 @_guarded
-def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_augm):
-    """x (P,3) normalised canonical points, T (P,4,4) or None, view / view_orig (P,3) -> sdf (P,), rgb (P,3)."""
+def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_augm, keep=False):
+    """x (P,3) normalised canonical points, T (P,4,4) or None, view / view_orig (P,3) -> sdf (P,), rgb (P,3).
+    keep=True: also the hand-over for shade_train_backward -- dict(cin, c, rgb4): the colour MLP's input and hidden
+    activations as (P, width) streams and the padded rgb; the backward then skips the normal sweep and the colour MLP."""
     lib = load_library()
     x, view = _f32(x), _f32(view)
     T = _f32(T) if (T is not None and rotate_normal) else None
@@ -612,13 +615,20 @@ def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_aug
     sdf = torch.empty(n, device=x.device)
     rgb4 = torch.empty(n, 4, device=x.device)
     tin = _train_in(x, T, view, vo, rotate_normal, ray_augm)
+    kept = None
+    if keep:
+        kept = {"cin": torch.empty(n, KIN_PAD[frame.color_mode], device=x.device),
+                "c": [torch.empty(n, w, device=x.device) for w in (256, 256, 128, 256, 256)], "rgb4": rgb4}
+        tin.tap_cin = _ptr(kept["cin"])
+        for i, t in enumerate(kept["c"]):
+            tin.tap_c[i] = _ptr(t).value
     _check(lib.arah_shade_train_forward(C.byref(frame.handle), C.byref(tin), _ptr(sdf), _ptr(rgb4), _ptr(buf),
                                         C.c_size_t(buf.numel()), _stream()), "arah_shade_train_forward")
-    return sdf, rgb4[:, :3]
+    return (sdf, rgb4[:, :3], kept) if keep else (sdf, rgb4[:, :3])
 
 
 @_guarded
-def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_augm, g_s, g_rgb):
+def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_augm, g_s, g_rgb, kept=None):
     """Recomputes the forward and returns the per-sample gradient dL/dx (P,3), the FiLM gradients (6,256) x 2 and the
     operand streams of the weight-gradient GEMMs (dict of dense (P, width) tensors, see ArahTrainGrads)."""
     lib = load_library()
@@ -631,8 +641,9 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
     E = lambda *shape: torch.empty(*shape, device=dev)
     st = {"sdf": E(n), "rgb4": E(n, 4), "gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256),
           "h": [E(n, 4)] + [E(n, 256) for _ in range(5)], "hd": [E(n, 4)] + [E(n, 256) for _ in range(6)],
-          "av": [E(n, 256) for _ in range(6)], "avd": [E(n, 256) for _ in range(6)], "cin": E(n, kin),
-          "c": [E(n, w) for w in (256, 256, 128, 256, 256)],
+          "av": [E(n, 256) for _ in range(6)], "avd": [E(n, 256) for _ in range(6)],
+          "cin": kept["cin"] if kept else E(n, kin),
+          "c": kept["c"] if kept else [E(n, w) for w in (256, 256, 128, 256, 256)],
           "d": [E(n, w) for w in (256, 256, 128, 256, 256)] + [E(n, 4)]}
     g = ArahTrainGrads()
     for k in ("sdf", "rgb4", "gx4", "film_freq", "film_phase", "cin"):
@@ -645,6 +656,11 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
     if getattr(ws, "train_slab", None) is None or ws.train_slab.numel() < nslab:
         ws.train_slab = torch.empty(nslab, dtype=torch.uint8, device=dev)
     tin = _train_in(x, T, view, vo, rotate_normal, ray_augm, g_s, g_rgb)
+    if kept:
+        tin.tap_cin = _ptr(kept["cin"])
+        for i, t in enumerate(kept["c"]):
+            tin.tap_c[i] = _ptr(t).value
+        tin.fwd_rgb4 = _ptr(kept["rgb4"])
     _check(lib.arah_shade_train_backward(C.byref(frame.handle), C.byref(tin), C.byref(g), _ptr(ws.train_slab),
                                          C.c_size_t(ws.train_slab.numel()), _ptr(buf), C.c_size_t(buf.numel()),
                                          _stream()), "arah_shade_train_backward")

@@ -131,8 +131,12 @@ class ShadeSamples(torch.autograd.Function):
     @staticmethod
     def forward(ctx, meta, x, *params):
         from . import hip
-        sdf, rgb = hip.shade_train_forward(meta["frame"], meta["ws"], x, meta["T"], meta["view"], meta["view_orig"],
-                                           meta["rotate_normal"], meta["ray_augm"])
+        # keep: the forward call leaves the colour MLP's activations for the backward (hip.shade_train_forward)
+        keep = os.environ.get("ARAH_TRAIN_HANDOVER", "1") != "0"
+        res = hip.shade_train_forward(meta["frame"], meta["ws"], x, meta["T"], meta["view"], meta["view_orig"],
+                                      meta["rotate_normal"], meta["ray_augm"], keep=keep)
+        sdf, rgb = res[0], res[1]
+        ctx.kept = res[2] if keep else None
         ctx.meta = meta
         ctx.save_for_backward(x, *params)
         return sdf, rgb
@@ -143,7 +147,8 @@ class ShadeSamples(torch.autograd.Function):
         meta = ctx.meta
         x, *params = ctx.saved_tensors
         st = hip.shade_train_backward(meta["frame"], meta["ws"], x, meta["T"], meta["view"], meta["view_orig"],
-                                      meta["rotate_normal"], meta["ray_augm"], g_sdf.contiguous(), g_rgb.contiguous())
+                                      meta["rotate_normal"], meta["ray_augm"], g_sdf.contiguous(), g_rgb.contiguous(),
+                                      kept=ctx.kept)
         sdf_w, sdf_b = params[0:7], params[7:14]
         col_w, col_b, pose = params[16:22], params[22:28], params[28]
         grads = []

@@ -256,6 +256,13 @@ typedef struct ArahTrainIn {
     const float* view_orig;     /* [P,3] (ray_augm) or NULL */
     const float* g_s;           /* [P]   dL/d sdf (normalised units)   -- backward only */
     const float* g_rgb;         /* [P,3] dL/d rgb                      -- backward only */
+    /* Optional hand-over from the forward to the backward call (all NULL: the backward recomputes the whole forward).
+     * Forward: tap_cin / tap_c non-NULL -> the colour MLP's input and hidden activations are written there.  Backward:
+     * the same buffers (they are also ArahTrainGrads.cin / .c) plus the forward's rgb -> the normal sweep and the colour
+     * MLP are not recomputed (9 of the backward kernel's 34 layer products, all on the fp32 MFMA). */
+    float* tap_cin;             /* [P,kInPad] */
+    float* tap_c[5];            /* [P,256] [P,256] [P,128] [P,256] [P,256] */
+    const float* fwd_rgb4;      /* [P,4] rgb of the forward call       -- backward only */
 } ArahTrainIn;
 
 /* Outputs of the backward.  Weight gradients are sums of outer products over all samples; the kernel streams their

@@ -57,6 +57,7 @@ def test_struct_sizes_match_header():
     n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 2 + 8 + 6 + 22 + 4 + 3 + 1   # sdf, skin (+2: point-owning-wave operands), colour (+6 transposed, +22 bf16 x 3 operands), knn, body, scalars
     assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * 3 + 4   # three ints (+ padding)
     assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
+    assert C.sizeof(hip.ArahTrainIn) == 4 * 4 + 8 * (6 + 1 + 5 + 1)
     assert C.sizeof(hip.ArahCounters) == 72
 
 
