@@ -741,14 +741,17 @@ def test_edge_cases(ctx, scene):
 
 
 @gpu
+@pytest.mark.parametrize("handover", [True, False])
 @pytest.mark.parametrize("name,ray_augm", [("zju313", True), ("zju377_mono", False), ("h36m", False)])
-def test_shade_samples_op_against_autograd(scene, name, ray_augm):
+def test_shade_samples_op_against_autograd(scene, name, ray_augm, handover, monkeypatch):
     """The hand-written forward / backward of loop D's per-sample part (training.ShadeSamples over csrc/train.hpp)
     against plain autograd on the same tensors: values, dL/dx and the gradient of EVERY parameter that reaches it
     (7 emitted SDF layers, FiLM frequencies / phases, the colour MLP's weight_g / weight_v / bias, the latent code),
     second-order path through the normal included, for the three config families (normal rotated by T / view
-    canonicalised, both colour modes) and with the view-augmentation revert (IDR:342-350)."""
+    canonicalised, both colour modes) and with the view-augmentation revert (IDR:342-350).  handover: the forward call
+    leaves the colour MLP's activations for the backward call (default) / the backward call recomputes everything."""
     from arah_release_amd import nets, renderer, training
+    monkeypatch.setenv("ARAH_TRAIN_HANDOVER", "1" if handover else "0")
     dev = torch.device("cuda:0")
     model, cfg = get_model(name, dev)
     idhr = model.idhr_network
