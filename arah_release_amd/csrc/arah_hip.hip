@@ -3710,13 +3710,15 @@ int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* s
                              size_t wbytes, void* stream) {
     if (!f || !in || !sdf || !rgb4 || !workspace || in->n < 0) return ARAH_E_BADARG;
     if (in->n == 0) return ARAH_OK;
-    if (!in->x || !in->view || (in->rotate_normal && !in->T) || (in->ray_augm && !in->view_orig)) return ARAH_E_BADARG;
+    if (!in->x) return ARAH_E_BADARG;
+    if (!in->geom_only && (!in->view || (in->rotate_normal && !in->T) || (in->ray_augm && !in->view_orig))) return ARAH_E_BADARG;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
     if (int arc = setup_attributes()) return arc;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const FrameDev fd = to_dev(*f);
     TrainIn ti{in->n, in->x, in->T, in->view, in->view_orig, in->rotate_normal, in->ray_augm, nullptr, nullptr};
+    ti.geom_only = in->geom_only ? 1 : 0;
     ti.tap_cin = in->tap_cin;
     for (int l = 0; l < 5; ++l) {
         if (in->tap_cin && !in->tap_c[l]) return ARAH_E_BADARG;
@@ -3746,8 +3748,8 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
                               size_t slab_bytes, void* workspace, size_t wbytes, void* stream) {
     if (!f || !in || !gr || !slab || !workspace || in->n < 0) return ARAH_E_BADARG;
     if (in->n == 0) return ARAH_OK;
-    if (!in->x || !in->view || (in->rotate_normal && !in->T) || (in->ray_augm && !in->view_orig) || !in->g_s || !in->g_rgb)
-        return ARAH_E_BADARG;
+    if (!in->x || !in->g_s || !in->g_rgb) return ARAH_E_BADARG;
+    if (!in->geom_only && (!in->view || (in->rotate_normal && !in->T) || (in->ray_augm && !in->view_orig))) return ARAH_E_BADARG;
     if (slab_bytes < arah_shade_train_slab_bytes()) return ARAH_E_WORKSPACE;
     Workspace w = carve(workspace, 1, 1);
     if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
@@ -3756,7 +3758,8 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
     const FrameDev fd = to_dev(*f);
     TrainIn ti{in->n, in->x, in->T, in->view, in->view_orig, in->rotate_normal, in->ray_augm, in->g_s, in->g_rgb};
     // hand-over from the forward call: its streams must be the ones the weight-gradient GEMMs will read
-    const bool handed = in->tap_cin && in->fwd_rgb4;
+    ti.geom_only = in->geom_only ? 1 : 0;
+    const bool handed = !in->geom_only && in->tap_cin && in->fwd_rgb4;
     if (handed) {
         if (in->tap_cin != gr->cin) return ARAH_E_BADARG;
         for (int l = 0; l < 5; ++l)

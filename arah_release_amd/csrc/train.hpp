@@ -46,6 +46,8 @@ struct TrainIn {
     float* tap_cin;           // forward: colour input stream out (or null); backward with fwd_rgb: the same, read only
     float* tap_c[5];
     const float* fwd_rgb;     // [P][4] the forward call's rgb: the backward then skips the normal sweep and the colour MLP
+    int geom_only;            // SDF value and normal only (the regulariser queries): no colour MLP; rgb <- the normal,
+                              // g_rgb = dL/dn, the feature h_6 goes out as c[0] in the backward
 };
 
 struct TrainOut {
@@ -141,8 +143,9 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][kNT];
-        const bool handed = BWD && in.fwd_rgb != nullptr;   // the forward call left cin, c1..c5 and rgb: nothing behind the
-        if (handed) {                                       // trunk is recomputed (wave-uniform)
+        const bool geom = in.geom_only != 0;
+        const bool handed = BWD && (geom || in.fwd_rgb != nullptr);   // the forward call left cin, c1..c5 and rgb (or there is
+        if (handed) {                                                 // no colour MLP): only the trunk is recomputed
             if constexpr (BWD) {
                 TrainTap tap;
                 tap.aslab = vslab;
@@ -150,13 +153,21 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 tap.row0 = row0;
                 tap.rows = rows;
                 sdf_trunk<false, kNT, B3, TrainTap>(net, xin, A, ldA, nullptr, dlast, wave, lane, tap);   // v_k, h_k only
+                if (geom) {   // the feature stream of dw_7; the colour MLP's gradient into h_6 is zero
+                    if constexpr (B3) unsplit_rows(A, ldA, tid);
+                    __syncthreads();
+                    stream_rows(A, ldA, 256, out.c[0], row0, rows, tid);
+                    __syncthreads();
+                    for (int e = tid; e < kTile * 64; e += kThreads)
+                        *reinterpret_cast<f32x4*>(A + (e >> 6) * ldA + (e & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+                } else
                 for (int e = tid; e < kTile * 64; e += kThreads) {   // B <- c5
                     const int r = e >> 6, c4 = e & 63;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (r < rows) v = reinterpret_cast<const f32x4*>(in.tap_c[4] + (row0 + r) * 256)[c4];
                     *reinterpret_cast<f32x4*>(B + r * ldB + c4 * 4) = v;
                 }
-                if (tid < kTile) {
+                if (!geom && tid < kTile) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
                     if (tid < rows) v = reinterpret_cast<const f32x4*>(in.fwd_rgb)[row0 + tid];
                     reinterpret_cast<f32x4*>(rgbv)[tid] = v;
@@ -184,6 +195,15 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         // test_shade_samples_op_against_autograd 10 % off); the reverse sweeps and the tangent pass have no gates
         sdf_backward<false>(net, B, ldB, spill, dlast, outv, 4, wave, lane, tid);
         __syncthreads();
+        if (geom) {   // regulariser queries: value and normal are the outputs
+            if (tid < rows) {
+                const long long p = row0 + tid;
+                out.sdf[p] = outv[tid * 4];
+                reinterpret_cast<f32x4*>(out.rgb)[p] = f32x4{outv[tid * 4 + 1], outv[tid * 4 + 2], outv[tid * 4 + 3], 0.f};
+            }
+            __syncthreads();
+            continue;
+        }
         // ---- colour input extras behind the feature: x(3), n(3) (rotated), [PE4(view) 27], zero pad
         if (tid < kTile) {
             float* e = A + tid * ldA + 256;
@@ -255,6 +275,15 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         }
         }   // !handed
         if constexpr (BWD) {
+            if (geom) {   // nt = dL/dn as given, no direct dL/dx, adj h_6 starts at zero (set above)
+                if (tid < kTile) {
+                    const f32x4 nt = {gin[tid * 4], gin[tid * 4 + 1], gin[tid * 4 + 2], 0.f};
+                    reinterpret_cast<f32x4*>(ntl)[tid] = nt;
+                    reinterpret_cast<f32x4*>(rgbv)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (tid < rows) reinterpret_cast<f32x4*>(out.hd[0])[row0 + tid] = nt;
+                }
+                __syncthreads();
+            } else {
             // =========================================================== 2. colour MLP backward
             // B holds c5.  delta_5 = g_rgb * rgb (1 - rgb)
             if (tid < kTile) {
@@ -400,6 +429,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 if (tid < rows) reinterpret_cast<f32x4*>(out.hd[0])[row0 + tid] = nt;
             }
             __syncthreads();
+            }   // !geom
             // =========================================================== 3. tangent pass hd_0 = nt  (B <- hd_k)
             {   // layer 1 (K = 3)
                 f32x4 xt[kNT];

@@ -70,7 +70,7 @@ class ArahFrame(C.Structure):
 
 
 class ArahTrainIn(C.Structure):
-    _fields_ = [("n", C.c_int32), ("rotate_normal", C.c_int32), ("ray_augm", C.c_int32), ("pad", C.c_int32),
+    _fields_ = [("n", C.c_int32), ("rotate_normal", C.c_int32), ("ray_augm", C.c_int32), ("geom_only", C.c_int32),
                 ("x", _fp), ("T", _fp), ("view", _fp), ("view_orig", _fp), ("g_s", _fp), ("g_rgb", _fp),
                 ("tap_cin", _fp), ("tap_c", _fp * 5), ("fwd_rgb4", _fp)]
 
@@ -625,6 +625,54 @@ def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_aug
     _check(lib.arah_shade_train_forward(C.byref(frame.handle), C.byref(tin), _ptr(sdf), _ptr(rgb4), _ptr(buf),
                                         C.c_size_t(buf.numel()), _stream()), "arah_shade_train_forward")
     return (sdf, rgb4[:, :3], kept) if keep else (sdf, rgb4[:, :3])
+
+
+@_guarded
+def sdf_normal_forward(frame, ws, x):
+    """The regulariser queries (IDR:104-128): x (P,3) normalised canonical points -> sdf (P,) in normalised units and its
+    gradient d sdf / d x (P,3), by the training kernel without its colour half (ArahTrainIn.geom_only)."""
+    lib = load_library()
+    x = _f32(x)
+    n = x.shape[0]
+    buf = ws.ensure(1, 1)
+    sdf = torch.empty(n, device=x.device)
+    n4 = torch.empty(n, 4, device=x.device)
+    tin = _train_in(x, None, None, None, False, False)
+    tin.geom_only = 1
+    _check(lib.arah_shade_train_forward(C.byref(frame.handle), C.byref(tin), _ptr(sdf), _ptr(n4), _ptr(buf),
+                                        C.c_size_t(buf.numel()), _stream()), "arah_shade_train_forward")
+    return sdf, n4[:, :3]
+
+
+@_guarded
+def sdf_normal_backward(frame, ws, x, g_s, g_n):
+    """dL/dx (P,3) and the operand streams of the SDF weight gradients (h, hd, av, avd, the feature h_6 as `feat`,
+    film_freq, film_phase) for upstream gradients g_s (P,) on the value and g_n (P,3) on the normal."""
+    lib = load_library()
+    x, g_s, g_n = _f32(x), _f32(g_s), _f32(g_n)
+    n, dev = x.shape[0], x.device
+    buf = ws.ensure(1, 1)
+    E = lambda *shape: torch.empty(*shape, device=dev)
+    st = {"gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256), "feat": E(n, 256),
+          "h": [E(n, 4)] + [E(n, 256) for _ in range(5)], "hd": [E(n, 4)] + [E(n, 256) for _ in range(6)],
+          "av": [E(n, 256) for _ in range(6)], "avd": [E(n, 256) for _ in range(6)]}
+    g = ArahTrainGrads()
+    for k in ("gx4", "film_freq", "film_phase"):
+        setattr(g, k, _ptr(st[k]))
+    for k in ("h", "hd", "av", "avd"):
+        arr = getattr(g, k)
+        for i, t in enumerate(st[k]):
+            arr[i] = _ptr(t).value
+    g.c[0] = _ptr(st["feat"]).value
+    nslab = lib.arah_shade_train_slab_bytes()
+    if getattr(ws, "train_slab", None) is None or ws.train_slab.numel() < nslab:
+        ws.train_slab = torch.empty(nslab, dtype=torch.uint8, device=dev)
+    tin = _train_in(x, None, None, None, False, False, g_s, g_n)
+    tin.geom_only = 1
+    _check(lib.arah_shade_train_backward(C.byref(frame.handle), C.byref(tin), C.byref(g), _ptr(ws.train_slab),
+                                         C.c_size_t(ws.train_slab.numel()), _ptr(buf), C.c_size_t(buf.numel()),
+                                         _stream()), "arah_shade_train_backward")
+    return st
 
 
 @_guarded

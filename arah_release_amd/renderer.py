@@ -207,14 +207,26 @@ class IDHRNetwork(nn.Module):
                 skinning_weights=input["skinning_weights"], vol_feat=input["vol_feat"],
                 bone_transforms=input["bone_transforms"], trans=input["trans"], coord_min=cmin, coord_max=cmax,
                 center=center, eval_mode=False, frame=frame)
-        inside_sdf = sdf_network(input["points_inside"]).squeeze(0) if "points_inside" in input else None
         n_reg = 1024
         eik = ((draw_uniform((B, n_reg, 3), dev, "eikonal") - 0.5) * 2).reshape(-1, 3)
-        probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3)], dim=0).requires_grad_(True)
-        sdf_probe = sdf_network(probe).squeeze(0)
-        uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
-        grad_eik = torch.autograd.grad(sdf_probe, probe, torch.ones_like(sdf_probe), create_graph=True,
-                                       retain_graph=True)[0][:B * n_reg]
+        if frame is not None and use_hip_shading and os.environ.get("ARAH_TRAIN_PROBE_OP", "1") != "0":
+            # the regulariser queries (IDR:104-128) through the training kernel without its colour half: value and gradient
+            # in one launch, the second-order path of the eikonal term in one more (training.SdfNormal) -- the autograd
+            # SIREN below is ~100 launches forward and ~150 backward for the same numbers
+            pts_in = input["points_inside"].reshape(-1, 3) if "points_inside" in input else eik[:0]
+            probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3), pts_in], dim=0)
+            sdf_probe, n_probe = training.sdf_normal_hip(frame, self.ray_tracer.workspace(dev), sdf_network, probe)
+            uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
+            grad_eik = n_probe[:B * n_reg]
+            inside_sdf = sdf_probe[2 * B * n_reg:].reshape(input["points_inside"].shape[:-1] + (1,)).squeeze(0) \
+                if "points_inside" in input else None
+        else:
+            inside_sdf = sdf_network(input["points_inside"]).squeeze(0) if "points_inside" in input else None
+            probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3)], dim=0).requires_grad_(True)
+            sdf_probe = sdf_network(probe).squeeze(0)
+            uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
+            grad_eik = torch.autograd.grad(sdf_probe, probe, torch.ones_like(sdf_probe), create_graph=True,
+                                           retain_graph=True)[0][:B * n_reg]
         vol_mask = s_mask.any(-1)
         dirs_in, ray_augm = ray_dirs, False
         if "view_noise" in pose_cond:

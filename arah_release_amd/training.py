@@ -197,6 +197,52 @@ class ShadeSamples(torch.autograd.Function):
         return (None, st["gx4"][:, :3]) + tuple(grads)
 
 
+class SdfNormal(torch.autograd.Function):
+    """SDF value and gradient at query points as one custom op on the training kernel without its colour half: what
+    `sdf_network(x)` + `autograd.grad(sdf, x, create_graph=True)` give the regularisers (IDR:104-128: eikonal on the gradient,
+    off-surface / inside terms on the value), with the second-order path into every SDF parameter in the backward.
+    apply(meta, x, *params): meta = dict(frame, ws), params = 7 weights, 7 biases, freq, phase (as in ShadeSamples)."""
+
+    @staticmethod
+    def forward(ctx, meta, x, *params):
+        from . import hip
+        sdf, normal = hip.sdf_normal_forward(meta["frame"], meta["ws"], x)
+        ctx.meta = meta
+        ctx.save_for_backward(x, *params)
+        return sdf, normal
+
+    @staticmethod
+    def backward(ctx, g_sdf, g_n):
+        from . import hip
+        x, *params = ctx.saved_tensors
+        g_sdf, g_n = g_sdf.contiguous(), g_n.contiguous()
+        st = hip.sdf_normal_backward(ctx.meta["frame"], ctx.meta["ws"], x, g_sdf, g_n)
+        sdf_w, sdf_b = params[0:7], params[7:14]
+        grads = []
+        for k in range(6):   # dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1}
+            n_in = sdf_w[k].shape[-1]
+            grads.append((gram(st["av"][k], st["h"][k][:, :n_in]) + gram(st["avd"][k], st["hd"][k][:, :n_in]))
+                         .reshape(sdf_w[k].shape))
+        grads.append((gram(g_sdf.reshape(-1, 1), st["feat"]) + st["hd"][6].sum(0, keepdim=True)).reshape(sdf_w[6].shape))
+        for k in range(6):
+            grads.append(st["av"][k].sum(0).reshape(sdf_b[k].shape))
+        grads.append(g_sdf.sum().reshape(sdf_b[6].shape))
+        grads.append(st["film_freq"].reshape(params[14].shape))
+        grads.append(st["film_phase"].reshape(params[15].shape))
+        return (None, st["gx4"][:, :3]) + tuple(grads)
+
+
+def sdf_normal_hip(frame, ws, sdf_network, x):
+    """x (P,3) normalised -> sdf (P,1) in normalised units, d sdf / d x (P,3); differentiable w.r.t. the emitted network."""
+    n = len(sdf_network)
+    sdf_w = [sdf_network[i][0].weights[0] for i in range(n - 1)] + [sdf_network[n - 1].weights[0]]
+    sdf_b = [sdf_network[i][0].biases.reshape(-1) for i in range(n - 1)] + [sdf_network[n - 1].biases.reshape(-1)]
+    freq = torch.cat([sdf_network[i][0].freq.reshape(-1) for i in range(n - 1)])
+    phase = torch.cat([sdf_network[i][0].phase_shift.reshape(-1) for i in range(n - 1)])
+    sdf, normal = SdfNormal.apply(dict(frame=frame, ws=ws), x.contiguous(), *(sdf_w + sdf_b + [freq, phase]))
+    return sdf.unsqueeze(-1), normal
+
+
 def shade_samples_hip(idhr, frame, ws, sdf_network, x, T, view, view_orig, pose_cond, ray_augm):
     """x (P,3) -> sdf (P,1) normalised units, rgb (P,3), differentiable w.r.t. x and every network parameter."""
     from .nets import folded_weight

@@ -249,7 +249,9 @@ typedef struct ArahTrainIn {
     int32_t n;                  /* P valid samples, dense */
     int32_t rotate_normal;      /* !cano_view_dirs: the colour net sees R n with R = T[:3,:3] (IDR:339-340) */
     int32_t ray_augm;           /* IDR:342-350: where n . view <= 0 the un-augmented view is used */
-    int32_t pad;
+    int32_t geom_only;          /* 1: SDF value and normal only (the regulariser queries of IDR:104-128): the forward returns the
+                                   normal in rgb4[:, :3]; the backward takes dL/dn in g_rgb and writes the feature stream h_6
+                                   to ArahTrainGrads.c[0]; T / view are ignored, no hand-over */
     const float* x;             /* [P,3] normalised canonical points */
     const float* T;             /* [P,16] forward transforms (rotate_normal) or NULL */
     const float* view;          /* [P,3] view input of the colour net */

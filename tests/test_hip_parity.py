@@ -831,6 +831,65 @@ def test_shade_samples_op_against_autograd(scene, name, ray_augm, handover, monk
 
 
 @gpu
+def test_sdf_normal_op_against_autograd(scene):
+    """training.SdfNormal (the regulariser queries: the training kernel without its colour half) against the autograd
+    SIREN: value, gradient w.r.t. the query point, and the gradient of a loss on BOTH (eikonal-style second-order path)
+    w.r.t. every emitted SDF parameter and the query points."""
+    from arah_release_amd import nets, renderer, training
+    dev = torch.device("cuda:0")
+    model, cfg = get_model("zju313", dev)
+    idhr = model.idhr_network
+    inputs = scene.make_inputs(64, 64, frame_idx=2, device=dev)
+    g = torch.Generator().manual_seed(5)
+    P = 300   # ragged: 4 full tiles + 44
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})["decoder"]
+    layers, leaves = [], []
+    for i in range(6):
+        lin = dec[i][0]
+        w, b = lin.weights.clone().requires_grad_(True), lin.biases.clone().requires_grad_(True)
+        f, p = lin.freq.clone().requires_grad_(True), lin.phase_shift.clone().requires_grad_(True)
+        leaves += [w, b, f, p]
+        layers.append(torch.nn.Sequential(nets.EmittedFiLMLinear(w, b, f, p), nets.Sine()))
+    w7, b7 = dec[6].weights.clone().requires_grad_(True), dec[6].biases.clone().requires_grad_(True)
+    leaves += [w7, b7]
+    sdf_network = torch.nn.Sequential(*layers, nets.EmittedLinear(w7, b7))
+    x = ((torch.rand(P, 3, generator=g) * 1.6 - 0.8)).to(dev).requires_grad_(True)
+    g_s = torch.randn(P, generator=g).to(dev)
+    g_n = torch.randn(P, 3, generator=g).to(dev)
+    everything = [x] + leaves
+
+    def loss_of(sdf, normal):   # a value term and a term on the gradient's norm and direction
+        return (sdf.reshape(-1) * g_s).sum() + ((normal.norm(dim=-1) - 1.0).abs()).sum() + (normal * g_n).sum()
+
+    xi = x.unsqueeze(0)
+    sdf_ref = sdf_network(xi).squeeze(0)
+    n_ref = torch.autograd.grad(sdf_ref, xi, torch.ones_like(sdf_ref), create_graph=True, retain_graph=True)[0].squeeze(0)
+    ref = torch.autograd.grad(loss_of(sdf_ref, n_ref), everything, allow_unused=True)
+    with torch.no_grad():
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(sdf_network, model.skinning_model, idhr.rendering_network, model.deviation_decoder,
+                                     pose_cond, inputs["smpl_verts"], inputs["skinning_weights"],
+                                     inputs["bone_transforms"], inputs["trans"], inputs["coord_min"], inputs["coord_max"],
+                                     inputs["center"])
+    ws = idhr.ray_tracer.workspace(dev)
+    sdf_hip, n_hip = training.sdf_normal_hip(frame, ws, sdf_network, x)
+    got = torch.autograd.grad(loss_of(sdf_hip, n_hip), everything, allow_unused=True)
+    np.testing.assert_allclose(sdf_hip.reshape(-1).detach().cpu().numpy(), sdf_ref.reshape(-1).detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(n_hip.detach().cpu().numpy(), n_ref.detach().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    names = ["x"] + ["sdf%d.%s" % (i // 4, "wbfp"[i % 4]) for i in range(24)] + ["sdf6.w", "sdf6.b"]
+    for nm, a, b in zip(names, got, ref):
+        assert (a is None) == (b is None), nm
+        if a is None:
+            continue
+        a, b = a.detach().cpu().numpy().astype(np.float64), b.detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(b).max() + 1e-12
+        assert np.abs(a - b).max() <= 2e-3 * scale, (nm, np.abs(a - b).max(), scale)
+
+
+@gpu
 def test_gemv_rows_against_torch():
     """arah_gemv_rows (the hypernetwork's wide output layers at inference) against F.linear, odd row counts included; and
     the emitted SDF layers of a model are the same through either path."""
