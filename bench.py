@@ -287,7 +287,8 @@ class GpuRuntime:
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         return {"note": "ZJUMOCAP-313 training step, 1 view x 2048 rays on one GPU: HIP ray tracer (no_grad) + hand-written "
-                        "loop-D forward/backward (k_shade_train) + regularisers / loss / hypernetwork on autograd + Adam",
+                        "loop-D forward/backward and regulariser queries (k_shade_train) + compositing / loss / hypernetwork on "
+                        "autograd + fused Adam",
                 "value": 2048 * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
 
 
