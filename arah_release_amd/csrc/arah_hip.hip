@@ -3813,6 +3813,35 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
     return check_launch();
 }
 
+// ---- density + compositing of the training forward and their backward (csrc/train.hpp) --------------------------------
+int arah_composite_train_forward(int32_t n_rays, int32_t n_steps, int32_t render_last_pt, const int32_t* len,
+                                 const int64_t* off, const float* sdf, const float* rgb, const float* z, const float* inv_beta,
+                                 float* out_rgb, float* out_acc, void* stream) {
+    if (n_rays < 0 || n_steps <= 0 || n_steps > ARAH_MAX_STEPS) return ARAH_E_BADARG;
+    if (n_rays == 0) return ARAH_OK;
+    if (!len || !off || !sdf || !rgb || !z || !inv_beta || !out_rgb || !out_acc) return ARAH_E_BADARG;
+    hipLaunchKernelGGL(k_composite_train_fwd, dim3((n_rays + 63) / 64), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), n_rays,
+                       len, reinterpret_cast<const long long*>(off), sdf, rgb, z, inv_beta, render_last_pt, 1.0f / (float)n_steps,
+                       out_rgb, out_acc);
+    return check_launch();
+}
+
+int arah_composite_train_backward(int32_t n_rays, int32_t n_steps, int32_t render_last_pt, const int32_t* len,
+                                  const int64_t* off, const float* sdf, const float* rgb, const float* z, const float* inv_beta,
+                                  const float* g_rgb_map, const float* g_acc, float* g_sdf, float* g_rgb, float* g_inv_beta,
+                                  void* stream) {
+    if (n_rays < 0 || n_steps <= 0 || n_steps > ARAH_MAX_STEPS) return ARAH_E_BADARG;
+    if (!g_inv_beta) return ARAH_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(g_inv_beta, 0, 4, s) != hipSuccess) return ARAH_E_LAUNCH;
+    if (n_rays == 0) return ARAH_OK;
+    if (!len || !off || !sdf || !rgb || !z || !inv_beta || !g_rgb_map || !g_acc || !g_sdf || !g_rgb) return ARAH_E_BADARG;
+    hipLaunchKernelGGL(k_composite_train_bwd, dim3((n_rays + 63) / 64), dim3(64), 0, s, n_rays, len,
+                       reinterpret_cast<const long long*>(off), sdf, rgb, z, inv_beta, render_last_pt, 1.0f / (float)n_steps,
+                       g_rgb_map, g_acc, g_sdf, g_rgb, g_inv_beta);
+    return check_launch();
+}
+
 // ---- skinny weight-gradient products of the training step -------------------------------------------------------
 // out[i][j] = sum_p a[p][i] b[p][j] with m <= 4 rows (the 1 x 256 SDF head, the 3 x 256 colour head, the 256 x 3 first
 // SIREN layer transposed): one pass over b at HBM speed.  A workgroup reduces kGramRows rows into partial[block][m][n];

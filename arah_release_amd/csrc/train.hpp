@@ -594,6 +594,103 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
     }
 }
 
+// ---- VolSDF density + alpha compositing of the training forward, with their backward (IDR:363-394) --------------------
+// One thread per ray over its L valid samples, which sit next to each other in the compacted per-sample arrays (offset
+// off[r]): s = SDF in metres, c = colour, z = depth.  With ib = 1 / beta:
+//   psi = 1/2 + 1/2 sign(-s) (1 - exp(-|s| ib)),  d = relu(ib psi),  alpha = 1 - exp(-d delta),
+//   q = 1 - alpha + 1e-7,  T_k = prod_{j<k} q_j,  w = alpha T,  C = sum w c,  A = sum w,  acc = clip(A, 0, 1)
+// delta_k = z_{k+1} - z_k; the last valid sample takes 1e10 (render_last_pt) or 1 / n_steps.  The arithmetic follows the
+// torch expressions of training.shade_composite_train operation by operation (the sums over k run in order here, as a
+// tree there).
+__device__ __forceinline__ float comp_delta(const float* z, long long p0, int k, int L, int render_last_pt, float inv_steps) {
+    return k + 1 < L ? z[p0 + k + 1] - z[p0 + k] : (render_last_pt ? 1e10f : inv_steps);
+}
+__device__ __forceinline__ void comp_density(float s, float ib, float& dens, float& dpsi_ds, float& dpsi_dib, float& psi) {
+    const float e = expf(-fabsf(s) * ib);
+    const float sg = s < 0.f ? 1.0f : (s > 0.f ? -1.0f : 0.f);   // sign(-s)
+    psi = 0.5f + 0.5f * sg * (1.0f - e);
+    dens = fmaxf(ib * psi, 0.f);
+    dpsi_ds = s != 0.f ? -0.5f * ib * e : 0.f;
+    dpsi_dib = -0.5f * s * e;   // 1/2 sign(-s) |s| e
+}
+
+__global__ void k_composite_train_fwd(int n_rays, const int* __restrict__ len, const long long* __restrict__ off,
+                                      const float* __restrict__ sdf, const float* __restrict__ rgb, const float* __restrict__ z,
+                                      const float* __restrict__ inv_beta, int render_last_pt, float inv_steps,
+                                      float* __restrict__ out_rgb, float* __restrict__ out_acc) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int L = len[r];
+    const long long p0 = off[r];
+    const float ib = inv_beta[0];
+    float cr = 0.f, cg = 0.f, cb = 0.f, A = 0.f, T = 1.0f;
+    for (int k = 0; k < L; ++k) {
+        float dens, a1, a2, psi;
+        comp_density(sdf[p0 + k], ib, dens, a1, a2, psi);
+        const float alpha = 1.0f - expf(-dens * comp_delta(z, p0, k, L, render_last_pt, inv_steps));
+        const float w = alpha * T;
+        cr += rgb[(p0 + k) * 3] * w;
+        cg += rgb[(p0 + k) * 3 + 1] * w;
+        cb += rgb[(p0 + k) * 3 + 2] * w;
+        A += w;
+        T *= 1.0f - alpha + 1e-7f;
+    }
+    out_rgb[(size_t)r * 3] = cr;
+    out_rgb[(size_t)r * 3 + 1] = cg;
+    out_rgb[(size_t)r * 3 + 2] = cb;
+    out_acc[r] = fminf(fmaxf(A, 0.f), 1.f);
+}
+
+// g_rgb_map [n_rays][3], g_acc [n_rays]  ->  g_sdf [P], g_rgb [P][3], g_ib += (one atomic per ray)
+__global__ void k_composite_train_bwd(int n_rays, const int* __restrict__ len, const long long* __restrict__ off,
+                                      const float* __restrict__ sdf, const float* __restrict__ rgb, const float* __restrict__ z,
+                                      const float* __restrict__ inv_beta, int render_last_pt, float inv_steps,
+                                      const float* __restrict__ g_map, const float* __restrict__ g_acc,
+                                      float* __restrict__ g_sdf, float* __restrict__ g_rgb, float* __restrict__ g_ib) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rays) return;
+    const int L = len[r];
+    const long long p0 = off[r];
+    const float ib = inv_beta[0];
+    const float gr = g_map[(size_t)r * 3], gg = g_map[(size_t)r * 3 + 1], gb = g_map[(size_t)r * 3 + 2];
+    // forward once more for A (the clip's gate) and the transmittances (kept: dividing them back out loses them once the
+    // product has underflowed)
+    float Tk[ARAH_MAX_STEPS];
+    float A = 0.f, T = 1.0f;
+    for (int k = 0; k < L; ++k) {
+        float dens, a1, a2, psi;
+        comp_density(sdf[p0 + k], ib, dens, a1, a2, psi);
+        const float alpha = 1.0f - expf(-dens * comp_delta(z, p0, k, L, render_last_pt, inv_steps));
+        Tk[k] = T;
+        A += alpha * T;
+        T *= 1.0f - alpha + 1e-7f;
+    }
+    const float gA = (A >= 0.f && A <= 1.f) ? g_acc[r] : 0.f;
+    // reverse sweep: suffix = sum_{j>k} u_j w_j
+    float suffix = 0.f, gib = 0.f;
+    for (int k = L - 1; k >= 0; --k) {
+        float dens, dpsi_ds, dpsi_dib, psi;
+        const float s = sdf[p0 + k];
+        comp_density(s, ib, dens, dpsi_ds, dpsi_dib, psi);
+        const float delta = comp_delta(z, p0, k, L, render_last_pt, inv_steps);
+        const float ex = expf(-dens * delta);
+        const float alpha = 1.0f - ex, q = 1.0f - alpha + 1e-7f;
+        T = Tk[k];
+        const float w = alpha * T;
+        const float c0 = rgb[(p0 + k) * 3], c1 = rgb[(p0 + k) * 3 + 1], c2 = rgb[(p0 + k) * 3 + 2];
+        g_rgb[(p0 + k) * 3] = gr * w;
+        g_rgb[(p0 + k) * 3 + 1] = gg * w;
+        g_rgb[(p0 + k) * 3 + 2] = gb * w;
+        const float u = gr * c0 + gg * c1 + gb * c2 + gA;
+        const float g_alpha = u * T - suffix / q;
+        suffix += u * w;
+        const float g_dens = (ib * psi > 0.f) ? g_alpha * delta * ex : 0.f;
+        g_sdf[p0 + k] = g_dens * ib * dpsi_ds;
+        gib += g_dens * (psi + ib * dpsi_dib);
+    }
+    if (L > 0) atomicAdd(g_ib, gib);
+}
+
 template <bool IDR>
 constexpr size_t lds_shade_train() {
     return (64 * 4 * 6) * 4 + (size_t)64 * ColDims<IDR>::kLdA * 4 + (size_t)64 * kSdfLd * 4;

@@ -93,7 +93,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
+           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events", "arah_set_canon_events"]
 
 _lib = None
@@ -713,6 +713,32 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
                                          C.c_size_t(ws.train_slab.numel()), _ptr(buf), C.c_size_t(buf.numel()),
                                          _stream()), "arah_shade_train_backward")
     return st
+
+
+@_guarded
+def composite_train_forward(lengths, offsets, sdf, rgb, z, inv_beta, n_steps, render_last_pt):
+    """lengths (R,) int32, offsets (R,) int64 into the compacted per-sample arrays sdf (P,) [metres], rgb (P,3), z (P,);
+    inv_beta (1,) -> rgb_map (R,3), acc (R,) = clip(sum of weights, 0, 1)."""
+    lib = load_library()
+    R, dev = int(lengths.shape[0]), sdf.device
+    out_rgb, out_acc = torch.empty(R, 3, device=dev), torch.empty(R, device=dev)
+    _check(lib.arah_composite_train_forward(C.c_int32(R), C.c_int32(int(n_steps)), C.c_int32(int(bool(render_last_pt))),
+                                            _ptr(lengths), _ptr(offsets), _ptr(sdf), _ptr(rgb), _ptr(z), _ptr(inv_beta),
+                                            _ptr(out_rgb), _ptr(out_acc), _stream()), "arah_composite_train_forward")
+    return out_rgb, out_acc
+
+
+@_guarded
+def composite_train_backward(lengths, offsets, sdf, rgb, z, inv_beta, n_steps, render_last_pt, g_map, g_acc):
+    """-> dL/d sdf (P,), dL/d rgb (P,3), dL/d inv_beta (1,)"""
+    lib = load_library()
+    R, dev = int(lengths.shape[0]), sdf.device
+    g_sdf, g_rgb, g_ib = torch.empty_like(sdf), torch.empty_like(rgb), torch.empty(1, device=dev)
+    _check(lib.arah_composite_train_backward(C.c_int32(R), C.c_int32(int(n_steps)), C.c_int32(int(bool(render_last_pt))),
+                                             _ptr(lengths), _ptr(offsets), _ptr(sdf), _ptr(rgb), _ptr(z), _ptr(inv_beta),
+                                             _ptr(_f32(g_map)), _ptr(_f32(g_acc)), _ptr(g_sdf), _ptr(g_rgb), _ptr(g_ib),
+                                             _stream()), "arah_composite_train_backward")
+    return g_sdf, g_rgb, g_ib
 
 
 def mesh_query(verts, faces, pts):

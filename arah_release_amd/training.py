@@ -264,6 +264,30 @@ def shade_samples_hip(idhr, frame, ws, sdf_network, x, T, view, view_orig, pose_
     return sdf.unsqueeze(-1), rgb
 
 
+class CompositeSamples(torch.autograd.Function):
+    """VolSDF density and alpha compositing over the compacted samples of every ray as one launch each way
+    (arah_composite_train_forward / _backward, csrc/train.hpp) instead of ~40 element-wise launches and ~100 in backward.
+    apply(lengths int32 (R,), offsets int64 (R,), z (P,), n_steps, render_last_pt, sdf (P,), rgb (P,3), inv_beta (1,))
+    -> rgb_map (R,3), acc (R,)."""
+
+    @staticmethod
+    def forward(ctx, lengths, offsets, z, n_steps, render_last_pt, sdf, rgb, inv_beta):
+        from . import hip
+        sdf, rgb, inv_beta = sdf.contiguous(), rgb.contiguous(), inv_beta.reshape(1).contiguous()
+        out = hip.composite_train_forward(lengths, offsets, sdf, rgb, z, inv_beta, n_steps, render_last_pt)
+        ctx.save_for_backward(lengths, offsets, z, sdf, rgb, inv_beta)
+        ctx.cfg = (n_steps, render_last_pt)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_map, g_acc):
+        from . import hip
+        lengths, offsets, z, sdf, rgb, inv_beta = ctx.saved_tensors
+        g_sdf, g_rgb, g_ib = hip.composite_train_backward(lengths, offsets, sdf, rgb, z, inv_beta, ctx.cfg[0], ctx.cfg[1],
+                                                          g_map.contiguous(), g_acc.contiguous())
+        return None, None, None, None, None, g_sdf, g_rgb, g_ib
+
+
 def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, converge_mask, view_dirs,
                           view_dirs_orig, pose_cond, bone_transforms, coord_min, coord_max, center, n_steps,
                           ray_augm=False, point_batch_size=100000, frame=None, ws=None):
@@ -332,6 +356,17 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
         rgb_all.append(idhr.rendering_network(pi.squeeze(0), normal.squeeze(0), vi, feat, pose_cond))
     sdf_v = torch.cat(sdf_all, dim=0)
     rgb_v = torch.cat(rgb_all, dim=0)
+    from .nets import SingleVarianceNetwork
+    if (frame is not None and isinstance(idhr.deviation_network, SingleVarianceNetwork)
+            and os.environ.get("ARAH_TRAIN_COMPOSITE_OP", "1") != "0"):
+        # density + compositing as one op on the compacted samples (rays own contiguous runs of them: nonzero() is row-major);
+        # beta is one number (decoder.py:127-133: ones_like(x) * |variance|)
+        inv_beta = torch.reciprocal(torch.linalg.norm(idhr.deviation_network.variance).clip(1e-6, 1e6))
+        len32 = lengths.to(torch.int32)
+        offsets = torch.cumsum(lengths, 0) - lengths
+        rgb_map, acc = CompositeSamples.apply(len32, offsets, z_vals[ridx, sidx].contiguous(), n_steps, idhr.render_last_pt,
+                                              sdf_v.reshape(-1), rgb_v, inv_beta.reshape(1))
+        return rgb_map, acc.unsqueeze(-1)
     beta = idhr.deviation_network(sdf_v).clip(1e-6, 1e6)
     inv_beta = torch.reciprocal(beta)
     dens_v = F.relu(inv_beta * (0.5 + 0.5 * torch.sign(-sdf_v) * (1 - torch.exp(-sdf_v.abs() * inv_beta))))

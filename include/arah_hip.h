@@ -294,6 +294,19 @@ int arah_shade_train_forward(const ArahFrame* h_frame, const ArahTrainIn* h_in, 
 int arah_shade_train_backward(const ArahFrame* h_frame, const ArahTrainIn* h_in, const ArahTrainGrads* h_out,
                               void* slab, size_t slab_bytes, void* workspace, size_t workspace_bytes, void* stream);
 
+/* VolSDF density + alpha compositing of the TRAINING forward and their backward (IDR:363-394 with self.training): one
+ * thread per ray over its `len[r]` valid samples, which are contiguous from `off[r]` in the compacted per-sample arrays
+ * sdf [P] (metres), rgb [P,3], z [P].  inv_beta: device scalar 1 / beta.  acc is clip(sum of weights, 0, 1).  The
+ * backward takes dL/d rgb_map [n_rays,3] and dL/d acc [n_rays] and returns dL/d sdf [P], dL/d rgb [P,3] and the scalar
+ * dL/d inv_beta.  Replaces ~40 element-wise launches forward and ~100 backward of the autograd formulation. */
+int arah_composite_train_forward(int32_t n_rays, int32_t n_steps, int32_t render_last_pt, const int32_t* len,
+                                 const int64_t* off, const float* sdf, const float* rgb, const float* z, const float* inv_beta,
+                                 float* out_rgb, float* out_acc, void* stream);
+int arah_composite_train_backward(int32_t n_rays, int32_t n_steps, int32_t render_last_pt, const int32_t* len,
+                                  const int64_t* off, const float* sdf, const float* rgb, const float* z, const float* inv_beta,
+                                  const float* g_rgb_map, const float* g_acc, float* g_sdf, float* g_rgb, float* g_inv_beta,
+                                  void* stream);
+
 /* Skinny weight-gradient product of the training step: partial[blk][i][j] = sum over the block's rows p of
  * a[p*lda + i] * b[p*ldb + j], i < m <= 4, j < n; blk < arah_gram_skinny_blocks(n_rows).  The caller sums over blk.
  * (The reference leaves these to autograd's matmul backward: IDR:336-361 through torch.autograd.) */

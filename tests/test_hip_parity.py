@@ -890,6 +890,68 @@ def test_sdf_normal_op_against_autograd(scene):
 
 
 @gpu
+@pytest.mark.parametrize("render_last_pt", [False, True])
+def test_composite_samples_op_against_torch(render_last_pt):
+    """training.CompositeSamples (VolSDF density + alpha compositing over the compacted samples, forward and backward in one
+    launch each) against the torch expressions of shade_composite_train on ragged rays: empty rays, full rays, samples on
+    both sides of the surface and exactly on it, opaque runs (alpha = 1: the transmittance hits 1e-7 per sample)."""
+    import torch.nn.functional as F
+    from arah_release_amd import training
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    R, S = 300, 64
+    lengths = torch.randint(0, S + 1, (R,), generator=g)
+    lengths[:4] = torch.tensor([0, S, 1, 2])
+    mask = (torch.arange(S)[None, :] < lengths[:, None])
+    P = int(lengths.sum())
+    sdf = (torch.randn(P, generator=g) * 0.02)
+    sdf[::17] = 0.0
+    sdf[5:40] = -0.05                                   # an opaque run
+    rgb = torch.rand(P, 3, generator=g)
+    z = torch.sort(torch.rand(R, S, generator=g) * 2 + 1, dim=1)[0][mask]
+    var = torch.tensor(2e-3)
+    g_map, g_acc = torch.randn(R, 3, generator=g), torch.randn(R, generator=g)
+    sdf, rgb, z, var, g_map, g_acc, lengths = [t.to(dev) for t in (sdf, rgb, z, var, g_map, g_acc, lengths)]
+    mask = mask.to(dev)
+
+    def reference(sdf, rgb, var):
+        inv_beta = torch.reciprocal(torch.linalg.norm(var).clip(1e-6, 1e6))
+        dens_v = F.relu(inv_beta * (0.5 + 0.5 * torch.sign(-sdf) * (1 - torch.exp(-sdf.abs() * inv_beta))))
+        ridx, sidx = mask.nonzero(as_tuple=True)
+        flat = ridx * S + sidx
+        col = torch.zeros(R * S, 3, device=dev).index_copy(0, flat, rgb).reshape(R, S, 3)
+        dens = torch.zeros(R * S, device=dev).index_copy(0, flat, dens_v).reshape(R, S)
+        zp = torch.full((R * S,), 1e10, device=dev).index_copy(0, flat, z).reshape(R, S)
+        delta = zp[:, 1:] - zp[:, :-1]
+        if render_last_pt:
+            delta = torch.cat([delta, torch.full((R, 1), 1e10, device=dev)], dim=-1)
+        else:
+            delta = torch.cat([delta, torch.full((R, 1), 1.0 / S, device=dev)], dim=-1)
+            last = F.one_hot((lengths - 1).clamp(min=0), S).bool() & (lengths > 0)[:, None]
+            delta = torch.where(last, torch.full_like(delta, 1.0 / S), delta)
+        alpha = 1.0 - torch.exp(-dens * delta)
+        trans = torch.cumprod(torch.cat([torch.ones(R, 1, device=dev), 1.0 - alpha + 1e-7], dim=-1), dim=-1)[:, :-1]
+        w = alpha * trans * mask
+        return (col * w.unsqueeze(-1)).sum(dim=1), w.sum(dim=-1).clip(0, 1)
+
+    def op(sdf, rgb, var):
+        inv_beta = torch.reciprocal(torch.linalg.norm(var).clip(1e-6, 1e6))
+        off = torch.cumsum(lengths, 0) - lengths
+        return training.CompositeSamples.apply(lengths.to(torch.int32), off, z, S, render_last_pt, sdf, rgb, inv_beta.reshape(1))
+
+    outs = []
+    for fn in (reference, op):
+        a, b, c = sdf.clone().requires_grad_(True), rgb.clone().requires_grad_(True), var.clone().requires_grad_(True)
+        m, acc = fn(a, b, c)
+        grads = torch.autograd.grad((m * g_map).sum() + (acc * g_acc).sum(), [a, b, c])
+        outs.append((m, acc) + grads)
+    for name, x, y in zip(("rgb_map", "acc", "g_sdf", "g_rgb", "g_variance"), outs[1], outs[0]):
+        x, y = x.detach().cpu().numpy().astype(np.float64), y.detach().cpu().numpy().astype(np.float64)
+        scale = np.abs(y).max() + 1e-12
+        assert np.abs(x - y).max() <= 2e-5 * scale + 1e-7, (name, np.abs(x - y).max(), scale)
+
+
+@gpu
 def test_gemv_rows_against_torch():
     """arah_gemv_rows (the hypernetwork's wide output layers at inference) against F.linear, odd row counts included; and
     the emitted SDF layers of a model are the same through either path."""
