@@ -109,8 +109,14 @@ class HyperLinear(nn.Module):
         self.register_buffer("hypo_params_init", torch.zeros(1, in_ch * out_ch + out_ch))
         self.hypo_params = _HyperHead(hyper_in_ch, hyper_hidden_ch, in_ch * out_ch + out_ch)
 
-    def emit(self, cond):
+    def emit(self, cond, hidden=None):
+        """hidden: the output of the head's two normed layers, when the caller has run them for all heads at once."""
         head = self.hypo_params.net
+        if hidden is not None:
+            p = head[2](hidden) + self.hypo_params_init
+            nw = self.in_ch * self.out_ch
+            w, b = p.split([nw, self.out_ch], dim=-1)
+            return w.reshape(*p.shape[:-1], self.out_ch, self.in_ch), b.reshape(*p.shape[:-1], 1, self.out_ch)
         if (not torch.is_grad_enabled() and cond.is_cuda and cond.numel() == cond.shape[-1] and head[2].out_features >= 4096
                 and os.environ.get("ARAH_HYPER_GEMV", "1") != "0"):
             # inference, one condition vector: the 256 -> in*out + out layer is a stream of its 67 MB weight matrix --
@@ -124,13 +130,13 @@ class HyperLinear(nn.Module):
         w, b = p.split([nw, self.out_ch], dim=-1)       # one backward node (a cat) instead of two zero-filled slices
         return w.reshape(*p.shape[:-1], self.out_ch, self.in_ch), b.reshape(*p.shape[:-1], 1, self.out_ch)
 
-    def forward(self, cond):
-        return EmittedLinear(*self.emit(cond))
+    def forward(self, cond, hidden=None):
+        return EmittedLinear(*self.emit(cond, hidden))
 
 
 class HyperLinearFiLM(HyperLinear):
-    def forward(self, cond, freq, phase_shift):
-        w, b = self.emit(cond)
+    def forward(self, cond, freq, phase_shift, hidden=None):
+        w, b = self.emit(cond, hidden)
         return EmittedFiLMLinear(w, b, freq, phase_shift)
 
 
@@ -139,8 +145,8 @@ class HyperLayerFiLM(nn.Module):
         super().__init__()
         self.hyper_linear = HyperLinearFiLM(in_ch, out_ch, **kw)
 
-    def forward(self, cond, freq, phase_shift):
-        return nn.Sequential(self.hyper_linear(cond, freq, phase_shift), Sine())
+    def forward(self, cond, freq, phase_shift, hidden=None):
+        return nn.Sequential(self.hyper_linear(cond, freq, phase_shift, hidden), Sine())
 
 
 class MappingNetwork(nn.Module):
@@ -176,16 +182,35 @@ class HyperFCFiLM(nn.Module):
         layers += [HyperLayerFiLM(hidden_ch, hidden_ch, **kw) for _ in range(num_hidden_layers)]
         layers += [HyperLinear(hidden_ch, out_ch, **kw)]
         self.layers = nn.ModuleList(layers)
+        self.batched_heads = True   # False: head by head also while training (tests compare the two)
         self.mapping_network = MappingNetwork(128, 256, (len(layers) - 1) * hidden_ch * 2)
 
     def forward(self, cond, latent_code):
         freqs, phases = self.mapping_network(latent_code)
         mods = []
         fs, ps = freqs.split(self.hidden_ch, dim=-1), phases.split(self.hidden_ch, dim=-1)
+        hidden = self._heads_hidden(cond) if (self.batched_heads and torch.is_grad_enabled()) else [None] * len(self.layers)
         for i, layer in enumerate(self.layers[:-1]):
-            mods.append(layer(cond, fs[i], ps[i]))
-        mods.append(self.layers[-1](cond))
+            mods.append(layer(cond, fs[i], ps[i], hidden[i]))
+        mods.append(self.layers[-1](cond, hidden[-1]))
         return nn.Sequential(*mods)
+
+    def _heads_hidden(self, cond):
+        """The two normed 256-wide layers of all seven hypernetwork heads as two batched products (training: 42 launches and
+        ~90 in backward become 18 and ~40; the per-head parameters are stacked on the fly, their gradients come back as views
+        of the stacked gradient).  Inference keeps the head-by-head modules (the reference's operation order)."""
+        import torch.nn.functional as F
+        heads = [l.hyper_linear for l in self.layers[:-1]] + [self.layers[-1]]
+        seq = [h.hypo_params.net for h in heads]
+        x = cond.reshape(1, -1, cond.shape[-1]).expand(len(seq), -1, -1)                       # (7, B, 144)
+        for j in (0, 1):
+            W = torch.stack([n[j].net[0].weight for n in seq])                                  # (7, 256, in)
+            b = torch.stack([n[j].net[0].bias for n in seq]).unsqueeze(1)
+            gw = torch.stack([n[j].net[1].weight for n in seq]).unsqueeze(1)
+            gb = torch.stack([n[j].net[1].bias for n in seq]).unsqueeze(1)
+            eps = seq[0][j].net[1].eps
+            x = torch.relu(F.layer_norm(torch.baddbmm(b, x, W.transpose(1, 2)), (W.shape[1],), eps=eps) * gw + gb)
+        return [h.reshape(*cond.shape[:-1], -1) for h in x.unbind(0)]
 
 
 class HierarchicalPoseEncoder(nn.Module):

@@ -67,3 +67,38 @@ def test_pose_encoder_levels_against_joint_by_joint(rel):
     for x, y in zip(ga, gb):
         np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-4, atol=1e-5)
     assert [len(l) for l in enc._levels()] == [1, 3, 3, 3, 5, 3, 2, 2, 2]
+
+
+def test_hypernetwork_heads_batched_against_head_by_head():
+    """HyperFCFiLM with the two normed layers of its seven heads as batched products (training) against the head-by-head
+    modules (hyperlayers.py:270-285): emitted parameters and every parameter gradient; inference stays head by head."""
+    from arah_release_amd import nets
+    torch.manual_seed(0)
+    net = nets.HyperBVPNet(out_features=1, in_features=3, hyper_in_ch=144, hidden_features=256, num_hidden_layers=5,
+                           hierarchical_pose=True, use_FiLM=True)
+    for l in net.net.layers:   # the residual heads start at zero: give them something to emit
+        h = l.hyper_linear if hasattr(l, "hyper_linear") else l
+        torch.nn.init.normal_(h.hypo_params.net[2].weight, std=1e-3)
+    rots, J, lat = torch.randn(1, 24, 9), torch.randn(1, 24, 3), torch.randn(1, 128)
+
+    def run(flag):
+        net.net.batched_heads = flag
+        out = net({"coords": torch.zeros(1, 1, 3), "rots": rots, "Jtrs": J, "latent": lat})
+        params = torch.cat([p.reshape(-1) for p in out["params"]])
+        grads = torch.autograd.grad((params ** 2).sum() * 1e3, list(net.parameters()), allow_unused=True)
+        return params.detach(), grads
+
+    a, ga = run(True)
+    b, gb = run(False)
+    np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-5, atol=1e-7)
+    for x, y in zip(ga, gb):
+        assert (x is None) == (y is None)
+        if x is not None:
+            np.testing.assert_allclose(x.numpy(), y.numpy(), rtol=1e-4, atol=1e-6 * float(y.abs().max()) + 1e-12)
+    outs = []
+    for flag in (True, False):   # inference ignores the switch
+        net.net.batched_heads = flag
+        with torch.no_grad():
+            o = net({"coords": torch.zeros(1, 1, 3), "rots": rots, "Jtrs": J, "latent": lat})
+        outs.append(torch.cat([p.reshape(-1) for p in o["params"]]))
+    assert torch.equal(outs[0], outs[1])
