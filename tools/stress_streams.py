@@ -44,7 +44,6 @@ def main():
         dt = time.perf_counter() - t0
         dog.cancel()
         dog.join()
-    dog.join()
         state["run"] = r
         img = outs[-1]["rgb_values"]
         if ref is None:
