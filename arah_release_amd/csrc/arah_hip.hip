@@ -962,10 +962,13 @@ __device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const f
 // SRC_POINTS : id = i, p = pts[i]                 -> x raw canonical
 // SRC_RAYS   : id = list[i] (ray), p = o + t[ray] d -> x NORMALISED (sphere tracing evaluates the SDF there)
 // SRC_SAMPLES: id = list[i] (q = ray*S + s), p = o + z[q] d -> x raw canonical
-// Two kernels per call, one of them returns at once (the list length lives on the device):
-//   n <  wave_below: k_nearest_wave -- one WAVE per query, clusters / spheres / bones straight from L2, no LDS, so
-//                    many waves per CU; the right shape for the sphere-tracing lists (<= one ray per pixel);
-//   n >= wave_below: k_nearest_invlbs -- one THREAD per query against the vertex table staged in 119 KB of LDS.
+// Three kernels share the walk (launch_nearest picks; the list length lives on the device, so a kernel whose range the
+// length is not in returns at once):
+//   ray and point lists  : k_nearest_group -- SIXTEEN lanes per query, four queries per wave, tables from L2 (round 3;
+//                          ARAH_KNN_GROUP=0: k_nearest_wave, one wave per query);
+//   sample list, n >= wave_below: k_nearest_invlbs -- one THREAD per query against the vertex table staged in 119 KB of
+//                          LDS (neighbouring samples walk the same clusters: the reads are broadcasts);
+//   sample list, n <  wave_below: k_nearest_wave.
 template <int SRC>
 __device__ __forceinline__ V3 knn_point_of(const float* pts, const RaySet& rs, const float* depth, int n_steps,
                                            const int* list, int i, int& id) {
