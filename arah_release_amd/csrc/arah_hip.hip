@@ -2796,6 +2796,151 @@ RaySet make_rays(const float* cam_loc, const float* dirs, int rays_per_cam) {
 }
 
 // ---- frame buffer layout -----------------------------------------------------------------
+// ---- one launch per KIND of packing job (arah_prepare_frame: ~95 launches of a few microseconds each became 13) ----------
+// A job list travels in the kernel arguments; a workgroup finds its job from the first-block table (uniform scan).
+constexpr int kMaxPackJobs = 30, kMaxCopyJobs = 40, kMaxAbsmaxJobs = 12, kMaxSplitJobs = 16, kMaxB3Jobs = 24;
+struct PackJob {
+    float* dst;
+    const float* src;
+    int M, ld, m_tiles, KC, transpose, ncol2;
+    ColSegs segs;
+    int block0;
+};
+struct PackJobs {
+    int n, blocks;
+    PackJob j[kMaxPackJobs];
+};
+struct CopyJob {   // rows4 == 0: dst[i] = i < n ? src[i] : 0 for i < n_pad;  rows4 != 0: k_pad_rows4(rows = n, rows_pad = n_pad, ncol = rows4)
+    float* dst;
+    const float* src;
+    int n, n_pad, rows4, block0;
+};
+struct CopyJobs {
+    int n, blocks;
+    CopyJob j[kMaxCopyJobs];
+};
+struct AbsmaxJob {
+    const float* src;
+    unsigned* amax;
+    int n, blocks, block0, pad;
+};
+struct AbsmaxJobs {
+    int n, blocks;
+    AbsmaxJob j[kMaxAbsmaxJobs];
+};
+struct SplitJob {
+    f16x8* dst;
+    const float* src;
+    const unsigned* amax;
+    int M, ld, m_tiles, KC32, perm, block0;
+};
+struct SplitJobs {
+    int n, blocks;
+    SplitJob j[kMaxSplitJobs];
+};
+struct B3Job {
+    bf16x8* dst;
+    const float* packed;
+    int m_tiles, KC16, block0, pad;
+};
+struct B3Jobs {
+    int n, blocks;
+    B3Job j[kMaxB3Jobs];
+};
+
+template <typename JOBS>
+__device__ __forceinline__ int job_of_block(const JOBS& jobs, int b) {
+    int k = 0;
+    while (k + 1 < jobs.n && b >= jobs.j[k + 1].block0) ++k;
+    return k;
+}
+
+__global__ void k_pack_multi(PackJobs jobs) {
+    const int k = job_of_block(jobs, blockIdx.x);
+    const PackJob& J = jobs.j[k];
+    const int idx = (blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
+    const int total = J.m_tiles * J.KC * 64;
+    if (idx >= total) return;
+    const int lane = idx & 63, tile = idx >> 6;
+    const int kc = tile % J.KC, mt = tile / J.KC;
+    const int row = mt * 16 + (lane & 15);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (J.transpose == 2) {
+        int sr = -1;
+        for (int s = 0; s < J.segs.n; ++s)
+            if (row >= J.segs.dst0[s] && row < J.segs.dst0[s] + J.segs.len[s]) sr = J.segs.src0[s] + (row - J.segs.dst0[s]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = kc * 16 + 4 * (lane >> 4) + t;
+            if (sr >= 0 && col < J.ncol2) v[t] = J.src[(size_t)col * J.ld + sr];
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int col = kc * 16 + 4 * (lane >> 4) + t;
+            int sc = -1;
+            for (int s = 0; s < J.segs.n; ++s)
+                if (col >= J.segs.dst0[s] && col < J.segs.dst0[s] + J.segs.len[s]) sc = J.segs.src0[s] + (col - J.segs.dst0[s]);
+            if (sc >= 0 && row < J.M) v[t] = J.transpose ? J.src[(size_t)sc * J.ld + row] : J.src[(size_t)row * J.ld + sc];
+        }
+    }
+    reinterpret_cast<f32x4*>(J.dst)[idx] = v;
+}
+
+__global__ void k_copy_multi(CopyJobs jobs) {
+    const int k = job_of_block(jobs, blockIdx.x);
+    const CopyJob& J = jobs.j[k];
+    const int i = (blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
+    if (i >= J.n_pad) return;
+    if (J.rows4) {   // rows of `rows4` floats -> rows of 4, zero padded
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (i < J.n)
+            for (int c = 0; c < 4; ++c) v[c] = c < J.rows4 ? J.src[(size_t)i * J.rows4 + c] : 0.f;
+        reinterpret_cast<f32x4*>(J.dst)[i] = v;
+    } else {
+        J.dst[i] = i < J.n ? J.src[i] : 0.f;
+    }
+}
+
+__global__ void k_absmax_multi(AbsmaxJobs jobs) {
+    const int k = job_of_block(jobs, blockIdx.x);
+    const AbsmaxJob& J = jobs.j[k];
+    float m = 0.f;
+    for (int i = (blockIdx.x - J.block0) * blockDim.x + threadIdx.x; i < J.n; i += J.blocks * blockDim.x) {
+        const float a = fabsf(J.src[i]);
+        if (a == a) m = fmaxf(m, a);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(J.amax, __float_as_uint(m));
+}
+
+__global__ void k_zero_words(unsigned* a, int na, unsigned* b, int nb) {
+    for (int i = threadIdx.x; i < na; i += blockDim.x) a[i] = 0u;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = 0u;
+}
+
+__global__ void k_pack_split_multi(SplitJobs jobs) {
+    const int k = job_of_block(jobs, blockIdx.x);
+    const SplitJob& J = jobs.j[k];
+    const int idx = (blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
+    if (idx >= J.m_tiles * J.KC32 * 64) return;
+    const float scale = split_weight_scale(*J.amax);
+    const int lane = idx & 63, tile = idx >> 6, kc = tile % J.KC32, mt = tile / J.KC32;
+    const int row = mt * 16 + (lane & 15);
+    f16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = J.perm ? (2 * kc + (e >> 2)) * 16 + 4 * (lane >> 4) + (e & 3) : kc * 32 + (lane >> 4) * 8 + e;
+        const float w = row < J.M ? J.src[(size_t)row * J.ld + col] * scale : 0.f;
+        const _Float16 h = (_Float16)w;
+        hi[e] = h;
+        lo[e] = (_Float16)(w - (float)h);
+    }
+    J.dst[(size_t)(tile * 2 + 0) * 64 + lane] = hi;
+    J.dst[(size_t)(tile * 2 + 1) * 64 + lane] = lo;
+}
+
 // ---- bf16 x 3 operands of the training kernels: made from the fp32 packings (any orientation / column permutation) ----
 constexpr int kB3Count = 22;
 struct B3Src {
@@ -2839,6 +2984,27 @@ __global__ void k_b3_from_packed(bf16x8* __restrict__ dst, const float* __restri
     }
     dst[(size_t)(tile * 2 + 0) * 64 + lane] = hi;
     dst[(size_t)(tile * 2 + 1) * 64 + lane] = lo;
+}
+
+__global__ void k_b3_from_packed_multi(B3Jobs jobs) {
+    const int k = job_of_block(jobs, blockIdx.x);
+    const B3Job& J = jobs.j[k];
+    const int KC32 = (J.KC16 + 1) / 2;
+    const int idx = (blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
+    if (idx >= J.m_tiles * KC32 * 64) return;
+    const int lane = idx & 63, tile = idx >> 6, kc = tile % KC32, mt = tile / KC32;
+    const int jj = lane & 15, g = lane >> 4;
+    bf16x8 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int col = kc * 32 + 8 * g + e, kc16 = col >> 4, gg = (col & 15) >> 2, r = col & 3;
+        const float w = kc16 < J.KC16 ? J.packed[((size_t)(mt * J.KC16 + kc16) * 64 + gg * 16 + jj) * 4 + r] : 0.f;
+        const __bf16 h = (__bf16)w;
+        hi[e] = h;
+        lo[e] = (__bf16)(w - (float)h);
+    }
+    J.dst[(size_t)(tile * 2 + 0) * 64 + lane] = hi;
+    J.dst[(size_t)(tile * 2 + 1) * 64 + lane] = lo;
 }
 
 struct FrameLayout {
@@ -2928,6 +3094,67 @@ ColSegs one_seg(int len) {
     s.len[0] = len;
     return s;
 }
+
+// host side of the multi-job packing kernels: collect, then one launch per kind
+struct PrepJobs {
+    PackJobs pack;
+    CopyJobs copy;
+    AbsmaxJobs amax;
+    SplitJobs split;
+    B3Jobs b3;
+    bool ok = true;
+    PrepJobs() {
+        pack.n = pack.blocks = copy.n = copy.blocks = amax.n = amax.blocks = split.n = split.blocks = b3.n = b3.blocks = 0;
+    }
+    static int blocks_for(int items) { return (items + 255) / 256; }
+    void add_pack(float* dst, const float* src, int M, int ld, int m_tiles, int KC, const ColSegs& segs, int transpose,
+                  int ncol2 = 0) {
+        if (pack.n >= kMaxPackJobs) { ok = false; return; }
+        PackJob& j = pack.j[pack.n++];
+        j.dst = dst; j.src = src; j.M = M; j.ld = ld; j.m_tiles = m_tiles; j.KC = KC; j.transpose = transpose; j.ncol2 = ncol2;
+        j.segs = segs;
+        j.block0 = pack.blocks;
+        pack.blocks += blocks_for(m_tiles * KC * 64);
+    }
+    void add_copy(float* dst, const float* src, int n, int n_pad, int rows4 = 0) {
+        if (copy.n >= kMaxCopyJobs) { ok = false; return; }
+        CopyJob& j = copy.j[copy.n++];
+        j.dst = dst; j.src = src; j.n = n; j.n_pad = n_pad; j.rows4 = rows4;
+        j.block0 = copy.blocks;
+        copy.blocks += blocks_for(n_pad);
+    }
+    void add_rows4(float* dst, const float* src, int rows, int rows_pad, int ncol) { add_copy(dst, src, rows, rows_pad, ncol); }
+    void add_absmax(const float* src, int n, unsigned* dst, int blocks) {
+        if (amax.n >= kMaxAbsmaxJobs) { ok = false; return; }
+        AbsmaxJob& j = amax.j[amax.n++];
+        j.src = src; j.amax = dst; j.n = n; j.blocks = blocks; j.pad = 0;
+        j.block0 = amax.blocks;
+        amax.blocks += blocks;
+    }
+    void add_split(f16x8* dst, const float* src, int M, int ld, int m_tiles, int KC32, const unsigned* mx, int perm) {
+        if (split.n >= kMaxSplitJobs) { ok = false; return; }
+        SplitJob& j = split.j[split.n++];
+        j.dst = dst; j.src = src; j.amax = mx; j.M = M; j.ld = ld; j.m_tiles = m_tiles; j.KC32 = KC32; j.perm = perm;
+        j.block0 = split.blocks;
+        split.blocks += blocks_for(m_tiles * KC32 * 64);
+    }
+    void add_b3(bf16x8* dst, const float* packed, int m_tiles, int KC16) {
+        if (b3.n >= kMaxB3Jobs) { ok = false; return; }
+        B3Job& j = b3.j[b3.n++];
+        j.dst = dst; j.packed = packed; j.m_tiles = m_tiles; j.KC16 = KC16; j.pad = 0;
+        j.block0 = b3.blocks;
+        b3.blocks += blocks_for(m_tiles * ((KC16 + 1) / 2) * 64);
+    }
+    void flush_a(hipStream_t s) {   // no dependencies
+        if (pack.n) hipLaunchKernelGGL(k_pack_multi, dim3(pack.blocks), dim3(256), 0, s, pack);
+        if (copy.n) hipLaunchKernelGGL(k_copy_multi, dim3(copy.blocks), dim3(256), 0, s, copy);
+        if (amax.n) hipLaunchKernelGGL(k_absmax_multi, dim3(amax.blocks), dim3(256), 0, s, amax);
+    }
+    void flush_b(hipStream_t s) {   // after flush_a on the same stream
+        if (split.n) hipLaunchKernelGGL(k_pack_split_multi, dim3(split.blocks), dim3(256), 0, s, split);
+        if (b3.n) hipLaunchKernelGGL(k_b3_from_packed_multi, dim3(b3.blocks), dim3(256), 0, s, b3);
+    }
+};
 
 // the nearest-vertex tables of one posed body, in a buffer of their own (arah_body_bytes) or inside the frame buffer
 struct BodyTables {
@@ -3041,59 +3268,46 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     const int kc0 = kin_pad / 16;
     const int n_view = idr ? 27 : 0;
     const int in_dim = 3 + n_view + 3 + 256 + nets->n_pose;   // decoder.py:29-41, config.py:101-127
+    // Every packing job is collected by kind and goes out as ONE launch per kind (PrepJobs): phase A has no dependencies
+    // (fp32 packings, copies, |w| maxima); phase B needs A's maxima (f16 split packings, FiLM folding, skinning scales)
+    // or A's packings (bf16 fragments).
+    PrepJobs jobs;
+    unsigned* amax_sdf = reinterpret_cast<unsigned*>(base + L.sdf_amax);
+    unsigned* amax_skin = reinterpret_cast<unsigned*>(base + L.skin_amax);
+    hipLaunchKernelGGL(k_zero_words, dim3(1), dim3(64), 0, s, amax_sdf, 64, amax_skin, 64);
     // ---- SDF MLP
-    hipLaunchKernelGGL(k_pad_rows4, dim3(1), dim3(256), 0, s, P(L.sdf_w0), nets->sdf_w[0], 256, 256, 3, 0.f);
+    jobs.add_rows4(P(L.sdf_w0), nets->sdf_w[0], 256, 256, 3);
     for (int i = 0; i < 5; ++i) {
-        launch_pack(P(L.sdf_wp[i]), nets->sdf_w[i + 1], 256, 256, 16, 16, one_seg(256), 0, s);
-        launch_pack(P(L.sdf_wpT[i]), nets->sdf_w[i + 1], 256, 256, 16, 16, one_seg(256), 1, s);
+        jobs.add_pack(P(L.sdf_wp[i]), nets->sdf_w[i + 1], 256, 256, 16, 16, one_seg(256), 0);
+        jobs.add_pack(P(L.sdf_wpT[i]), nets->sdf_w[i + 1], 256, 256, 16, 16, one_seg(256), 1);
     }
-    hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, P(L.sdf_w6), nets->sdf_w[6], 256, 256);
-    for (int i = 0; i < 6; ++i)
-        hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, P(L.sdf_bias) + i * 256, nets->sdf_b[i], 256, 256);
-    hipLaunchKernelGGL(k_copy, dim3(6), dim3(256), 0, s, P(L.sdf_freq), nets->film_freq, 6 * 256, 6 * 256);
-    hipLaunchKernelGGL(k_copy, dim3(6), dim3(256), 0, s, P(L.sdf_phase), nets->film_phase, 6 * 256, 6 * 256);
-    hipLaunchKernelGGL(k_copy, dim3(1), dim3(64), 0, s, P(L.sdf_b6), nets->sdf_b[6], 1, 64);
-    {
-        unsigned* amax = reinterpret_cast<unsigned*>(base + L.sdf_amax);
-        if (hipMemsetAsync(amax, 0, 64 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
-        for (int i = 0; i < 5; ++i) {
-            hipLaunchKernelGGL(k_absmax, dim3(16), dim3(256), 0, s, nets->sdf_w[i + 1], 256 * 256, amax + i);
-            hipLaunchKernelGGL(k_pack_split<false>, dim3(16 * 8 * 64 / 256), dim3(256), 0, s,
-                               reinterpret_cast<f16x8*>(base + L.sdf_wps[i]), nets->sdf_w[i + 1], 256, 256, 16, 8,
-                               (const unsigned*)(amax + i));
-        }
-        hipLaunchKernelGGL(k_fold_film, dim3(6), dim3(256), 0, s, (const float*)P(L.sdf_freq), (const float*)P(L.sdf_phase),
-                           (const float*)P(L.sdf_bias), (const unsigned*)amax, P(L.sdf_fw), P(L.sdf_pw), P(L.sdf_fws));
+    jobs.add_copy(P(L.sdf_w6), nets->sdf_w[6], 256, 256);
+    for (int i = 0; i < 6; ++i) jobs.add_copy(P(L.sdf_bias) + i * 256, nets->sdf_b[i], 256, 256);
+    jobs.add_copy(P(L.sdf_freq), nets->film_freq, 6 * 256, 6 * 256);
+    jobs.add_copy(P(L.sdf_phase), nets->film_phase, 6 * 256, 6 * 256);
+    jobs.add_copy(P(L.sdf_b6), nets->sdf_b[6], 1, 64);
+    for (int i = 0; i < 5; ++i) {
+        jobs.add_absmax(nets->sdf_w[i + 1], 256 * 256, amax_sdf + i, 16);
+        jobs.add_split(reinterpret_cast<f16x8*>(base + L.sdf_wps[i]), nets->sdf_w[i + 1], 256, 256, 16, 8, amax_sdf + i, 0);
     }
     // ---- skinning MLP
-    hipLaunchKernelGGL(k_pad_rows4, dim3(1), dim3(128), 0, s, P(L.skin_w0), nets->skin_w[0], 128, 128, 3, 0.f);
-    for (int i = 0; i < 3; ++i) launch_pack(P(L.skin_wp[i]), nets->skin_w[i + 1], 128, 128, 8, 8, one_seg(128), 0, s);
-    launch_pack(P(L.skin_w4p), nets->skin_w[4], 25, 128, 2, 8, one_seg(128), 0, s);
-    for (int i = 0; i < 4; ++i)
-        hipLaunchKernelGGL(k_copy, dim3(1), dim3(128), 0, s, P(L.skin_bias) + i * 128, nets->skin_b[i], 128, 128);
-    hipLaunchKernelGGL(k_copy, dim3(1), dim3(32), 0, s, P(L.skin_bias) + 512, nets->skin_b[4], 25, 32);
-    {
-        unsigned* amax = reinterpret_cast<unsigned*>(base + L.skin_amax);
-        if (hipMemsetAsync(amax, 0, 64 * 4, s) != hipSuccess) return ARAH_E_LAUNCH;
-        SkinRaw raw;
-        for (int i = 0; i < 4; ++i) {
-            raw.w[i] = nets->skin_w[i];
-            raw.b[i] = nets->skin_b[i];
-        }
-        hipLaunchKernelGGL(k_skin_probe, dim3(9 * 9 * 9), dim3(128), 0, s, raw, amax);
-        for (int i = 0; i < 4; ++i) {
-            const int M = i < 3 ? 128 : 25, mt = i < 3 ? 8 : 2;
-            hipLaunchKernelGGL(k_absmax, dim3(8), dim3(256), 0, s, nets->skin_w[i + 1], M * 128, amax + 4 + i);
-            hipLaunchKernelGGL(k_pack_split<false>, dim3((mt * 4 * 64 + 255) / 256), dim3(256), 0, s,
-                               reinterpret_cast<f16x8*>(base + L.skin_wps[i]), nets->skin_w[i + 1], M, 128, mt, 4,
-                               (const unsigned*)(amax + 4 + i));
-            hipLaunchKernelGGL(k_pack_split<true>, dim3((mt * 4 * 64 + 255) / 256), dim3(256), 0, s,
-                               reinterpret_cast<f16x8*>(base + L.skin_wpr + (size_t)i * kCwLayerBytes), nets->skin_w[i + 1], M, 128, mt, 4,
-                               (const unsigned*)(amax + 4 + i));
-        }
-        hipLaunchKernelGGL(k_skin_scales, dim3(1), dim3(64), 0, s, (const unsigned*)amax, P(L.skin_scales));
-        hipLaunchKernelGGL(k_skin_wave_consts, dim3(1), dim3(128), 0, s, raw, nets->skin_b[4], (const unsigned*)amax,
-                           P(L.skin_wconsts));
+    jobs.add_rows4(P(L.skin_w0), nets->skin_w[0], 128, 128, 3);
+    for (int i = 0; i < 3; ++i) jobs.add_pack(P(L.skin_wp[i]), nets->skin_w[i + 1], 128, 128, 8, 8, one_seg(128), 0);
+    jobs.add_pack(P(L.skin_w4p), nets->skin_w[4], 25, 128, 2, 8, one_seg(128), 0);
+    for (int i = 0; i < 4; ++i) jobs.add_copy(P(L.skin_bias) + i * 128, nets->skin_b[i], 128, 128);
+    jobs.add_copy(P(L.skin_bias) + 512, nets->skin_b[4], 25, 32);
+    SkinRaw raw;
+    for (int i = 0; i < 4; ++i) {
+        raw.w[i] = nets->skin_w[i];
+        raw.b[i] = nets->skin_b[i];
+    }
+    hipLaunchKernelGGL(k_skin_probe, dim3(9 * 9 * 9), dim3(128), 0, s, raw, amax_skin);
+    for (int i = 0; i < 4; ++i) {
+        const int M = i < 3 ? 128 : 25, mt = i < 3 ? 8 : 2;
+        jobs.add_absmax(nets->skin_w[i + 1], M * 128, amax_skin + 4 + i, 8);
+        jobs.add_split(reinterpret_cast<f16x8*>(base + L.skin_wps[i]), nets->skin_w[i + 1], M, 128, mt, 4, amax_skin + 4 + i, 0);
+        jobs.add_split(reinterpret_cast<f16x8*>(base + L.skin_wpr + (size_t)i * kCwLayerBytes), nets->skin_w[i + 1], M, 128, mt, 4,
+                       amax_skin + 4 + i, 1);
     }
     // ---- colour MLP: permute input columns to [feat(256), x(3), n(3), view(27)], fold the pose tail
     {
@@ -3105,33 +3319,33 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         sg.dst0[1] = 256; sg.src0[1] = 0; sg.len[1] = 3;                 // x
         sg.dst0[2] = 259; sg.src0[2] = 3 + n_view; sg.len[2] = 3;        // normal
         if (idr) { sg.dst0[3] = 262; sg.src0[3] = 3; sg.len[3] = 27; }   // PE(view)
-        launch_pack(P(L.col_w0p), nets->col_w[0], 256, in_dim, 16, kc0, sg, 0, s);
-        launch_pack(P(L.col_w3ap), nets->col_w[3], 256, in_dim + 128, 16, kc0, sg, 0, s);
+        jobs.add_pack(P(L.col_w0p), nets->col_w[0], 256, in_dim, 16, kc0, sg, 0);
+        jobs.add_pack(P(L.col_w3ap), nets->col_w[3], 256, in_dim + 128, 16, kc0, sg, 0);
         ColSegs sb = one_seg(128);
         sb.src0[0] = in_dim;                                             // cat([input, x], -1): x comes last
-        launch_pack(P(L.col_w3bp), nets->col_w[3], 256, in_dim + 128, 16, 8, sb, 0, s);
-        launch_pack(P(L.col_w1p), nets->col_w[1], 256, 256, 16, 16, one_seg(256), 0, s);
-        launch_pack(P(L.col_w2p), nets->col_w[2], 128, 256, 8, 16, one_seg(256), 0, s);
-        launch_pack(P(L.col_w4p), nets->col_w[4], 256, 256, 16, 16, one_seg(256), 0, s);
+        jobs.add_pack(P(L.col_w3bp), nets->col_w[3], 256, in_dim + 128, 16, 8, sb, 0);
+        jobs.add_pack(P(L.col_w1p), nets->col_w[1], 256, 256, 16, 16, one_seg(256), 0);
+        jobs.add_pack(P(L.col_w2p), nets->col_w[2], 128, 256, 8, 16, one_seg(256), 0);
+        jobs.add_pack(P(L.col_w4p), nets->col_w[4], 256, 256, 16, 16, one_seg(256), 0);
         // transposed operands of the training backward: rows = (permuted) inputs of the layer, K = its outputs
-        launch_pack(P(L.col_w0pT), nets->col_w[0], kin_pad, in_dim, kc0, 16, sg, 2, s, 256);
-        launch_pack(P(L.col_w3apT), nets->col_w[3], kin_pad, in_dim + 128, kc0, 16, sg, 2, s, 256);
-        launch_pack(P(L.col_w3bpT), nets->col_w[3], 128, in_dim + 128, 8, 16, sb, 2, s, 256);
-        launch_pack(P(L.col_w1pT), nets->col_w[1], 256, 256, 16, 16, one_seg(256), 1, s);
-        launch_pack(P(L.col_w2pT), nets->col_w[2], 256, 256, 16, 8, one_seg(128), 1, s);
-        launch_pack(P(L.col_w4pT), nets->col_w[4], 256, 256, 16, 16, one_seg(256), 1, s);
-        hipLaunchKernelGGL(k_copy, dim3(3), dim3(256), 0, s, P(L.col_w5), nets->col_w[5], 3 * 256, 3 * 256);
+        jobs.add_pack(P(L.col_w0pT), nets->col_w[0], kin_pad, in_dim, kc0, 16, sg, 2, 256);
+        jobs.add_pack(P(L.col_w3apT), nets->col_w[3], kin_pad, in_dim + 128, kc0, 16, sg, 2, 256);
+        jobs.add_pack(P(L.col_w3bpT), nets->col_w[3], 128, in_dim + 128, 8, 16, sb, 2, 256);
+        jobs.add_pack(P(L.col_w1pT), nets->col_w[1], 256, 256, 16, 16, one_seg(256), 1);
+        jobs.add_pack(P(L.col_w2pT), nets->col_w[2], 256, 256, 16, 8, one_seg(128), 1);
+        jobs.add_pack(P(L.col_w4pT), nets->col_w[4], 256, 256, 16, 16, one_seg(256), 1);
+        jobs.add_copy(P(L.col_w5), nets->col_w[5], 3 * 256, 3 * 256);
         float* cb = P(L.col_bias);
         hipLaunchKernelGGL(k_fold_bias, dim3(1), dim3(256), 0, s, cb, nets->col_b[0], nets->col_w[0], in_dim,
                            feat0 + 256, nets->pose_vec, nets->pose_vec ? nets->n_pose : 0, 256);
-        hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, cb + 256, nets->col_b[1], 256, 256);
-        hipLaunchKernelGGL(k_copy, dim3(1), dim3(128), 0, s, cb + 512, nets->col_b[2], 128, 128);
+        jobs.add_copy(cb + 256, nets->col_b[1], 256, 256);
+        jobs.add_copy(cb + 512, nets->col_b[2], 128, 128);
         hipLaunchKernelGGL(k_fold_bias, dim3(1), dim3(256), 0, s, cb + 640, nets->col_b[3], nets->col_w[3],
                            in_dim + 128, feat0 + 256, nets->pose_vec, nets->pose_vec ? nets->n_pose : 0, 256);
-        hipLaunchKernelGGL(k_copy, dim3(1), dim3(256), 0, s, cb + 896, nets->col_b[4], 256, 256);
-        hipLaunchKernelGGL(k_copy, dim3(1), dim3(4), 0, s, cb + 1152, nets->col_b[5], 3, 4);
+        jobs.add_copy(cb + 896, nets->col_b[4], 256, 256);
+        jobs.add_copy(cb + 1152, nets->col_b[5], 3, 4);
     }
-    // ---- bf16 hi/lo fragments for loop D's normal sweep (W^T of the trunk) and colour MLP: eleven small launches
+    // ---- bf16 hi/lo fragments for loop D's normal sweep (W^T of the trunk) and colour MLP
     if (nets->precision == ARAH_PRECISION_SPLIT_F16 && shade_b3()) {
         const size_t src[kB3Count] = {L.sdf_wp[0], L.sdf_wp[1], L.sdf_wp[2], L.sdf_wp[3], L.sdf_wp[4],
                                       L.sdf_wpT[0], L.sdf_wpT[1], L.sdf_wpT[2], L.sdf_wpT[3], L.sdf_wpT[4],
@@ -3139,11 +3353,17 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
                                       L.col_w0pT, L.col_w1pT, L.col_w2pT, L.col_w3apT, L.col_w3bpT, L.col_w4pT};
         for (int i = 5; i < 16; ++i) {
             const B3Src e = b3_source(i, kc0);
-            const int total = e.m_tiles * ((e.kc16 + 1) / 2) * 64;
-            hipLaunchKernelGGL(k_b3_from_packed, dim3((total + 255) / 256), dim3(256), 0, s,
-                               reinterpret_cast<bf16x8*>(base + L.b3[i]), (const float*)P(src[i]), e.m_tiles, e.kc16);
+            jobs.add_b3(reinterpret_cast<bf16x8*>(base + L.b3[i]), (const float*)P(src[i]), e.m_tiles, e.kc16);
         }
     }
+    if (!jobs.ok) return ARAH_E_LAUNCH;
+    jobs.flush_a(s);
+    jobs.flush_b(s);
+    hipLaunchKernelGGL(k_fold_film, dim3(6), dim3(256), 0, s, (const float*)P(L.sdf_freq), (const float*)P(L.sdf_phase),
+                       (const float*)P(L.sdf_bias), (const unsigned*)amax_sdf, P(L.sdf_fw), P(L.sdf_pw), P(L.sdf_fws));
+    hipLaunchKernelGGL(k_skin_scales, dim3(1), dim3(64), 0, s, (const unsigned*)amax_skin, P(L.skin_scales));
+    hipLaunchKernelGGL(k_skin_wave_consts, dim3(1), dim3(128), 0, s, raw, nets->skin_b[4], (const unsigned*)amax_skin,
+                       P(L.skin_wconsts));
     // ---- body
     if (!body->trans || !body->center || !body->coord_min || !body->coord_max) return ARAH_E_BADARG;
     hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, s, P(L.scalars), body->trans, body->center, body->coord_min,
@@ -3799,13 +4019,14 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
                                       f->sdf_wpT[0], f->sdf_wpT[1], f->sdf_wpT[2], f->sdf_wpT[3], f->sdf_wpT[4],
                                       f->col_w0p, f->col_w1p, f->col_w2p, f->col_w3ap, f->col_w3bp, f->col_w4p,
                                       f->col_w0pT, f->col_w1pT, f->col_w2pT, f->col_w3apT, f->col_w3bpT, f->col_w4pT};
+        PrepJobs jobs;
         for (int i = 0; i < kB3Count; ++i) {
             if (i >= 10 && i < 16) continue;   // forward colour products stay on the fp32 MFMA (train.hpp)
             const B3Src e = b3_source(i, kc0);
-            const int total = e.m_tiles * ((e.kc16 + 1) / 2) * 64;
-            hipLaunchKernelGGL(k_b3_from_packed, dim3((total + 255) / 256), dim3(256), 0, s,
-                               reinterpret_cast<bf16x8*>(const_cast<void*>(f->b3[i])), src[i], e.m_tiles, e.kc16);
+            jobs.add_b3(reinterpret_cast<bf16x8*>(const_cast<void*>(f->b3[i])), src[i], e.m_tiles, e.kc16);
         }
+        if (!jobs.ok) return ARAH_E_LAUNCH;
+        jobs.flush_b(s);
         if (idr) ARAH_LAUNCH_TRAIN(true, true, true, slab4);
         else ARAH_LAUNCH_TRAIN(false, true, true, slab4);
     } else {
