@@ -112,6 +112,13 @@ class HyperLinear(nn.Module):
     def emit(self, cond, hidden=None):
         """hidden: the output of the head's two normed layers, when the caller has run them for all heads at once."""
         head = self.hypo_params.net
+        if (hidden is not None and not torch.is_grad_enabled() and hidden.is_cuda and hidden.numel() == hidden.shape[-1]
+                and head[2].out_features >= 4096 and os.environ.get("ARAH_HYPER_GEMV", "1") != "0"):
+            from . import hip   # inference, one condition vector: the wide output layer as an HBM stream (see below)
+            p = hip.gemv_rows(head[2].weight, hidden, head[2].bias, self.hypo_params_init).reshape(*hidden.shape[:-1], -1)
+            nw = self.in_ch * self.out_ch
+            w, b = p.split([nw, self.out_ch], dim=-1)
+            return w.reshape(*p.shape[:-1], self.out_ch, self.in_ch), b.reshape(*p.shape[:-1], 1, self.out_ch)
         if hidden is not None:
             p = head[2](hidden) + self.hypo_params_init
             nw = self.in_ch * self.out_ch
@@ -189,7 +196,8 @@ class HyperFCFiLM(nn.Module):
         freqs, phases = self.mapping_network(latent_code)
         mods = []
         fs, ps = freqs.split(self.hidden_ch, dim=-1), phases.split(self.hidden_ch, dim=-1)
-        hidden = self._heads_hidden(cond) if (self.batched_heads and torch.is_grad_enabled()) else [None] * len(self.layers)
+        hidden = (self._heads_hidden(cond) if (self.batched_heads and (torch.is_grad_enabled() or cond.is_cuda))
+                  else [None] * len(self.layers))
         for i, layer in enumerate(self.layers[:-1]):
             mods.append(layer(cond, fs[i], ps[i], hidden[i]))
         mods.append(self.layers[-1](cond, hidden[-1]))
@@ -234,7 +242,9 @@ class HierarchicalPoseEncoder(nn.Module):
             par = torch.as_tensor(self.parents[1:], device=Jtrs.device, dtype=torch.long)
             Jtrs = torch.cat([Jtrs[:, :1], Jtrs[:, 1:] - Jtrs[:, par]], dim=1).detach()
         glob = self.layer_0(torch.cat([rots.reshape(B, -1), Jtrs.reshape(B, -1)], dim=-1))
-        if self.batched_levels and torch.is_grad_enabled():   # training; inference keeps the reference's operation order
+        # training, and inference on the GPU (whose sums already run in another order than the CPU's); on the CPU without
+        # gradients -- the oracle's side of the fixtures -- the reference's operation order is kept
+        if self.batched_levels and (torch.is_grad_enabled() or rots.is_cuda):
             return self._forward_levels(rots, Jtrs, glob)
         feats = []
         for j in range(self.num_joints):
