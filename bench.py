@@ -352,7 +352,8 @@ def run(args, rt):
     def timed_pass(full_shading, precision="split", n_streams=None):
         """K timed steps (barrier + sync on both sides), then the same K steps again with HIP events
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
-        tracer.full_shading = full_shading
+        # ARAH_FULL_SHADING=1 forces the shade-everything path in every pass (the profiler's full-shading PMC passes)
+        tracer.full_shading = full_shading or os.environ.get("ARAH_FULL_SHADING") == "1"
         os.environ["ARAH_PRECISION"] = precision
         n_streams = args.streams if n_streams is None else n_streams
         rt.render_many(warm_inputs, n_streams)
@@ -436,7 +437,7 @@ def run(args, rt):
         canon_kernel = "k_canon_wave" if split and os.environ.get("ARAH_CANON_KERNEL", "wave") != "tile" else "k_canon_solve"
         dens_traffic, traffic_src = pmc_traffic("k_density<%s" % tf[split])
         canon_traffic, canon_src = pmc_traffic(canon_kernel + "<")
-        shade_traffic, shade_src = pmc_traffic("k_shade<%s, %s>" % (tf[mode == "idr"], tf[split]), full_shading=True)
+        shade_traffic, shade_src = pmc_traffic("k_shade<%s, %s" % (tf[mode == "idr"], tf[split]), full_shading=True)
         peak_fwd = PEAK_SPLIT_TFLOPS if split else PEAK_F32_MFMA_TFLOPS
         # k_shade: forward trunk on the default engine; reverse sweep and colour MLP on the bf16 x 3 engine (three bf16
         # MFMAs per fp32 product: the same rate as the f16 split) unless ARAH_SHADE_ENGINE=fp32 / the exact engine
