@@ -210,7 +210,7 @@ __global__ void k_pack_split(f16x8* __restrict__ dst, const float* __restrict__ 
                              int KC32, const unsigned* amax) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= m_tiles * KC32 * 64) return;
-    const float scale = split_weight_scale(*amax);
+    const float scale = PERM ? 1.0f : split_weight_scale(*amax);
     const int lane = idx & 63, tile = idx >> 6, kc = tile % KC32, mt = tile / KC32;
     const int row = mt * 16 + (lane & 15);
     f16x8 hi, lo;
@@ -291,32 +291,56 @@ __global__ void k_skin_scales(const unsigned* amax, float* scales) {
     scales[4 + k] = 1.0f / (split_weight_scale(amax[4 + k]) * S);
 }
 
-// constants of the point-owning-wave kernels (SkinWave::consts, layout kCw* in mlp.hpp); amax[4..7] = |W| of layers 1..4
-__global__ void k_skin_wave_consts(SkinRaw net, const float* __restrict__ w4b, const unsigned* amax, float* __restrict__ c) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// constants of the point-owning-wave kernels (SkinWave::consts, layout kCw* in mlp.hpp, where the units are explained);
+// amax[0..3]: probed activation maxima (k_skin_probe, x units).  One thread per output row.
+__global__ void k_skin_wave_consts(SkinRaw net, const float* __restrict__ w4, const float* __restrict__ w4b, const unsigned* amax,
+                                   float* __restrict__ c) {
+    const int i = threadIdx.x;
+    // activation scale of layer k's output (z units): 1 for an ordinary network, smaller when the probed maximum times 32
+    // would leave the f16 range
+    auto act_scale = [&](int k) {
+        const float a = __uint_as_float(amax[k]) * kZUnit;
+        if (!(a > 0.f) || a > 3.0e38f) return 1.0f;
+        int e;
+        frexpf(a, &e);   // a = m 2^e, m in [0.5, 1)
+        return e > 11 ? ldexpf(1.0f, 11 - e) : 1.0f;
+    };
+    const double M = (double)kCwShift;
     if (i < 128) {
-        c[kCwW0 + i * 4 + 0] = net.w[0][i * 3 + 0] * kZUnit;
-        c[kCwW0 + i * 4 + 1] = net.w[0][i * 3 + 1] * kZUnit;
-        c[kCwW0 + i * 4 + 2] = net.w[0][i * 3 + 2] * kZUnit;
-        c[kCwW0 + i * 4 + 3] = net.b[0][i] * kZUnit;
+        unsigned* ct = reinterpret_cast<unsigned*>(c + kCwW0T) + i * 8;
+        unsigned short h[3], l[3];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) c[kCwBz + (k - 1) * 128 + i] = net.b[k][i] * kZUnit;
+        for (int k = 0; k < 3; ++k) {
+            const float w = net.w[0][i * 3 + k] * kZUnit;
+            const _Float16 hh = (_Float16)w, ll = (_Float16)(w - (float)hh);
+            h[k] = __builtin_bit_cast(unsigned short, hh);
+            l[k] = __builtin_bit_cast(unsigned short, ll);
+        }
+        ct[0] = ct[2] = (unsigned)h[0] | ((unsigned)h[1] << 16);
+        ct[1] = ct[3] = (unsigned)h[2];
+        ct[4] = ct[6] = (unsigned)l[0] | ((unsigned)l[1] << 16);
+        ct[5] = ct[7] = (unsigned)l[2];
+        c[kCwBinit + i] = (float)((double)net.b[0][i] * (double)kZUnit - M);
+#pragma unroll 1
+        for (int k = 1; k < 4; ++k) {
+            double rs = 0.0;
+            for (int col = 0; col < 128; ++col) rs += (double)net.w[k][i * 128 + col];
+            c[kCwBinit + k * 128 + i] = (float)(((double)net.b[k][i] * (double)kZUnit + M * rs - M) * (double)act_scale(k - 1));
+        }
     }
-    if (i < 32) c[kCwB4 + i] = i < 25 ? w4b[i] : 0.f;
+    if (i < 32) {
+        double v = 0.0;
+        if (i < 25) {
+            double rs = 0.0;
+            for (int col = 0; col < 128; ++col) rs += (double)w4[i * 128 + col];
+            v = ((double)w4b[i] * (100.0 / 0.6931471805599453) + M * rs) * (double)act_scale(3);
+        }
+        c[kCwBinit + 512 + i] = (float)v;
+    }
     if (i < 4) {
-        // activation scale of layer i's output (z units: 100 log2(e) x): 1 for an ordinary network, smaller when the
-        // probed maximum times 32 would leave the f16 range (amax[0..3]: k_skin_probe, x units)
-        auto act_scale = [&](int k) {
-            const float a = __uint_as_float(amax[k]) * kZUnit;
-            if (!(a > 0.f) || a > 3.0e38f) return 1.0f;
-            int e;
-            frexpf(a, &e);   // a = m 2^e, m in [0.5, 1)
-            return e > 11 ? ldexpf(1.0f, 11 - e) : 1.0f;
-        };
         c[kCwActS + i] = act_scale(i);
         if (i == 0) c[kCwScaled] = (act_scale(0) != 1.0f || act_scale(1) != 1.0f || act_scale(2) != 1.0f || act_scale(3) != 1.0f) ? 1.0f : 0.0f;
-        const float k4 = i == 3 ? (float)(0.6931471805599453 / 100.0) : 1.0f;
-        c[kCwInv + i] = k4 / (split_weight_scale(amax[4 + i]) * act_scale(i));
+        c[kCwInv + i] = i < 3 ? 1.0f / act_scale(i) : (float)(0.2 * 0.6931471805599453) / act_scale(3);
     }
 }
 
@@ -1505,13 +1529,16 @@ constexpr int kSeedChunk = 64;   // seeds a wave takes from the queue per atomic
 
 // 25 raw logits of a slot -> 24 weights in registers; the four lanes of the slot share the 25 sigmoids through the
 // slot's LDS row (in place).  Same arithmetic as hsoftmax<float>(20 * logits).
+// X20: the row already holds 20 x logit (k_canon_wave folds the factor into the accumulator's conversion).
+template <bool X20 = false>
 __device__ __forceinline__ void hsoftmax_quad(float* row, int g, float (&w)[24]) {
     float ra, rb, rc, sa, sb, sc;
-    softmax3<float>(row[1] * 20.0f, row[2] * 20.0f, row[3] * 20.0f, ra, rb, rc);
-    softmax3<float>(row[12] * 20.0f, row[13] * 20.0f, row[14] * 20.0f, sa, sb, sc);
+    const float k20 = X20 ? 1.0f : 20.0f;
+    softmax3<float>(row[1] * k20, row[2] * k20, row[3] * k20, ra, rb, rc);
+    softmax3<float>(row[12] * k20, row[13] * k20, row[14] * k20, sa, sb, sc);
     float sg_own[7];
 #pragma unroll
-    for (int k = 0; k < 7; ++k) sg_own[k] = sigm(row[min(g + 4 * k, 24)] * 20.0f);
+    for (int k = 0; k < 7; ++k) sg_own[k] = sigm(row[min(g + 4 * k, 24)] * k20);
 #pragma unroll
     for (int k = 0; k < 7; ++k)
         if (g + 4 * k < 25) row[g + 4 * k] = sg_own[k];
@@ -2925,7 +2952,8 @@ __global__ void k_pack_split_multi(SplitJobs jobs) {
     const SplitJob& J = jobs.j[k];
     const int idx = (blockIdx.x - J.block0) * blockDim.x + threadIdx.x;
     if (idx >= J.m_tiles * J.KC32 * 64) return;
-    const float scale = split_weight_scale(*J.amax);
+    // the point-owning-wave operands (perm) stay UNSCALED: f16 subnormals carry the lo halves of small weights (mlp.hpp)
+    const float scale = J.perm ? 1.0f : split_weight_scale(*J.amax);
     const int lane = idx & 63, tile = idx >> 6, kc = tile % J.KC32, mt = tile / J.KC32;
     const int row = mt * 16 + (lane & 15);
     f16x8 hi, lo;
@@ -3050,7 +3078,7 @@ FrameLayout frame_layout(int col_mode) {
     L.skin_scales = take(64);
     L.skin_amax = take(64);
     L.skin_wpr = take(kCwWeightBytes / 4);
-    L.skin_wconsts = take(1024);
+    L.skin_wconsts = take((kCwSize + 255) / 256 * 256);
     L.col_w0p = take((size_t)256 * kin_pad);
     L.col_w1p = take(256 * 256);
     L.col_w2p = take(128 * 256);
@@ -3240,6 +3268,14 @@ int arah_set_density_events(void* start_event, void* stop_event) {
     return ARAH_OK;
 }
 
+#ifdef CW_DEBUG
+float* g_cw_dbg = nullptr;   // debugging builds only (tools/jobs): 64 floats per point, written by k_canon_wave
+extern "C" int arah_debug_set_buffer(void* p) {
+    g_cw_dbg = reinterpret_cast<float*>(p);
+    return ARAH_OK;
+}
+#endif
+
 int arah_set_canon_events(void* start_event, void* stop_event) {
     g_canon_ev0 = reinterpret_cast<hipEvent_t>(start_event);
     g_canon_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
@@ -3362,8 +3398,8 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     hipLaunchKernelGGL(k_fold_film, dim3(6), dim3(256), 0, s, (const float*)P(L.sdf_freq), (const float*)P(L.sdf_phase),
                        (const float*)P(L.sdf_bias), (const unsigned*)amax_sdf, P(L.sdf_fw), P(L.sdf_pw), P(L.sdf_fws));
     hipLaunchKernelGGL(k_skin_scales, dim3(1), dim3(64), 0, s, (const unsigned*)amax_skin, P(L.skin_scales));
-    hipLaunchKernelGGL(k_skin_wave_consts, dim3(1), dim3(128), 0, s, raw, nets->skin_b[4], (const unsigned*)amax_skin,
-                       P(L.skin_wconsts));
+    hipLaunchKernelGGL(k_skin_wave_consts, dim3(1), dim3(128), 0, s, raw, nets->skin_w[4], nets->skin_b[4],
+                       (const unsigned*)amax_skin, P(L.skin_wconsts));
     // ---- body
     if (!body->trans || !body->center || !body->coord_min || !body->coord_max) return ARAH_E_BADARG;
     hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, s, P(L.scalars), body->trans, body->center, body->coord_min,
@@ -3620,6 +3656,11 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
         return 1;
     }();
     if (g_canon_ev0) hipEventRecord(g_canon_ev0, s);
+#ifdef CW_DEBUG
+    unsigned long long* const clk_arg = reinterpret_cast<unsigned long long*>(g_cw_dbg);
+#else
+    unsigned long long* const clk_arg = w.ctr->clk;
+#endif
     if (fd.split && mode != 0) {
         long long gw = (max_pts + kCwWaves * kCwSlots - 1) / (kCwWaves * kCwSlots);
         const int cus = num_cus();
@@ -3630,17 +3671,17 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
         if (mode == 1) {
             hipLaunchKernelGGL((k_canon_wave<true, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
                                (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
-                               &w.ctr->n_split_nonfinite, w.ctr->clk);
+                               &w.ctr->n_split_nonfinite, clk_arg);
             hipLaunchKernelGGL((k_canon_wave<true, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
                                (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
-                               &w.ctr->n_split_nonfinite, w.ctr->clk);
+                               &w.ctr->n_split_nonfinite, clk_arg);
         } else {
             hipLaunchKernelGGL((k_canon_wave<false, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
                                (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
-                               &w.ctr->n_canon, &w.ctr->n_split_nonfinite, w.ctr->clk);
+                               &w.ctr->n_canon, &w.ctr->n_split_nonfinite, clk_arg);
             hipLaunchKernelGGL((k_canon_wave<false, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
                                (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
-                               &w.ctr->n_canon, &w.ctr->n_split_nonfinite, w.ctr->clk);
+                               &w.ctr->n_canon, &w.ctr->n_split_nonfinite, clk_arg);
         }
     } else {
         LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),

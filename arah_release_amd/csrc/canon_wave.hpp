@@ -19,7 +19,10 @@
 //     80 bytes loaded while the point before it was being solved), so a retiring point is replaced without waiting for
 //     HBM; the four lanes of a point keep its best transform in registers, its Broyden state (27 floats) in the wave's
 //     private LDS.
-// Activations travel in z = 100 log2(e) x (softplus_z); results differ from the tile kernel's by rounding only.
+// Activations travel in z = 100 log2(e) x, shifted by 24 (softplus_shift, mlp.hpp: four vector instructions per
+// activation straight off the accumulator, whose start value carries bias and shift); the K = 3 input layer is one
+// padded MFMA chunk (B = {x_hi | x_lo} of the lane group 0, zeros elsewhere).  Results differ from the tile kernel's
+// by rounding only.
 #pragma once
 
 #ifndef CW_NT
@@ -35,8 +38,9 @@ constexpr int kCwThreads = kCwWaves * 64;
 constexpr int kCwSlots = 16 * kCwNT;            // points per wave
 constexpr int kCwRowLd = 36;                    // logits row stride (floats): 16-byte aligned rows
 constexpr int kCwHiBytes = (3 * 32 + 8) * 1024; // hi fragments: 3 x (8 M-tiles x 4 chunks) + 2 x 4, 1 KB each
-constexpr int kCwConstFloats = kCwInv;          // w0c, bz, b4 are staged in LDS (the four scales stay scalar)
+constexpr int kCwConstFloats = kCwInv;          // input-layer operands and accumulator start values are staged in LDS
 constexpr int kCwWaveFloats = kCwSlots * ST_SIZE + 16 * kCwRowLd;   // per wave: slot states | logits rows
+constexpr unsigned kCwWhiOff = (kCwConstFloats + 24 * 16 + kCwWaves * kCwWaveFloats) * 4;   // hi fragments: byte offset in LDS
 constexpr size_t kLdsCanonWave = (size_t)kCwHiBytes + (kCwConstFloats + 24 * 16 + kCwWaves * kCwWaveFloats) * 4;
 constexpr int kCwSeedChunk = 64;                // seeds a wave takes from the queue per atomic
 
@@ -72,6 +76,9 @@ __host__ __device__ constexpr CwParts cw_parts(int NT, int L, int kc, int mp) {
 #ifndef CW_HI_DIST
 #define CW_HI_DIST 0    // the same for the hi fragments (LDS): requested ahead they cost more in registers than they hide
 #endif
+#ifndef CW_CI_MODE
+#define CW_CI_MODE 0    // bisecting aid: 0 start values LDS -> accumulator, 1 zero start + bias added in the epilogue, 2 as 0, one load per N-tile
+#endif
 #ifndef CW_PIN_MASK
 #define CW_PIN_MASK 0x040f
 #endif
@@ -94,11 +101,15 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
 #endif
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
+#ifdef CW_FORCE_SCRATCH   // bisecting aid: a private segment that the register allocator did not ask for
+    volatile int priv[16];
+    for (int i = 0; i < 16; ++i) priv[i] = tid + i;
+    if (priv[tid & 15] == -12345) return;
+#endif
     // small operands first: their absolute LDS offsets stay below 64 KB, i.e. inside the offset field of the DS
     // instructions (one address register per lane pattern, not one per constant for the compiler to hoist and spill)
-    float* w0c = smem;
-    float* bz = w0c + kCwBz;
-    float* b4 = w0c + kCwB4;
+    float* w0c = smem;                   // kCwW0T: the input layer's A operands by row (32 bytes each)
+    float* binit = w0c + kCwBinit;       // accumulator start values [4][128] + [32]
     float* sbones = w0c + kCwConstFloats;
     float* state = sbones + 24 * 16 + wave * kCwWaveFloats;   // [kCwSlots][ST_SIZE]
     float* rows = state + kCwSlots * ST_SIZE;                 // [16][kCwRowLd] logits of the N-tile in the tail
@@ -116,8 +127,10 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                     fr.skw.wpr[(size_t)L * (kCwLayerBytes / 16) + (size_t)(f * 2) * 64 + lane];
         }
     }
-    const float inv1 = cst[kCwInv], inv2 = cst[kCwInv + 1], inv3 = cst[kCwInv + 2], c_out = cst[kCwInv + 3];
+    const float inv1 = cst[kCwInv], inv2 = cst[kCwInv + 1], inv3 = cst[kCwInv + 2], c20 = cst[kCwInv + 3];
     const float as0 = cst[kCwActS], as1 = cst[kCwActS + 1], as2 = cst[kCwActS + 2], as3 = cst[kCwActS + 3];
+    float inf;   // +infinity the compiler cannot see through (softplus_shift)
+    asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(inf));
     // RFU:37-44 as one fma per coordinate: x_norm = (x - center - cmin + pad) * 2 / (1.1 rng) - 1
     const float nrm_s = 2.0f / ((bc.cmax - bc.cmin) * 1.1f);
     float nrm_o[3];
@@ -144,9 +157,25 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             f16x8, __builtin_amdgcn_raw_buffer_load_b128(wsrd, (int)aoff, (L - 1) * kCwLayerBytes + (f * 2 + s) * 1024, 0));
     };
     auto ld_lo = [&](int L, int f) { return ld_w(L, f, 1); };
-    auto ld_hi = [&](int L, int f) {
-        if (HI_LDS) return *reinterpret_cast<const f16x8*>(whi + ((L - 1) * 32 + f) * 1024 + aoff);
-        return ld_w(L, f, 0);
+    // hi fragments in LDS: 104 KB behind 53 KB of small operands -- beyond the 16-bit offset field of a DS instruction from
+    // one base.  Three bases 64 KB apart (opaque to the compiler, which otherwise re-derives an address per fragment: 168
+    // v_add_u32 per pass in round 3's listing) put every fragment at base + immediate.
+    typedef __attribute__((address_space(3))) const f16x8 lds_f16x8;
+    unsigned hb0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)reinterpret_cast<char*>(smem) + aoff;
+    unsigned hb1 = hb0 + 65536u, hb2 = hb0 + 131072u;
+    asm volatile("" : "+v"(hb0), "+v"(hb1), "+v"(hb2));
+    auto ld_hi = [&](auto Lc, auto fc) -> f16x8 {
+        constexpr int L = decltype(Lc)::value, f = decltype(fc)::value;
+        if constexpr (HI_LDS) {
+            constexpr unsigned o = kCwWhiOff + (unsigned)((L - 1) * 32 + f) * 1024u;
+            f16x8 v;
+            if constexpr (o < 65536u) v = *reinterpret_cast<lds_f16x8*>(hb0 + o);
+            else if constexpr (o < 131072u) v = *reinterpret_cast<lds_f16x8*>(hb1 + (o - 65536u));
+            else v = *reinterpret_cast<lds_f16x8*>(hb2 + (o - 131072u));
+            return v;
+        } else {
+            return ld_w(L, f, 0);
+        }
     };
 
     // The NEXT start state of every slot, claimed from the launch-wide queue when the slot last refilled, travels in three
@@ -290,57 +319,43 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             if (!pending) break;     // nothing in the slots, nothing on its way: the queue is dry
             continue;
         }
-        // ---- (2) normalised coordinates of the lane's points (the four lanes of a point compute the same values)
-        f32x4 xr[NT];
+        // ---- (2) the input layer's B fragments: normalised coordinates as f16 hi | lo in lane group 0's eight k slots
+        //      {x_hi(3), 0, x_lo(3), 0}, zeros in the other groups (the A operand repeats {w, 0, w, 0} in every group)
+        f16x8 bx[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            xr[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (id[t] >= 0)
-                xr[t] = f32x4{fmaf(st[t][ST_X], nrm_s, nrm_o[0]), fmaf(st[t][ST_X + 1], nrm_s, nrm_o[1]),
-                              fmaf(st[t][ST_X + 2], nrm_s, nrm_o[2]), 0.f};
+            float xn[3] = {0.f, 0.f, 0.f};
+            if (id[t] >= 0 && g == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) xn[c] = fmaf(st[t][ST_X + c], nrm_s, nrm_o[c]);
+            }
+            const float v4[4] = {xn[0], xn[1], xn[2], 0.f};
+            unsigned u0, u1, u2, u3;
+            split4(v4, u0, u1, u2, u3);
+            bx[t] = __builtin_bit_cast(f16x8, u32x4{u0, u1, u2, u3});
         }
         clk.mark(0);
         // ---- (3) skinning MLP, accumulators -> B fragments in registers
         f32x4 acc[2][8][NT];
         f16x8 bch[NT], bcl[NT], bnh[NT], bnl[NT];
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         u32x4 pkh[NT], pkl[NT];   // the fragments being produced, as packed words
         f16x8 lo_ring[kCwLoDist + 1][2], hi_ring[kCwHiDist + 1][2];
-        // part p of the epilogue of layer L's M-tile pair q (L = 0: the K = 3 input layer) -> B chunk q of layer L + 1.
-        // Its constants (bias quad; first-layer rows) are fetched by epre ahead of the MFMAs of the step the part rides with.
-        struct EpiPre {
-            f32x4 v[4];
-        };
-        auto epre = [&](auto Lc, auto qc, auto pc) {
-            constexpr int L = decltype(Lc)::value, q = decltype(qc)::value, p = decltype(pc)::value;
-            constexpr int mt = 2 * q + (p & 1);
-            EpiPre e;
-            if constexpr (L == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) e.v[r] = *reinterpret_cast<const f32x4*>(w0c + (mt * 16 + 4 * g + r) * 4);
-            } else {
-                e.v[0] = *reinterpret_cast<const f32x4*>(bz + (L - 1) * 128 + mt * 16 + 4 * g);
-            }
-            return e;
-        };
-        auto epart = [&](auto Lc, auto qc, auto pc, const EpiPre& e) {
+        // part p of the epilogue of layer L's M-tile pair q -> B chunk q of layer L + 1: four vector instructions per
+        // activation straight off the accumulator (softplus_shift), three per pair for the hi / lo split
+        auto epart = [&](auto Lc, auto qc, auto pc) {
             constexpr int L = decltype(Lc)::value, q = decltype(qc)::value, p = decltype(pc)::value;
             constexpr int t = p >> 1, h = p & 1;
             constexpr int mt = 2 * q + h;
             float v[4];
-            if constexpr (L == 0) {
+            f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (CW_CI_MODE == 1) bq = *reinterpret_cast<const f32x4*>(binit + L * 128 + mt * 16 + 4 * g);
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    v[r] = softplus_z(fmaf(e.v[r][2], xr[t][2], fmaf(e.v[r][1], xr[t][1], fmaf(e.v[r][0], xr[t][0], e.v[r][3]))));
-            } else {
-                const float inv = L == 1 ? inv1 : (L == 2 ? inv2 : inv3);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = softplus_z(fmaf(acc[L & 1][mt][t][r], inv, e.v[0][r]));
-            }
-            if constexpr (SCALED) {   // a wide-range layer travels scaled down (a power of two: exact)
-                const float as = L == 0 ? as0 : (L == 1 ? as1 : (L == 2 ? as2 : as3));
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] *= as;
+            for (int r = 0; r < 4; ++r) {
+                float a = acc[L & 1][mt][t][r];
+                if constexpr (CW_CI_MODE == 1) a += bq[r];
+                if constexpr (SCALED && L > 0) a *= L == 1 ? inv1 : (L == 2 ? inv2 : inv3);   // powers of two: exact
+                v[r] = softplus_shift(a, inf);
+                if constexpr (SCALED) v[r] *= L == 0 ? as0 : (L == 1 ? as1 : (L == 2 ? as2 : as3));
             }
             unsigned h0, h1, l0, l1;
             split4(v, h0, h1, l0, l1);
@@ -362,12 +377,70 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
         auto load_hi = [&](auto Gc) {
             constexpr int G = decltype(Gc)::value;
             constexpr CwStep s = cw_step(G);
-            hi_ring[G % (kCwHiDist + 1)][0] = ld_hi(s.L, (2 * s.mp + 0) * 4 + s.kc);
-            hi_ring[G % (kCwHiDist + 1)][1] = ld_hi(s.L, (2 * s.mp + 1) * 4 + s.kc);
+            hi_ring[G % (kCwHiDist + 1)][0] = ld_hi(IC<s.L>{}, IC<(2 * s.mp + 0) * 4 + s.kc>{});
+            hi_ring[G % (kCwHiDist + 1)][1] = ld_hi(IC<s.L>{}, IC<(2 * s.mp + 1) * 4 + s.kc>{});
+        };
+        // The start values (bias, shift terms: mlp.hpp) of a chunk-0 step's accumulators are read from LDS INTO the
+        // accumulators, a step ahead: they are free by then -- a layer's accumulators were the layer before last's, whose
+        // last epilogue part rides with chunk 2 of the layer in between.
+        auto load_ci = [&](auto Gc) {   // only chunk-0 steps start an accumulator chain
+            constexpr int G = decltype(Gc)::value;
+            constexpr CwStep s = cw_step(G);
+            if constexpr (s.kc == 0) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (CW_CI_MODE == 1 && s.L < 4) {
+                            acc[s.L & 1][2 * s.mp + h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        } else {
+                            acc[s.L & 1][2 * s.mp + h][t] = *reinterpret_cast<const f32x4*>(binit + s.L * 128 + (2 * s.mp + h) * 16 + 4 * g);
+                            if constexpr (CW_CI_MODE == 2) {
+                                f32x4& q = acc[s.L & 1][2 * s.mp + h][t];
+                                asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+                            }
+                        }
+                    }
+            }
         };
         static_for<0, kCwLoDist>([&](auto Gc) { load_lo(Gc); });
         static_for<0, kCwHiDist>([&](auto Gc) { load_hi(Gc); });
-        static_for<0, 2 * NT>([&](auto pc) { epart(IC<0>{}, IC<0>{}, pc, epre(IC<0>{}, IC<0>{}, pc)); });
+        load_ci(IC<0>{});
+        // input layer: per M-tile two MFMAs (A = w_hi | w_lo of the row, repeated over both halves of the lane group's
+        // k slots; B = {x_hi | x_lo}), the start value is b0 100 log2(e) - 24
+        static_for<0, 4>([&](auto mpc) {
+            constexpr int mp = decltype(mpc)::value;
+            f16x8 a_hi[2], a_lo[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* row = w0c + ((2 * mp + h) * 16 + j) * 8;
+                a_hi[h] = *reinterpret_cast<const f16x8*>(row);
+                a_lo[h] = *reinterpret_cast<const f16x8*>(row + 4);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    if constexpr (CW_CI_MODE == 1) {
+                        acc[0][2 * mp + h][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    } else {
+                        acc[0][2 * mp + h][t] = *reinterpret_cast<const f32x4*>(binit + (2 * mp + h) * 16 + 4 * g);
+                        if constexpr (CW_CI_MODE == 2) {
+                            f32x4& q = acc[0][2 * mp + h][t];
+                            asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[0][2 * mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi[h], bx[t], acc[0][2 * mp + h][t], 0, 0, 0);
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[0][2 * mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo[h], bx[t], acc[0][2 * mp + h][t], 0, 0, 0);
+        });
+        static_for<0, 2 * NT>([&](auto pc) { epart(IC<0>{}, IC<0>{}, pc); });
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             bch[t] = bnh[t];
@@ -380,6 +453,7 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             constexpr int MP = s.L < 4 ? 4 : 1;
             if constexpr (G + kCwLoDist < kCwSteps) load_lo(IC<G + kCwLoDist>{});
             if constexpr (G + kCwHiDist < kCwSteps) load_hi(IC<G + kCwHiDist>{});
+            if constexpr (G + 1 < kCwSteps) load_ci(IC<G + 1>{});
             // which epilogue parts ride with this step (up to four): kc < 3 -> pair kc + 1 of the previous layer (one part per
             // step of a hidden layer, all four in a step of the output layer); last chunk -> pair 0 of THIS layer, which is
             // final after its own step (mp = 0)
@@ -387,21 +461,18 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             constexpr int EL = prev ? s.L - 1 : s.L, EQ = prev ? s.kc + 1 : 0;
             constexpr CwParts parts = cw_parts(NT, s.L, s.kc, s.mp);
             constexpr int P0 = parts.first, NP = parts.count;
-            EpiPre pre[NP > 0 ? NP : 1];
-            static_for<0, NP>([&](auto ic) { pre[decltype(ic)::value] = epre(IC<EL>{}, IC<EQ>{}, IC<P0 + decltype(ic)::value>{}); });
 #ifndef CW_NO_PIN
             // the requests above stay above: ALU work may cross (mask: ALU | VALU | SALU | MFMA | transcendental), memory
             // operations may not -- under register pressure the scheduler otherwise sinks every request to just ahead of
             // its first use and the wave sits out the L2 / LDS latency fifty times per pass
             __builtin_amdgcn_sched_barrier(CW_PIN_MASK);
 #endif
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
-                        lo_ring[G % (kCwLoDist + 1)][h], bch[t], s.kc == 0 ? zero4 : acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
+                        lo_ring[G % (kCwLoDist + 1)][h], bch[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -414,7 +485,7 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                 for (int t = 0; t < NT; ++t)
                     acc[s.L & 1][2 * s.mp + h][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
                         hi_ring[G % (kCwHiDist + 1)][h], bch[t], acc[s.L & 1][2 * s.mp + h][t], 0, 0, 0);
-            static_for<0, NP>([&](auto ic) { epart(IC<EL>{}, IC<EQ>{}, IC<P0 + decltype(ic)::value>{}, pre[decltype(ic)::value]); });
+            static_for<0, NP>([&](auto ic) { epart(IC<EL>{}, IC<EQ>{}, IC<P0 + decltype(ic)::value>{}); });
             if constexpr (s.mp == MP - 1 && !(s.L == 4 && s.kc == 3)) {   // chunk done: the fragments produced meanwhile are next
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
@@ -441,20 +512,30 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
         for (int t = 0; t < NT; ++t) {
             float* row = rows + j * kCwRowLd;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const f32x4 b = *reinterpret_cast<const f32x4*>(b4 + h * 16 + 4 * g);
+            for (int h = 0; h < 2; ++h) {   // 20 x logit (the bias came in through the accumulator's start value)
                 f32x4 lg;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lg[r] = fmaf(acc[0][h][t][r], c_out, b[r]);
+                for (int r = 0; r < 4; ++r) lg[r] = acc[0][h][t][r] * c20;
                 *reinterpret_cast<f32x4*>(row + h * 16 + 4 * g) = lg;
             }
+#ifdef CW_DEBUG
+            if (clk_out && id[t] >= 0) {   // first evaluation of a point: its 32 scaled logits -> dbg[id][0..31]
+                float* d = reinterpret_cast<float*>(clk_out) + (size_t)id[t] * 64;
+                if (sti[t][ST_NEV] == 0) {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) d[h * 16 + 4 * g + r] = acc[0][h][t][r] * c20;
+                }
+            }
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             f32x4 tr = {0.f, 0.f, 0.f, 0.f};
             {
                 float w[24];
-                hsoftmax_quad(row, g, w);
+                hsoftmax_quad<true>(row, g, w);
 #pragma unroll
                 for (int s6 = 0; s6 < 6; ++s6) {
                     const float a = sbones[(4 * s6 + g) * 16 + j];
@@ -468,6 +549,16 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                 }
             }
             Trow[t] = tr;
+#ifdef CW_DEBUG
+            if (clk_out && id[t] >= 0 && sti[t][ST_NEV] == 0) {   // ... its sigmoids as the lanes read them back -> [32..56], T row g -> [56 + 4 g ..]... (g < 2 only)
+                float* d = reinterpret_cast<float*>(clk_out) + (size_t)id[t] * 64;
+                if (g == 0)
+                    for (int i = 0; i < 25; ++i) d[32 + i] = row[i];
+                if (g < 2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d[56 + 4 * g + r] = tr[r];
+            }
+#endif
             const float* s_ = st[t];
             gn[t] = fmaf(tr[0], s_[ST_X], fmaf(tr[1], s_[ST_X + 1], fmaf(tr[2], s_[ST_X + 2], tr[3]))) - s_[ST_TG + min(g, 2)];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

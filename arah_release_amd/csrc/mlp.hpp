@@ -604,11 +604,26 @@ __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, i
 // reads its f16 operand straight out of the packed hi register and writes the f16 result into its half of the packed
 // lo register (v_fma_mixlo_f16 / v_fma_mixhi_f16: h * 1.0 - hi, exact in fp32, one rounding to f16): three VALU
 // operations per pair of channels, against seven for convert / convert back / subtract / convert.  Same bits.
+// Round 4: written in C, not asm.  gfx940-class parts need wait states around VALU instructions that write half a
+// register (a VALU or MFMA reading the word next; an in-flight MFMA still reading the registers the word lands in), and the
+// compiler cannot see into an asm statement: with round 4's shorter loop-C epilogue an MFMA came to sit right behind a
+// v_fma_mixhi_f16 often enough for 6 % of the F1 points to miss their root, depending on the schedule
+// (profiles/r04_dstsel_hazard.txt).  Built without packed fp32 (the library always is), instruction selection turns
+// fptrunc(fma(a, k, -fpext(hi))) into exactly the two mixed-precision FMAs, provided it cannot fold the multiplier away:
+// `one` is 1.0 in a scalar register it cannot see through.
+__device__ __forceinline__ float opaque_one() {
+    float one;
+    asm("s_mov_b32 %0, 1.0" : "=s"(one));
+    return one;
+}
 __device__ __forceinline__ unsigned split_residual2(float a, float b, unsigned hi_pk) {
-    unsigned lo_pk;
-    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(lo_pk) : "v"(a), "v"(hi_pk));
-    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo_pk) : "v"(b), "v"(hi_pk));
-    return lo_pk;
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const float one = opaque_one();
+    const f16x2 h = __builtin_bit_cast(f16x2, hi_pk);
+    f16x2 l;
+    l[0] = (_Float16)__builtin_fmaf(a, one, -(float)h[0]);
+    l[1] = (_Float16)__builtin_fmaf(b, one, -(float)h[1]);
+    return __builtin_bit_cast(unsigned, l);
 }
 __device__ __forceinline__ void store_split4(float* act, int ld, int lo_off, int pt, int ch0, const f32x4 hs) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -1223,33 +1238,65 @@ constexpr int kLogitLd = 33;
 // layer's accumulators become the next layer's B fragments without leaving the registers.  That fixes the order in
 // which a 32-chunk of the contraction walks the channels -- lane (j, g) of a 16x16 accumulator tile holds channels
 // mt*16 + 4g + r of point j, so chunk kc, lane group g, element e is channel (2 kc + (e >> 2)) * 16 + 4 g + (e & 3)
-// -- and the weights are split-packed in that order (k_pack_split<PERM>).  Activations travel in the unit
-// z = 100 log2(e) x, in which Softplus(beta = 100) is log2(1 + 2^z) and needs no constants.
+// -- and the weights are split-packed in that order (k_pack_split<PERM>).
+//
+// Units (round 4).  Activations travel in z = 100 log2(e) x, in which Softplus(beta = 100) is S(z) = log2(1 + 2^z), and
+// SHIFTED by kCwShift = 24: a layer hands r' = S(z) - 24 to the next one and its accumulator holds z' = z - 24, because
+//     S(z) - 24 = log2(2^-24 + 2^(z - 24)) = max(z', log2(2^-24 + min(2^z', 1)))
+// is FOUR vector instructions straight off the accumulator -- v_exp_f32 with the clamp modifier (min(., 1): above z' = 0
+// the log term is log2(1 + 2^-24) = 0 in fp32 and the max returns z' itself, which is S(z) - 24 to fp32 for z >= 24),
+// v_add, v_log_f32, v_med3 -- against seven for max(z, 0) + log2(1 + 2^-|z|) behind an un-scaling fma.  What makes
+// the accumulator usable as it is: (1) the weights are split UNSCALED (f16 subnormals carry the lo halves of small
+// weights: absolute resolution 2^-25, below the 2^-23 relative resolution of the layer's largest weights, which
+// dominate the error), so there is no power of two to undo; (2) the bias, the shift of the incoming activations
+// (24 * rowsum(W)) and the layer's own -24 are the accumulator's START value (the C operand of the first MFMA of
+// a chain).  Measured against an fp64 chain on the synthetic subject's network: rms logit error 4.0e-7 (scaled
+// weights / unshifted: 3.4e-7, the exact fp32 engine: 3.3e-7).
 struct SkinWave {
     const f16x8* wpr;      // layer L (0..3) at byte kCwLayerBytes * L: [(mt*4 + kc)*2 + s][64 lanes] of 8 halves (s = 0 hi,
                            // 1 lo) in the permuted channel order -- ONE block, so that a single buffer descriptor plus a
                            // compile-time scalar offset addresses every fragment (no per-fragment address registers)
-    const float* consts;   // kCwW0 ..: see the enum
+    const float* consts;   // kCwW0T ..: see the enum
 };
 constexpr int kCwLayerBytes = 128 * 128 * 4;                 // hi + lo halves of a 128 x 128 layer
 constexpr int kCwWeightBytes = 3 * kCwLayerBytes + 32 * 128 * 4;
 enum {
-    kCwW0 = 0,      // [128][4]  {w0x, w0y, w0z, b0} * 100 log2(e)
-    kCwBz = 512,    // [3][128]  b_k * 100 log2(e), k = 1..3
-    kCwB4 = 896,    // [32]      b_4 (25 valid)
-    kCwInv = 928,   // [4]       1 / (weight scale of layer k * activation scale of layer k - 1), k = 1..3; the same * ln(2)/100 for k = 4
-    kCwActS = 932,  // [4]       activation scale of layers 0..3: 1 unless the probed activations (k_skin_probe) call for
-                    //           less -- a power of two that keeps 32 x the probed maximum inside the f16 range
-    kCwScaled = 936, // [1]      1 if any activation scale differs from 1 (selects the SCALED instance of the kernel), else 0
-    kCwSize = 940
+    kCwW0T = 0,       // [128][8] words: the K = 3 input layer's A operands by output row, as halves of w0 * 100 log2(e):
+                      //           {h0 h1 | h2 0 | h0 h1 | h2 0} (hi fragment of every lane) {l0 l1 | l2 0 | l0 l1 | l2 0} (lo)
+    kCwBinit = 1024,  // [4][128] + [32]: accumulator start values of layers 0..4 (bias, shift terms, activation scale)
+    kCwInv = 1568,    // [4]       1 / activation scale of layer k - 1, k = 1..3; [3]: accumulator of layer 4 -> 20 x logit
+    kCwActS = 1572,   // [4]       activation scale of layers 0..3: 1 unless the probed activations (k_skin_probe) call for
+                      //           less -- a power of two that keeps 32 x the probed maximum inside the f16 range
+    kCwScaled = 1576, // [1]       1 if any activation scale differs from 1 (selects the SCALED instance of the kernel), else 0
+    kCwSize = 1580
 };
 constexpr float kZUnit = 144.269504088896341f;   // 100 log2(e)
+constexpr float kCwShift = 24.0f;
 
 // Softplus(beta = 100) in z units: S(z) = log2(1 + 2^z) = max(z, 0) + log2(1 + 2^-|z|).  Two transcendentals and
 // three plain operations; the absolute error is that of 1 + e (6e-8 in z, 4e-10 in x).
 __device__ __forceinline__ float softplus_z(float z) {
     const float e = __builtin_amdgcn_exp2f(-fabsf(z));
     return fmaxf(z, 0.f) + __builtin_amdgcn_logf(1.0f + e);
+}
+// The shifted form (see above): zs = z - 24 -> S(z) - 24.  `inf` is +infinity in a register the compiler cannot see
+// through: med3(a, b, +inf) = max(a, b) without the canonicalising v_max(a, a) an fmaxf of an MFMA result costs.
+#ifndef CW_SP_FORM
+#define CW_SP_FORM 0
+#endif
+__device__ __forceinline__ float softplus_shift(float zs, float inf) {
+#if CW_SP_FORM == 3    // bisecting aid: the unshifted form behind two adds
+    return softplus_z(zs + kCwShift) - kCwShift;
+#elif CW_SP_FORM == 1  // v_min instead of the clamp modifier
+    const float e = fminf(__builtin_amdgcn_exp2f(zs), 1.0f);
+    return __builtin_amdgcn_fmed3f(zs, __builtin_amdgcn_logf(e + 0x1p-24f), inf);
+#elif CW_SP_FORM == 2  // canonicalising max instead of med3
+    const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(zs), 0.f, 1.f);
+    return fmaxf(zs, __builtin_amdgcn_logf(e + 0x1p-24f));
+#else
+    const float e = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(zs), 0.f, 1.f);   // v_exp_f32 ... clamp
+    return __builtin_amdgcn_fmed3f(zs, __builtin_amdgcn_logf(e + 0x1p-24f), inf);
+#endif
 }
 
 // Softplus(beta=100): log1p(exp(100 x))/100 == max(x,0) + log1p(exp(-|100 x|))/100.  The correction is

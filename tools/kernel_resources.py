@@ -6,7 +6,7 @@ import sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 src = os.path.join(root, "arah_release_amd", "csrc", "arah_hip.hip")
-cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-c", src, "-o", "/tmp/arah_res.o",
+cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-fno-slp-vectorize", "-c", src, "-o", "/tmp/arah_res.o",
        "-Rpass-analysis=kernel-resource-usage"] + sys.argv[1:]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 rows, cur = [], None

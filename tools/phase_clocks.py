@@ -25,7 +25,7 @@ NAMES = NAMES_TILE if os.environ.get("ARAH_CANON_KERNEL") == "tile" else NAMES_W
 def build():
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     csrc = os.path.join(ROOT, "arah_release_amd", "csrc")
-    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-DARAH_CLOCKS",
+    subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-value", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops", "-fno-slp-vectorize", "-DARAH_CLOCKS",
                     "-shared", "-fPIC", os.path.join(csrc, "arah_hip.hip"), "-o", LIB], check=True, cwd=csrc)
 
 

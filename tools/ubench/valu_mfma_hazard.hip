@@ -1,0 +1,90 @@
+// valu_mfma_hazard.hip -- wait states gfx950 needs between a VALU write of an MFMA's B operand (a plain v_mov_b32, a
+// v_cvt_pk_f16_f32, a half-register write v_fma_mixhi_f16) or of its SrcC and the v_mfma_f32_16x16x32_f16 that reads it.
+// One asm block on fixed registers: writer ; s_nop K-1 ; mfma.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/valu_mfma_hazard.hip -o tools/ubench/bin/valu_mfma_hazard
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// v[110:113] = B (first filled with a decoy), v[100:103] = acc.  WRITER puts the real value into v113 (or v103 for SrcC).
+#define SEQ(WRITER, K)                                                                                             \
+    asm volatile("v_mov_b32 v100, 0\n v_mov_b32 v101, 0\n v_mov_b32 v102, 0\n v_mov_b32 v103, 0\n"                  \
+                 "v_mov_b32 v110, %1\n v_mov_b32 v111, %2\n v_mov_b32 v112, %3\n v_mov_b32 v113, %5\n v_mov_b32 v114, %4\n" \
+                 "v_mov_b32 v115, %6\n v_mov_b32 v116, %7\n s_nop 7\n s_nop 7\n" WRITER "\n" K                      \
+                 "v_mfma_f32_16x16x32_f16 v[100:103], %8, v[110:113], v[100:103]\n s_nop 7\n s_nop 7\n"             \
+                 "v_mov_b32 %0, v100\n"                                                                             \
+                 : "=v"(r)                                                                                          \
+                 : "v"(bw[0]), "v"(bw[1]), "v"(bw[2]), "v"(bw[3]), "v"(decoy), "v"(f0), "v"(f1), "v"(a)             \
+                 : "v100", "v101", "v102", "v103", "v110", "v111", "v112", "v113", "v114", "v115", "v116")
+
+template <int W, int K>
+__global__ void k(const f16x8* A, const f16x8* B, float* out, int iters) {
+    const int lane = threadIdx.x & 63;
+    const f16x8 a = A[lane], b = B[lane];
+    const u32x4 bw = __builtin_bit_cast(u32x4, b);
+    const unsigned decoy = 0x3c003c00u;   // (1.0, 1.0)
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 last = __builtin_bit_cast(f16x2, bw[3]);
+    const float f0 = (float)last[0], f1 = (float)last[1];
+    // expected: a plain MFMA with the true B
+    f32x4 e = {0.f, 0.f, 0.f, 0.f};
+    e = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, e, 0, 0, 0);
+    int bad = 0;
+    for (int it = 0; it < iters; ++it) {
+        float r;
+        if constexpr (W == 0) {        // v_mov_b32 v113, <true word>
+            if constexpr (K == 0) SEQ("v_mov_b32 v113, v114", "");
+            if constexpr (K == 1) SEQ("v_mov_b32 v113, v114", "s_nop 0\n");
+            if constexpr (K == 2) SEQ("v_mov_b32 v113, v114", "s_nop 1\n");
+            if constexpr (K == 4) SEQ("v_mov_b32 v113, v114", "s_nop 3\n");
+        } else if constexpr (W == 1) { // v_cvt_pk_f16_f32 v113, f0, f1
+            if constexpr (K == 0) SEQ("v_cvt_pk_f16_f32 v113, v115, v116", "");
+            if constexpr (K == 1) SEQ("v_cvt_pk_f16_f32 v113, v115, v116", "s_nop 0\n");
+            if constexpr (K == 2) SEQ("v_cvt_pk_f16_f32 v113, v115, v116", "s_nop 1\n");
+            if constexpr (K == 4) SEQ("v_cvt_pk_f16_f32 v113, v115, v116", "s_nop 3\n");
+        } else {                       // low half by v_fma_mixlo_f16 (long before), high half by v_fma_mixhi_f16 right before
+            if constexpr (K == 0) SEQ("v_fma_mixlo_f16 v113, v115, 1.0, 0\n s_nop 7\n v_fma_mixhi_f16 v113, v116, 1.0, 0", "");
+            if constexpr (K == 1) SEQ("v_fma_mixlo_f16 v113, v115, 1.0, 0\n s_nop 7\n v_fma_mixhi_f16 v113, v116, 1.0, 0", "s_nop 0\n");
+            if constexpr (K == 2) SEQ("v_fma_mixlo_f16 v113, v115, 1.0, 0\n s_nop 7\n v_fma_mixhi_f16 v113, v116, 1.0, 0", "s_nop 1\n");
+            if constexpr (K == 4) SEQ("v_fma_mixlo_f16 v113, v115, 1.0, 0\n s_nop 7\n v_fma_mixhi_f16 v113, v116, 1.0, 0", "s_nop 3\n");
+        }
+        if (r != e[0]) ++bad;
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (float)bad;
+}
+
+template <int W, int K>
+void run(const f16x8* dA, const f16x8* dB, float* dOut, int blocks, int threads) {
+    const int n = blocks * threads;
+    (void)hipMemset(dOut, 0, n * sizeof(float));
+    hipLaunchKernelGGL((k<W, K>), dim3(blocks), dim3(threads), 0, 0, dA, dB, dOut, 2000);
+    (void)hipDeviceSynchronize();
+    std::vector<float> h(n);
+    (void)hipMemcpy(h.data(), dOut, n * sizeof(float), hipMemcpyDeviceToHost);
+    double bad = 0;
+    for (int i = 0; i < n; ++i) bad += h[i];
+    const char* names[3] = {"v_mov_b32", "v_cvt_pk_f16_f32", "v_fma_mixhi_f16"};
+    printf("writer %-17s distance %d : %10.0f wrong of %.0f\n", names[W], K, bad, (double)n * 2000);
+}
+
+int main() {
+    std::vector<_Float16> hA(64 * 8), hB(64 * 8);
+    for (int i = 0; i < 64 * 8; ++i) {
+        hA[i] = (_Float16)(0.01f * (float)((i * 7) % 13 - 6));
+        hB[i] = (_Float16)(0.02f * (float)((i * 5) % 11 - 5) + 0.003f);
+    }
+    f16x8 *dA, *dB;
+    float* dOut;
+    const int blocks = 512, threads = 512;
+    (void)hipMalloc(&dA, 64 * 16);
+    (void)hipMalloc(&dB, 64 * 16);
+    (void)hipMalloc(&dOut, blocks * threads * sizeof(float));
+    (void)hipMemcpy(dA, hA.data(), 64 * 16, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dB, hB.data(), 64 * 16, hipMemcpyHostToDevice);
+#define ALLK(W) run<W, 0>(dA, dB, dOut, blocks, threads); run<W, 1>(dA, dB, dOut, blocks, threads); run<W, 2>(dA, dB, dOut, blocks, threads); run<W, 4>(dA, dB, dOut, blocks, threads);
+    ALLK(0) ALLK(1) ALLK(2)
+    return 0;
+}
