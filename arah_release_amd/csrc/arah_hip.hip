@@ -340,7 +340,7 @@ __global__ void k_skin_wave_consts(SkinRaw net, const float* __restrict__ w4, co
     if (i < 4) {
         c[kCwActS + i] = act_scale(i);
         if (i == 0) c[kCwScaled] = (act_scale(0) != 1.0f || act_scale(1) != 1.0f || act_scale(2) != 1.0f || act_scale(3) != 1.0f) ? 1.0f : 0.0f;
-        c[kCwInv + i] = i < 3 ? 1.0f / act_scale(i) : (float)(0.2 * 0.6931471805599453) / act_scale(3);
+        c[kCwInv + i] = i < 3 ? 1.0f / act_scale(i) : 0.2f / act_scale(3);   // [3]: 20 log2(e) ln(2) / 100 = 0.2
     }
 }
 
@@ -1527,6 +1527,39 @@ struct CanonOut {
 
 constexpr int kSeedChunk = 64;   // seeds a wave takes from the queue per atomic
 
+// 25 gates (sigmoids; entries 1..3 and 12..14 unused) + the two 3-way softmaxes -> 24 weights along the SMPL tree
+// (utils/utils.py:138-181).  A gate q splits a parent's weight into child = parent q and parent (1 - q); the second is
+// written parent - child: one operation instead of two, and parent + child stays the weight that came in to the last bit
+// (the weights sum to one as exactly as the reference's do; each differs from its own (1 - q) product by one rounding).
+__device__ __forceinline__ void hsoftmax_tree(const float (&sgm)[25], float ra, float rb, float rc, float sa, float sb, float sc,
+                                              float (&w)[24]) {
+    const float g0 = sgm[0];
+    w[1] = g0 * ra;
+    w[2] = g0 * rb;
+    w[3] = g0 * rc;
+    w[0] = 1.0f - g0;
+    auto split = [&](int parent, int child, float q) {
+        w[child] = w[parent] * q;
+        w[parent] = w[parent] - w[child];
+    };
+#pragma unroll
+    for (int k = 0; k < 3; ++k) split(1 + k, 4 + k, sgm[4 + k]);     // hips / spine1 -> knees / spine2
+#pragma unroll
+    for (int k = 0; k < 3; ++k) split(4 + k, 7 + k, sgm[7 + k]);     // -> ankles / spine3
+#pragma unroll
+    for (int k = 0; k < 2; ++k) split(7 + k, 10 + k, sgm[10 + k]);   // ankles -> feet
+    const float up = w[9] * sgm[24];                                   // spine3 -> neck and collars
+    w[12] = up * sa;
+    w[13] = up * sb;
+    w[14] = up * sc;
+    w[9] = w[9] - up;
+    split(12, 15, sgm[15]);                                            // neck -> head
+#pragma unroll
+    for (int lvl = 0; lvl < 4; ++lvl)   // 13,14 -> 16,17 -> 18,19 -> 20,21 -> 22,23
+#pragma unroll
+        for (int k = 0; k < 2; ++k) split((lvl == 0 ? 13 : 14 + 2 * lvl) + k, 16 + 2 * lvl + k, sgm[16 + 2 * lvl + k]);
+}
+
 // 25 raw logits of a slot -> 24 weights in registers; the four lanes of the slot share the 25 sigmoids through the
 // slot's LDS row (in place).  Same arithmetic as hsoftmax<float>(20 * logits).
 // X20: the row already holds 20 x logit (k_canon_wave folds the factor into the accumulator's conversion).
@@ -1550,49 +1583,7 @@ __device__ __forceinline__ void hsoftmax_quad(float* row, int g, float (&w)[24])
     float sgm[25];
 #pragma unroll
     for (int i = 0; i < 25; ++i) sgm[i] = row[i];
-    const float g0 = sgm[0];
-    w[1] = g0 * ra;
-    w[2] = g0 * rb;
-    w[3] = g0 * rc;
-    w[0] = 1.0f - g0;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float q = sgm[4 + k];
-        w[4 + k] = w[1 + k] * q;
-        w[1 + k] = w[1 + k] * (1.0f - q);
-    }
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float q = sgm[7 + k];
-        w[7 + k] = w[4 + k] * q;
-        w[4 + k] = w[4 + k] * (1.0f - q);
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const float q = sgm[10 + k];
-        w[10 + k] = w[7 + k] * q;
-        w[7 + k] = w[7 + k] * (1.0f - q);
-    }
-    const float g24 = sgm[24];
-    w[12] = w[9] * g24 * sa;
-    w[13] = w[9] * g24 * sb;
-    w[14] = w[9] * g24 * sc;
-    w[9] = w[9] * (1.0f - g24);
-    {
-        const float q = sgm[15];
-        w[15] = w[12] * q;
-        w[12] = w[12] * (1.0f - q);
-    }
-#pragma unroll
-    for (int lvl = 0; lvl < 4; ++lvl) {   // 13,14 -> 16,17 -> 18,19 -> 20,21 -> 22,23
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int p = (lvl == 0 ? 13 : 14 + 2 * lvl) + k, c = 16 + 2 * lvl + k;
-            const float q = sgm[c];
-            w[c] = w[p] * q;
-            w[p] = w[p] * (1.0f - q);
-        }
-    }
+    hsoftmax_tree(sgm, ra, rb, rc, sa, sb, sc, w);
 }
 
 // per-slot state block in LDS (floats): the Broyden state of the point in the slot between two passes

@@ -17,8 +17,17 @@
 //     fragment bytes per point of the tile kernel;
 //   * every slot keeps a PREFETCHED start state (claimed from the launch-wide queue when the slot last refilled, its
 //     80 bytes loaded while the point before it was being solved), so a retiring point is replaced without waiting for
-//     HBM; the four lanes of a point keep its best transform in registers, its Broyden state (27 floats) in the wave's
-//     private LDS.
+//     HBM;
+//   * the per-point tail runs on the FOUR LANES (j, g) of a point, with no LDS round trip between them (round 4; round 3
+//     exchanged logits, gates and T rows through LDS rows behind wave barriers and ran the Broyden step on 32 of the 64
+//     lanes: 38-41 % of the kernel's time in its phase clocks).  What one lane has and the other three need crosses on the
+//     MATRIX pipe: v_mfma_f32_16x16x4_f32 with A[i][k] = (i mod 4 == k) hands every lane of point n the four values
+//     B[0..3][n] its lane groups supplied (an exact copy: products with 1 and sums with 0), with A[i][k] = (k < 3) their
+//     sum over the three rows of a 3-vector (an fmaf chain in row order).  Lane g keeps row g of everything: the gate
+//     sigmoids of its own eight logits (gathered: 8 MFMAs), row g of T (six MFMA steps as before), component g of x, step,
+//     residual and best x, row g of J^-1 -- the Broyden update needs one gather of the new residual, one of the old, and
+//     three row sums (v^T = dx^T J^-1).  The two N-tiles of a wave are independent instruction streams the compiler
+//     interleaves.  State between passes: 2 x 16 bytes per lane plus 2 x 16 per point, read and written as ds_*_b128.
 // Activations travel in z = 100 log2(e) x, shifted by 24 (softplus_shift, mlp.hpp: four vector instructions per
 // activation straight off the accumulator, whose start value carries bias and shift); the K = 3 input layer is one
 // padded MFMA chunk (B = {x_hi | x_lo} of the lane group 0, zeros elsewhere).  Results differ from the tile kernel's
@@ -36,10 +45,15 @@ static_assert(kCwNT == 2, "the only validated geometry (one N-tile per wave gave
 constexpr int kCwWaves = CW_WAVES;
 constexpr int kCwThreads = kCwWaves * 64;
 constexpr int kCwSlots = 16 * kCwNT;            // points per wave
-constexpr int kCwRowLd = 36;                    // logits row stride (floats): 16-byte aligned rows
 constexpr int kCwHiBytes = (3 * 32 + 8) * 1024; // hi fragments: 3 x (8 M-tiles x 4 chunks) + 2 x 4, 1 KB each
 constexpr int kCwConstFloats = kCwInv;          // input-layer operands and accumulator start values are staged in LDS
-constexpr int kCwWaveFloats = kCwSlots * ST_SIZE + 16 * kCwRowLd;   // per wave: slot states | logits rows
+// per wave (floats): the state of its 32 slots between two passes, laid out for conflict-free 16-byte accesses
+//   P0 [3][32][4]  row g of the point in slot s: {x_g, step_g, best x_g, g_g}
+//   P1 [3][32][4]  {J^-1[g][0..2], -}
+//   S0 [32][4]     {|g|_best, evaluations so far (int), id (int; -1: empty), -}
+//   S1 [32][4]     {target(3), -}
+constexpr int kCwP0 = 0, kCwP1 = 3 * 32 * 4, kCwS0 = 2 * 3 * 32 * 4, kCwS1 = kCwS0 + 32 * 4;
+constexpr int kCwWaveFloats = kCwS1 + 32 * 4;
 constexpr unsigned kCwWhiOff = (kCwConstFloats + 24 * 16 + kCwWaves * kCwWaveFloats) * 4;   // hi fragments: byte offset in LDS
 constexpr size_t kLdsCanonWave = (size_t)kCwHiBytes + (kCwConstFloats + 24 * 16 + kCwWaves * kCwWaveFloats) * 4;
 constexpr int kCwSeedChunk = 64;                // seeds a wave takes from the queue per atomic
@@ -101,18 +115,12 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
 #endif
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
-#ifdef CW_FORCE_SCRATCH   // bisecting aid: a private segment that the register allocator did not ask for
-    volatile int priv[16];
-    for (int i = 0; i < 16; ++i) priv[i] = tid + i;
-    if (priv[tid & 15] == -12345) return;
-#endif
     // small operands first: their absolute LDS offsets stay below 64 KB, i.e. inside the offset field of the DS
     // instructions (one address register per lane pattern, not one per constant for the compiler to hoist and spill)
     float* w0c = smem;                   // kCwW0T: the input layer's A operands by row (32 bytes each)
     float* binit = w0c + kCwBinit;       // accumulator start values [4][128] + [32]
     float* sbones = w0c + kCwConstFloats;
-    float* state = sbones + 24 * 16 + wave * kCwWaveFloats;   // [kCwSlots][ST_SIZE]
-    float* rows = state + kCwSlots * ST_SIZE;                 // [16][kCwRowLd] logits of the N-tile in the tail
+    float* wst = sbones + 24 * 16 + wave * kCwWaveFloats;     // this wave's slot states (kCwP0 ...)
     char* whi = reinterpret_cast<char*>(sbones + 24 * 16 + kCwWaves * kCwWaveFloats);   // hi fragments (HI_LDS)
     const float* cst = fr.skw.consts;
     // ---- launch prologue: operands into LDS (the only workgroup barrier of the kernel)
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
                     fr.skw.wpr[(size_t)L * (kCwLayerBytes / 16) + (size_t)(f * 2) * 64 + lane];
         }
     }
-    const float inv1 = cst[kCwInv], inv2 = cst[kCwInv + 1], inv3 = cst[kCwInv + 2], c20 = cst[kCwInv + 3];
+    const float inv1 = cst[kCwInv], inv2 = cst[kCwInv + 1], inv3 = cst[kCwInv + 2], c20 = cst[kCwInv + 3];   // c20: accumulator of layer 4 -> 20 log2(e) x logit
     const float as0 = cst[kCwActS], as1 = cst[kCwActS + 1], as2 = cst[kCwActS + 2], as3 = cst[kCwActS + 3];
     float inf;   // +infinity the compiler cannot see through (softplus_shift)
     asm volatile("s_mov_b32 %0, 0x7f800000" : "=s"(inf));
@@ -137,13 +145,15 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
 #pragma unroll
     for (int c = 0; c < 3; ++c) nrm_o[c] = ((bc.cmax - bc.cmin) * 0.05f - bc.center[c] - bc.cmin) * nrm_s - 1.0f;
     const int n = *count;
-    float* st[NT];
-    int* sti[NT];
+    const int g2 = min(g, 2);   // lane group 3 mirrors row 2 (it reads it, never writes it)
+    float *P0[NT], *P1[NT], *S0[NT], *S1[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        st[t] = state + (t * 16 + j) * ST_SIZE;
-        sti[t] = reinterpret_cast<int*>(st[t]);
-        if (g == 0) sti[t][ST_ID] = -1;
+        P0[t] = wst + kCwP0 + (g2 * 32 + t * 16 + j) * 4;
+        P1[t] = wst + kCwP1 + (g2 * 32 + t * 16 + j) * 4;
+        S0[t] = wst + kCwS0 + (t * 16 + j) * 4;
+        S1[t] = wst + kCwS1 + (t * 16 + j) * 4;
+        if (g == 0) *reinterpret_cast<f32x4*>(S0[t]) = f32x4{0.f, 0.f, __int_as_float(-1), 0.f};
     }
     __syncthreads();
 
@@ -239,26 +249,20 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
         bool want[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            id[t] = sti[t][ST_ID];
+            id[t] = __float_as_int(S0[t][2]);
             cl[t] = -1;
             if (id[t] < 0 && nid[t] >= 0) {
                 id[t] = nid[t];
                 nid[t] = -1;
                 f32x4 t0 = nT[t];
-                if (g == 3) {
-                    st[t][ST_TG] = t0[0];
-                    st[t][ST_TG + 1] = t0[1];
-                    st[t][ST_TG + 2] = t0[2];
+                if (g == 3) {   // row 3 of the seed's T0 carries the target
+                    *reinterpret_cast<f32x4*>(S1[t]) = f32x4{t0[0], t0[1], t0[2], 0.f};
                     t0 = f32x4{0.f, 0.f, 0.f, t0[3]};
                 } else {
-                    st[t][ST_X + g] = nx[t];
-                    st[t][ST_XB + g] = nx[t];
+                    *reinterpret_cast<f32x4*>(P0[t]) = f32x4{nx[t], 0.f, nx[t], 0.f};
                 }
                 tbr[t] = t0;                                   // T0 doubles as the initial best T (broyden.py:41)
-                if (g == 0) {
-                    sti[t][ST_ID] = id[t];
-                    sti[t][ST_NEV] = 0;
-                }
+                if (g == 0) *reinterpret_cast<f32x4*>(S0[t]) = f32x4{0.f, __int_as_float(0), __int_as_float(id[t]), 0.f};
                 want[t] = true;
             } else {
                 want[t] = id[t] < 0 && nid[t] < 0 && fid[t] < 0;   // empty, nothing ready, nothing on its way
@@ -327,7 +331,7 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             float xn[3] = {0.f, 0.f, 0.f};
             if (id[t] >= 0 && g == 0) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) xn[c] = fmaf(st[t][ST_X + c], nrm_s, nrm_o[c]);
+                for (int c = 0; c < 3; ++c) xn[c] = fmaf(wst[kCwP0 + (c * 32 + t * 16 + j) * 4], nrm_s, nrm_o[c]);
             }
             const float v4[4] = {xn[0], xn[1], xn[2], 0.f};
             unsigned u0, u1, u2, u3;
@@ -498,170 +502,174 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             if constexpr (G == 47) clk.mark(4);
         });
         clk.mark(5);
-        // ---- (4) per point: hierarchical softmax, T = sum_j w_j A_j, residual; then the Broyden bookkeeping of k_canon_solve
-        // (a) per N-tile: the four lanes of a point share the 25 gates through its logits row; T on the matrix pipe:
-        //     D[entry][point] += bones[joint][entry] w[joint][point] in six fp32 steps of four joints (an fmaf chain in joint
-        //     order, like the loop it replaces) -- lane (j, g) supplies bones[4 s + g][entry j] and w[4 s + g] of its point
-        //     and receives entries 4 g .. 4 g + 3 = row g of T
+        // ---- (4) per point, on its four lanes: gates, hierarchical softmax, T = sum_j w_j A_j, residual, Broyden step
+        // (RFU:54-113, 147-167, utils/utils.py:138-181, broyden.py:44-78).  See the header for how values cross lanes.
         hand_over();     // last pass's requests have landed long ago
         request(cl);     // this pass's claims: a whole pass to land in
-        f32x4 Trow[NT];
-        float gn[NT];
-        const unsigned long long kOddG = 0xffff0000ffff0000ull, kHighG = 0xffffffff00000000ull;   // lanes with g & 1, g & 2
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        const float selA = ((j & 3) == g) ? 1.0f : 0.0f, sumA = g < 3 ? 1.0f : 0.0f;
+        auto gather = [&](float v) { return __builtin_amdgcn_mfma_f32_16x16x4f32(selA, v, zero4, 0, 0, 0); };
+        auto sum3 = [&](float v) { return __builtin_amdgcn_mfma_f32_16x16x4f32(sumA, v, zero4, 0, 0, 0); };
+        f32x4 p0[NT], p1[NT], s0[NT];
+        float tgt[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {   // the point's state: in flight under the gates
+            p0[t] = *reinterpret_cast<const f32x4*>(P0[t]);
+            p1[t] = *reinterpret_cast<const f32x4*>(P1[t]);
+            s0[t] = *reinterpret_cast<const f32x4*>(S0[t]);
+            tgt[t] = S1[t][g2];
+        }
+        // (a) gates of the lane's own eight logits (channels 4 g + r and 16 + 4 g + r), in half-revolution-free base 2:
+        //     u = 20 log2(e) logit, sigmoid = 1 / (1 + 2^-u) (2^-u = inf gives 0, 0 gives 1: no clamps), and the two 3-way
+        //     softmaxes where their logits live -- channels 1..3 in lane group 0, 12..14 in lane group 3
+        f32x4 gq[NT][2];
+        float pq[NT][3];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float* row = rows + j * kCwRowLd;
+            float u[2][4];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {   // 20 x logit (the bias came in through the accumulator's start value)
-                f32x4 lg;
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) lg[r] = acc[0][h][t][r] * c20;
-                *reinterpret_cast<f32x4*>(row + h * 16 + 4 * g) = lg;
-            }
-#ifdef CW_DEBUG
-            if (clk_out && id[t] >= 0) {   // first evaluation of a point: its 32 scaled logits -> dbg[id][0..31]
-                float* d = reinterpret_cast<float*>(clk_out) + (size_t)id[t] * 64;
-                if (sti[t][ST_NEV] == 0) {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) d[h * 16 + 4 * g + r] = acc[0][h][t][r] * c20;
+                for (int r = 0; r < 4; ++r) {
+                    u[h][r] = acc[0][h][t][r] * c20;
+                    gq[t][h][r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-u[h][r]));
                 }
-            }
-#endif
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            f32x4 tr = {0.f, 0.f, 0.f, 0.f};
-            {
-                float w[24];
-                hsoftmax_quad<true>(row, g, w);
+            // lane group 0: (u1, u2, u3); lane group 3: (u0, u1, u2) of its first quad
+            const float a0 = g == 0 ? u[0][1] : u[0][0], a1 = g == 0 ? u[0][2] : u[0][1], a2 = g == 0 ? u[0][3] : u[0][2];
+            const float m = fmaxf(a0, fmaxf(a1, a2));
+            const float e0 = __builtin_amdgcn_exp2f(a0 - m), e1 = __builtin_amdgcn_exp2f(a1 - m), e2 = __builtin_amdgcn_exp2f(a2 - m);
+            const float sum = e0 + e1 + e2;   // in [1, 3]
+            float rs = __builtin_amdgcn_rcpf(sum);
+            rs = fmaf(fmaf(-sum, rs, 1.0f), rs, rs);
+            pq[t][0] = e0 * rs;
+            pq[t][1] = e1 * rs;
+            pq[t][2] = e2 * rs;
+        }
+        // (b) every lane of a point gets all 25 gates and both softmaxes: 11 gathers per N-tile
+        float w[NT][24];
 #pragma unroll
-                for (int s6 = 0; s6 < 6; ++s6) {
-                    const float a = sbones[(4 * s6 + g) * 16 + j];
-                    // w[4 s + g] by three selects on constant lane masks (written out: left to itself the compiler turns
-                    // the selection into a lane-indexed load from a scratch copy of w)
-                    float wl, wh, wb;
-                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(wl) : "v"(w[4 * s6]), "v"(w[4 * s6 + 1]), "s"(kOddG));
-                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(wh) : "v"(w[4 * s6 + 2]), "v"(w[4 * s6 + 3]), "s"(kOddG));
-                    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(wb) : "v"(wl), "v"(wh), "s"(kHighG));
-                    tr = __builtin_amdgcn_mfma_f32_16x16x4f32(a, wb, tr, 0, 0, 0);
-                }
+        for (int t = 0; t < NT; ++t) {
+            f32x4 G0[4], G1[4], GP[3];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                G0[r] = gather(gq[t][0][r]);   // [q]: channel 4 q + r
+                G1[r] = gather(gq[t][1][r]);   // [q]: channel 16 + 4 q + r
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) GP[r] = gather(pq[t][r]);   // [0]: softmax of 1..3, [3]: softmax of 12..14
+            float sgm[25];
+#pragma unroll
+            for (int c = 0; c < 25; ++c) sgm[c] = c < 16 ? G0[c & 3][c >> 2] : G1[c & 3][(c & 15) >> 2];
+            hsoftmax_tree(sgm, GP[0][0], GP[1][0], GP[2][0], GP[0][3], GP[1][3], GP[2][3], w[t]);
+        }
+        // (c) T on the matrix pipe: D[entry][point] += bones[joint][entry] w[joint][point] in six fp32 steps of four joints
+        //     (an fmaf chain in joint order, like the loop it replaces) -- lane (j, g) supplies bones[4 s + g][entry j] and
+        //     w[4 s + g] of its point and receives entries 4 g .. 4 g + 3 = row g of T
+        f32x4 Trow[NT];
+        // w[4 s + g] by selects on the two bits of g, written as selects: indexed by g the compiler would read w from a
+        // scratch copy.  Round 3 wrote the three v_cndmask as inline asm; the compiler cannot see that an asm statement
+        // writes an MFMA operand, and v_mfma_f32_16x16x4_f32 needs TWO wait states behind a VALU write of its B register
+        // (tools/ubench/valu_mfma32_hazard.hip: distance 0 and 1 read the old register, an s_waitcnt that has nothing to wait
+        // for is one wait state, not two).  Whenever the scheduler put the fourth step -- joints 12..15 -- right behind its
+        // select, points skinned to the head, neck and collars missed their roots (profiles/r04_hazard_ubench.txt).
+        const bool g_odd = (g & 1) != 0, g_high = (g & 2) != 0;
+        float bone[6];
+#pragma unroll
+        for (int s6 = 0; s6 < 6; ++s6) bone[s6] = sbones[(4 * s6 + g) * 16 + j];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 tr = zero4;
+#pragma unroll
+            for (int s6 = 0; s6 < 6; ++s6) {
+                const float wl = g_odd ? w[t][4 * s6 + 1] : w[t][4 * s6], wh = g_odd ? w[t][4 * s6 + 3] : w[t][4 * s6 + 2];
+                const float wb = g_high ? wh : wl;
+                tr = __builtin_amdgcn_mfma_f32_16x16x4f32(bone[s6], wb, tr, 0, 0, 0);
             }
             Trow[t] = tr;
-#ifdef CW_DEBUG
-            if (clk_out && id[t] >= 0 && sti[t][ST_NEV] == 0) {   // ... its sigmoids as the lanes read them back -> [32..56], T row g -> [56 + 4 g ..]... (g < 2 only)
-                float* d = reinterpret_cast<float*>(clk_out) + (size_t)id[t] * 64;
-                if (g == 0)
-                    for (int i = 0; i < 25; ++i) d[32 + i] = row[i];
-                if (g < 2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) d[56 + 4 * g + r] = tr[r];
-            }
-#endif
-            const float* s_ = st[t];
-            gn[t] = fmaf(tr[0], s_[ST_X], fmaf(tr[1], s_[ST_X + 1], fmaf(tr[2], s_[ST_X + 2], tr[3]))) - s_[ST_TG + min(g, 2)];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        // (b) both N-tiles at once: point (t, j) hands {rows 0..2 of T | residual} to lane (j, g = t) through the logits
-        //     rows (free by now), which does the point's Broyden step -- one pass over this code for kCwNT * 16 points
-        static_assert(NT <= 4 && NT * 16 * 16 <= 16 * kCwRowLd, "exchange area");
+        // (d) residual component g and what the Broyden step needs from the other rows
+        f32x4 gv[NT], gpv[NT], Mc[NT][3], vT[NT][3];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            float* xp = rows + (t * 16 + j) * 16;
-            if (g < 3) {
-                *reinterpret_cast<f32x4*>(xp + 4 * g) = Trow[t];
-                xp[12 + g] = gn[t];
+            const f32x4 xv = gather(p0[t][0]);
+            const float gn = fmaf(Trow[t][0], xv[0], fmaf(Trow[t][1], xv[1], fmaf(Trow[t][2], xv[2], Trow[t][3]))) - tgt[t];
+            gv[t] = gather(gn);
+            gpv[t] = gather(p0[t][3]);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                Mc[t][c] = gather(Trow[t][c]);            // [q]: T[q][c] (first evaluation: J^-1_0 = (T[:3,:3])^-1, RFU:327-328)
+                vT[t][c] = sum3(p0[t][1] * p1[t][c]);     // v^T[c] = sum_r dx_r J^-1[r][c] (broyden.py:69)
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int flags = 0;   // bit 0: keep, bit 1: improved
-        {
-            int idc = id[0];
+        // (e) the step, lane g holding row g (lane group 3 computes along on row 2's state and writes nothing)
 #pragma unroll
-            for (int t = 1; t < NT; ++t) idc = g == t ? id[t] : idc;
-            if (g < NT && idc >= 0) {
-                float* s_ = state + (g * 16 + j) * ST_SIZE;
-                int* si_ = reinterpret_cast<int*>(s_);
-                const float* xp = rows + (g * 16 + j) * 16;
-                const f32x4 r0 = *reinterpret_cast<const f32x4*>(xp), r1 = *reinterpret_cast<const f32x4*>(xp + 4),
-                            r2 = *reinterpret_cast<const f32x4*>(xp + 8), gnew = *reinterpret_cast<const f32x4*>(xp + 12);
-                const int nev = si_[ST_NEV];
-                const float x0 = s_[ST_X], x1 = s_[ST_X + 1], x2 = s_[ST_X + 2];
-                const bool first = nev == 0;
-                float gx[3], stp[3], eb, J[9];
-                bool keep, improved = false;
-                if (first) {   // J^-1_0 = (T[:3,:3])^-1 from the same weights (RFU:327-328)
-                    const float T9[16] = {r0[0], r0[1], r0[2], 0.f, r1[0], r1[1], r1[2], 0.f, r2[0], r2[1], r2[2], 0.f, 0.f, 0.f, 0.f, 1.f};
-                    inv3_of44(T9, J);
+        for (int t = 0; t < NT; ++t) {
+            const bool live = id[t] >= 0;
+            const int nev = __float_as_int(s0[t][1]);
+            const bool first = nev == 0;
+            const float x = p0[t][0], dx = p0[t][1];
+            float xb = p0[t][2], eb = s0[t][0];
+            float Jr[3] = {p1[t][0], p1[t][1], p1[t][2]};
+            float gx[3], stp;
+            bool keep, improved = false;
+            if (first) {
+                const float T9[16] = {Mc[t][0][0], Mc[t][1][0], Mc[t][2][0], 0.f, Mc[t][0][1], Mc[t][1][1], Mc[t][2][1], 0.f,
+                                      Mc[t][0][2], Mc[t][1][2], Mc[t][2][2], 0.f, 0.f, 0.f, 0.f, 1.f};
+                float R[9];
+                inv3_of44(T9, R);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) gx[r] = gnew[r];
-                    eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                    keep = true;                                        // every point takes at least one step
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) stp[r] = -(J[r * 3] * gx[0] + J[r * 3 + 1] * gx[1] + J[r * 3 + 2] * gx[2]);
-                    // a FIRST residual (at the nearest-vertex start) that is not finite: an activation left the f16 range
-                    // (later ones also come from iterates that genuinely diverge; either way the point retires below)
-                    if (!(fabsf(gx[0] + gx[1] + gx[2]) < 3.0e38f)) ++n_bad;
-                } else {
-                    float dg[3], dxv[3];
-                    eb = s_[ST_EB];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        const float gp = s_[ST_G + r];
-                        dxv[r] = s_[ST_STEP + r];
-                        dg[r] = gnew[r] - gp;
-                        gx[r] = gp + dg[r];                             // broyden.py:50-51
-                    }
-                    const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
-                    improved = err < eb;                                // broyden.py:54-61
-                    if (improved) {
-                        eb = err;
-                        s_[ST_XB] = x0;
-                        s_[ST_XB + 1] = x1;
-                        s_[ST_XB + 2] = x2;
-                    }
-                    keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
-                    if (keep) {
-#pragma unroll
-                        for (int e = 0; e < 9; ++e) J[e] = s_[ST_J + e];
-                        broyden_update<3>(J, dxv, dg, gx, stp);          // broyden.py:69-75
-                    }
+                for (int c = 0; c < 3; ++c) {
+                    Jr[c] = g2 == 0 ? R[c] : (g2 == 1 ? R[3 + c] : R[6 + c]);
+                    gx[c] = gv[t][c];
                 }
-                if (nev + 1 > kBroydenSteps) keep = false;              // 1 + 50 evaluations (broyden.py:44)
+                eb = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                keep = true;                                        // every point takes at least one step
+                // a FIRST residual (at the nearest-vertex start) that is not finite: an activation left the f16 range
+                // (later ones also come from iterates that genuinely diverge; either way the point retires below)
+                if (live && g == 0 && !(fabsf(gx[0] + gx[1] + gx[2]) < 3.0e38f)) ++n_bad;
+            } else {
+                float dg[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    dg[c] = gv[t][c] - gpv[t][c];
+                    gx[c] = gpv[t][c] + dg[c];                      // broyden.py:50-51
+                }
+                const float err = sqrtf(gx[0] * gx[0] + gx[1] * gx[1] + gx[2] * gx[2]);
+                improved = err < eb;                                // broyden.py:54-61
+                if (improved) {
+                    eb = err;
+                    xb = x;
+                }
+                keep = (eb > kRootThresh) && (err < kDvg);          // broyden.py:64
+                // broyden.py:69-75 on row g: a_g = dx_g - J[g] dg, b = v^T dg (+-eps), J[g] += (a_g / b) v^T
+                const float v0 = vT[t][0][0], v1 = vT[t][1][0], v2 = vT[t][2][0];
+                const float a_g = dx - (Jr[0] * dg[0] + Jr[1] * dg[1] + Jr[2] * dg[2]);
+                float bq = v0 * dg[0] + v1 * dg[1] + v2 * dg[2];
+                bq = (bq >= 0.f) ? bq + 1e-6f : bq - 1e-6f;
+                const float uq = a_g / bq;
+                Jr[0] += uq * v0;
+                Jr[1] += uq * v1;
+                Jr[2] += uq * v2;
+            }
+            stp = -(Jr[0] * gx[0] + Jr[1] * gx[1] + Jr[2] * gx[2]);
+            if (nev + 1 > kBroydenSteps) keep = false;              // 1 + 50 evaluations (broyden.py:44)
+            if (improved) tbr[t] = Trow[t];
+            if (live) {
                 if (keep) {
-                    si_[ST_NEV] = nev + 1;
-                    s_[ST_EB] = eb;
-                    s_[ST_X] = x0 + stp[0];
-                    s_[ST_X + 1] = x1 + stp[1];
-                    s_[ST_X + 2] = x2 + stp[2];
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) {
-                        s_[ST_STEP + r] = stp[r];
-                        s_[ST_G + r] = gx[r];
+                    if (g < 3) {
+                        *reinterpret_cast<f32x4*>(P0[t]) = f32x4{x + stp, stp, xb, gx[g2]};
+                        *reinterpret_cast<f32x4*>(P1[t]) = f32x4{Jr[0], Jr[1], Jr[2], 0.f};
                     }
-#pragma unroll
-                    for (int e = 0; e < 9; ++e) s_[ST_J + e] = J[e];
-                } else {   // retire: the best iterate is the result (broyden.py:78); its T row follows below
-                    const float xb0 = improved ? x0 : s_[ST_XB], xb1 = improved ? x1 : s_[ST_XB + 1], xb2 = improved ? x2 : s_[ST_XB + 2];
-                    outp.pts[(size_t)idc * 3] = xb0;
-                    outp.pts[(size_t)idc * 3 + 1] = xb1;
-                    outp.pts[(size_t)idc * 3 + 2] = xb2;
-                    outp.err[idc] = eb;
-                    si_[ST_ID] = -1;
+                    if (g == 0) *reinterpret_cast<f32x4*>(S0[t]) = f32x4{eb, __int_as_float(nev + 1), __int_as_float(id[t]), 0.f};
+                } else {   // retire: the best iterate is the result (broyden.py:78)
+                    if (g < 3) outp.pts[(size_t)id[t] * 3 + g] = xb;
+                    reinterpret_cast<f32x4*>(outp.T + (size_t)id[t] * 16)[g] = tbr[t];
+                    if (g == 0) {
+                        outp.err[id[t]] = eb;
+                        *reinterpret_cast<f32x4*>(S0[t]) = f32x4{eb, __int_as_float(nev + 1), __int_as_float(-1), 0.f};
+                    }
                 }
-                flags = (keep ? 1 : 0) | (improved ? 2 : 0);
             }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int f = __shfl(flags, j + 16 * t);
-            if (f & 2) tbr[t] = Trow[t];
-            if (id[t] >= 0 && !(f & 1)) reinterpret_cast<f32x4*>(outp.T + (size_t)id[t] * 16)[g] = tbr[t];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -1264,7 +1264,7 @@ enum {
     kCwW0T = 0,       // [128][8] words: the K = 3 input layer's A operands by output row, as halves of w0 * 100 log2(e):
                       //           {h0 h1 | h2 0 | h0 h1 | h2 0} (hi fragment of every lane) {l0 l1 | l2 0 | l0 l1 | l2 0} (lo)
     kCwBinit = 1024,  // [4][128] + [32]: accumulator start values of layers 0..4 (bias, shift terms, activation scale)
-    kCwInv = 1568,    // [4]       1 / activation scale of layer k - 1, k = 1..3; [3]: accumulator of layer 4 -> 20 x logit
+    kCwInv = 1568,    // [4]       1 / activation scale of layer k - 1, k = 1..3; [3]: accumulator of layer 4 -> 20 log2(e) x logit
     kCwActS = 1572,   // [4]       activation scale of layers 0..3: 1 unless the probed activations (k_skin_probe) call for
                       //           less -- a power of two that keeps 32 x the probed maximum inside the f16 range
     kCwScaled = 1576, // [1]       1 if any activation scale differs from 1 (selects the SCALED instance of the kernel), else 0

@@ -1,6 +1,7 @@
-// valu_mfma_hazard.hip -- wait states gfx950 needs between a VALU write of an MFMA's B operand (a plain v_mov_b32, a
-// v_cvt_pk_f16_f32, a half-register write v_fma_mixhi_f16) or of its SrcC and the v_mfma_f32_16x16x32_f16 that reads it.
-// One asm block on fixed registers: writer ; s_nop K-1 ; mfma.
+// valu_mfma_hazard.hip -- wait states gfx950 needs between a VALU write of an MFMA's B operand and the v_mfma_f32_16x16x32_f16
+// that reads it, and whether an s_waitcnt that has nothing to wait for counts as one.  One asm block on fixed registers:
+// v_mov_b32 (B word) ; s_nop K-1 | s_waitcnt ; mfma.  (The v_cvt_pk / v_fma_mixhi writers of the first version compared against a
+// wrong expectation and are not run.)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench/valu_mfma_hazard.hip -o tools/ubench/bin/valu_mfma_hazard
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -40,6 +41,8 @@ __global__ void k(const f16x8* A, const f16x8* B, float* out, int iters) {
             if constexpr (K == 1) SEQ("v_mov_b32 v113, v114", "s_nop 0\n");
             if constexpr (K == 2) SEQ("v_mov_b32 v113, v114", "s_nop 1\n");
             if constexpr (K == 4) SEQ("v_mov_b32 v113, v114", "s_nop 3\n");
+            if constexpr (K == 100) SEQ("v_mov_b32 v113, v114", "s_waitcnt vmcnt(0) lgkmcnt(0)\n");   // a satisfied wait as the only separator
+            if constexpr (K == 101) SEQ("v_mov_b32 v113, v114", "s_waitcnt lgkmcnt(2)\n");
         } else if constexpr (W == 1) { // v_cvt_pk_f16_f32 v113, f0, f1
             if constexpr (K == 0) SEQ("v_cvt_pk_f16_f32 v113, v115, v116", "");
             if constexpr (K == 1) SEQ("v_cvt_pk_f16_f32 v113, v115, v116", "s_nop 0\n");
@@ -67,7 +70,8 @@ void run(const f16x8* dA, const f16x8* dB, float* dOut, int blocks, int threads)
     double bad = 0;
     for (int i = 0; i < n; ++i) bad += h[i];
     const char* names[3] = {"v_mov_b32", "v_cvt_pk_f16_f32", "v_fma_mixhi_f16"};
-    printf("writer %-17s distance %d : %10.0f wrong of %.0f\n", names[W], K, bad, (double)n * 2000);
+    if (K >= 100) printf("writer %-17s separated from the MFMA by %s only : %10.0f wrong of %.0f\n", names[W], K == 100 ? "s_waitcnt vmcnt(0) lgkmcnt(0)" : "s_waitcnt lgkmcnt(2)", bad, (double)n * 2000);
+    else printf("writer %-17s distance %d : %10.0f wrong of %.0f\n", names[W], K, bad, (double)n * 2000);
 }
 
 int main() {
@@ -85,6 +89,8 @@ int main() {
     (void)hipMemcpy(dA, hA.data(), 64 * 16, hipMemcpyHostToDevice);
     (void)hipMemcpy(dB, hB.data(), 64 * 16, hipMemcpyHostToDevice);
 #define ALLK(W) run<W, 0>(dA, dB, dOut, blocks, threads); run<W, 1>(dA, dB, dOut, blocks, threads); run<W, 2>(dA, dB, dOut, blocks, threads); run<W, 4>(dA, dB, dOut, blocks, threads);
-    ALLK(0) ALLK(1) ALLK(2)
+    ALLK(0)
+    run<0, 100>(dA, dB, dOut, blocks, threads);
+    run<0, 101>(dA, dB, dOut, blocks, threads);
     return 0;
 }
