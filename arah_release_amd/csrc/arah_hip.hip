@@ -2295,7 +2295,9 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
                                                      const float* pts, const float* T, const int* list,
                                                      const int* count, int n_direct, f32x4* shaded,
                                                      f32x4* spill_all, unsigned long long* ctr_fwd,
-                                                     unsigned long long* ctr_grad, unsigned long long* ctr_col, B3Nets b3) {
+                                                     unsigned long long* ctr_grad, unsigned long long* ctr_col, B3Nets b3,
+                                                     f32x4* sdfn_out = nullptr) {
+    // sdfn_out (the per-sample seam arah_shade_points): {sdf (normalised units), d sdf / d x} as the sweep left them
     const BodyConst bc = load_bc(fr);
     typedef ColDims<IDR> D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2410,6 +2412,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
         if (tid < kTile && ids[tid] >= 0) {
             const float dens = volsdf_density(outv[tid * 4] * scale, inv_beta);   // IDR:359, 368
             shaded[ids[tid]] = f32x4{rgbv[tid * 4], rgbv[tid * 4 + 1], rgbv[tid * 4 + 2], dens};
+            if (sdfn_out) sdfn_out[ids[tid]] = reinterpret_cast<const f32x4*>(outv)[tid];
         }
         __syncthreads();
     }
@@ -3929,6 +3932,40 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     if (g_shade_ev1) hipEventRecord(g_shade_ev1, s);
     hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);
+    return check_launch();
+}
+
+int arah_shade_points(const ArahFrame* f, const float* x_norm, const float* T, const float* dirs, int32_t n,
+                      int32_t cano_view_dirs, float* rgbs, float* sdfn, void* workspace, size_t wbytes, void* stream) {
+    if (!f || !x_norm || !T || !dirs || !rgbs || !sdfn || n < 0 || !workspace) return ARAH_E_BADARG;
+    if (n == 0) return ARAH_OK;
+    Workspace w = carve(workspace, n, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    const B3Nets b3 = b3_of(*f);
+    const int g = grid_for(n, kTile);
+    f32x4* out = reinterpret_cast<f32x4*>(rgbs);
+    f32x4* dbg = reinterpret_cast<f32x4*>(sdfn);
+    // the kernels of shade_impl, one sample per "ray" (S = 1: dirs are per point), no list
+    if (fd.split && shade_b3()) {
+        if (f->col_mode == ARAH_COLOR_IDR)
+            hipLaunchKernelGGL((k_shade<true, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade_b3<true>()), s, fd, 1,
+                               cano_view_dirs, dirs, x_norm, T, (const int*)nullptr, (const int*)nullptr, n, out, w.spill,
+                               &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3, dbg);
+        else
+            hipLaunchKernelGGL((k_shade<false, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade_b3<false>()), s, fd, 1,
+                               cano_view_dirs, dirs, x_norm, T, (const int*)nullptr, (const int*)nullptr, n, out, w.spill,
+                               &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3, dbg);
+    } else if (f->col_mode == ARAH_COLOR_IDR)
+        LAUNCH_ENGINE(fd.split, (k_shade<true, true>), (k_shade<true, false>), dim3(g), dim3(kThreads), lds_shade<true>(),
+                      s, fd, 1, cano_view_dirs, dirs, x_norm, T, (const int*)nullptr, (const int*)nullptr, n, out, w.spill,
+                      &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3, dbg);
+    else
+        LAUNCH_ENGINE(fd.split, (k_shade<false, true>), (k_shade<false, false>), dim3(g), dim3(kThreads),
+                      lds_shade<false>(), s, fd, 1, cano_view_dirs, dirs, x_norm, T, (const int*)nullptr, (const int*)nullptr, n,
+                      out, w.spill, &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3, dbg);
     return check_launch();
 }
 

@@ -92,7 +92,7 @@ COUNTER_BYTES = C.sizeof(ArahCounters)
 EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_prepare_body", "arah_workspace_bytes", "arah_counters_reset",
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
-           "arah_shade_composite", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
+           "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
            "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
            "arah_set_density_events", "arah_set_canon_events"]
 
@@ -475,6 +475,21 @@ def color_eval(frame, ws, x_norm, normal, view, feat):
     _check(lib.arah_color_eval(C.byref(frame.handle), _ptr(x), _ptr(nr), _ptr(vw), _ptr(ft), C.c_int32(n), _ptr(rgb),
                                _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_color_eval")
     return rgb
+
+
+@_guarded
+def shade_points(frame, ws, x_norm, T, dirs, cano_view_dirs=True):
+    """The per-sample half of loop D on the frame's own engine (arah_shade_points): n normalised canonical points with their
+    transforms (n,4,4) and ray directions (n,3) -> rgb (n,3), density (n,), sdf (n,), d sdf / d x_norm (n,3)."""
+    lib = load_library()
+    x, Tm, d = _f32(x_norm), _f32(T), _f32(dirs)
+    n = x.shape[0]
+    buf = ws.ensure(n, 1)
+    rgbs = torch.empty(n, 4, device=x.device)
+    sdfn = torch.empty(n, 4, device=x.device)
+    _check(lib.arah_shade_points(C.byref(frame.handle), _ptr(x), _ptr(Tm), _ptr(d), C.c_int32(n), C.c_int32(int(bool(cano_view_dirs))),
+                                 _ptr(rgbs), _ptr(sdfn), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_shade_points")
+    return rgbs[:, :3], rgbs[:, 3], sdfn[:, 0], sdfn[:, 1:]
 
 
 @_guarded

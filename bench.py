@@ -101,7 +101,11 @@ def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays, model_g
     dt = time.perf_counter() - t0
     out = {"value": n / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
            "sample": "%d rays evenly subsampled from frame 0 of the %dx%dx%d workload, oracle/arah_oracle.py "
-                     "(torch CPU fp32, cKDTree 1-NN), %.1f s" % (n, size, size, n_steps, dt)}
+                     "(torch CPU fp32, cKDTree 1-NN), %.1f s" % (n, size, size, n_steps, dt),
+           # the oracle's own work counters per ray (tests/test_hip_parity.py::test_work_counters_against_oracle
+           # holds the kernels' counters against them): the reference shades every valid sample and evaluates the start
+           # point of every loop-C sample twice, so n_col / n_sdf_grad / n_skin_fwd are larger than the default path's
+           "work": {"per_ray": {k: v / max(n, 1) for k, v in ref["frame"].counters.items()}}}
     if model_gpu is not None:
         with torch.no_grad():
             got = model_gpu(scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays, device=dev), eval=True)
@@ -466,13 +470,8 @@ def run(args, rt):
                          "traffic_unit": "bytes/launch", "traffic_source": canon_src, "traffic_live": False,
                          "avg_launch_ms": canon_avg_ms, "evaluations_per_launch": canon_evals,
                          "flops_per_evaluation": F_SKIN,
-                         "peak_note": ("algorithmic fp32 MFMA flops of the skinning MLP against dense f16 MFMA peak / 3 (three "
-                                       "f16 MFMAs per fp32 product) at the 2.4 GHz peak clock; under this kernel the chip runs "
-                                       "at 1.75-1.9 GHz (power), where the f16 16x16x32 MFMA microbenchmark ceiling is 1955 "
-                                       "TFLOP/s = 652 algorithmic (MI355X_MICROARCH.md); the kernel's Softplus epilogues, softmax "
-                                       "tree and Broyden update keep the vector ALU 76 % busy (rocprofv3 SQ counters, "
-                                       "profiles/): it is vector-ALU bound (DESIGN.md section 4)" if split else
-                                       "dense fp32 MFMA peak")},
+                         "peak_note": ("dense f16 MFMA peak / 3: three v_mfma_f32_16x16x32_f16 per fp32 product "
+                                       "(MI355X_MICROARCH.md)" if split else "dense fp32 MFMA peak")},
             "roofline_k_density": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
                                    "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
                                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_live": False,

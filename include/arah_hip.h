@@ -12,6 +12,7 @@
  *   arah_sample_canonicalize BodyRayTracing.ray_sampler / inv_transform_points_opt /
  *                           search_canonical_corr  ray_tracing.py:313-461, root_finding_utils.py:267-362
  *   arah_shade_composite    IDHRNetwork.get_rbg_value_vol_sdf + the eval tail of forward
+ *   arah_shade_points       its per-sample half (SDF, normal, colour, density) on the shipped engine
  *                           renderer/implicit_differentiable_renderer.py:261-396, :142-148,:225-257
  *   arah_render             IDHRNetwork.forward (eval)  implicit_differentiable_renderer.py:42-259
  *   arah_sdf_eval           sdf_network(x) / gradient(sdf, x)   hyperlayers.py:385-415,
@@ -353,6 +354,14 @@ int arah_shade_composite(const ArahFrame* h_frame, const ArahSampling* h_cfg, co
                          const float* z, const float* pts, const float* T, const uint8_t* mask,
                          int32_t n_rays, float* rgb, float* acc, uint8_t* vol_mask, void* workspace,
                          size_t workspace_bytes, void* stream);
+/* Per-sample half of loop D as a seam of its own (IDR:291-368 before the compositing): the SHIPPED shading kernel -- on a
+ * split-engine frame the bf16 x 3 normal sweep and colour MLP (ARAH_SHADE_ENGINE=fp32: the fp32 MFMA), on an fp32 frame the
+ * exact engine -- on n normalised canonical points with their own blended transforms T [n,16] and ray directions dirs [n,3].
+ * -> rgbs [n,4] = {rgb, VolSDF density}, sdfn [n,4] = {sdf (normalised units), d sdf / d x_norm}.  Needs a workspace of
+ * arah_workspace_bytes(n, 1). */
+int arah_shade_points(const ArahFrame* h_frame, const float* x_norm, const float* T, const float* dirs, int32_t n_pts,
+                      int32_t cano_view_dirs, float* rgbs, float* sdfn, void* workspace, size_t workspace_bytes,
+                      void* stream);
 /* whole eval forward.  pose34 = DEVICE [3][4] world->camera (R|t), read by the last kernel only (no host copy of
  * the pose, no stream drain).  Any of the optional outputs may be NULL, then they live in the workspace.
  * -> rgb [N,3], points_cam [N,3], vol_mask [N] */
