@@ -88,6 +88,10 @@ class GradientExchange:
             p0 = self.params[idx[0]]
             self.flat.append(torch.zeros(off, dtype=p0.dtype, device=p0.device))
         self.hooks = []
+        # On the GPU (RCCL) the collectives are issued from ONE stream of this object's own, ordered by events behind the copies
+        # that fill a bucket: a gradient hook runs on whatever stream autograd replays that node on, and the exchange must not
+        # depend on which.  (ProcessGroupNCCL makes its internal stream wait for the stream that is current at the call.)
+        self.comm_stream = torch.cuda.Stream(self.params[0].device) if self.params and self.params[0].is_cuda else None
         if world > 1:
             for i, p in enumerate(self.params):
                 self.hooks.append(p.register_post_accumulate_grad_hook(lambda _p, i=i: self._ready(i)))
@@ -97,6 +101,7 @@ class GradientExchange:
         self.fired = [False] * len(self.params)
         self.missing = [len(idx) for idx in self.buckets]
         self.work = [None] * len(self.buckets)
+        self.filled = [[] for _ in self.buckets]   # GPU: events behind the copies into each bucket
         self.next = 0        # first bucket that has not been sent yet
 
     def _slice(self, i):
@@ -109,9 +114,21 @@ class GradientExchange:
         self.fired[i] = True
         self._slice(i).copy_(self.params[i].grad.reshape(-1))
         self.missing[self.bucket_of[i]] -= 1
+        if self.comm_stream is not None:
+            self.filled[self.bucket_of[i]].append(torch.cuda.current_stream(self.params[i].device).record_event())
         while self.next < len(self.buckets) and self.missing[self.next] == 0:
-            self.work[self.next] = self.dist.all_reduce(self.flat[self.next], async_op=True)
+            self._send(self.next)
             self.next += 1
+
+    def _send(self, b):
+        """All-reduce bucket b (asynchronously), behind everything that wrote into it."""
+        if self.comm_stream is None:
+            self.work[b] = self.dist.all_reduce(self.flat[b], async_op=True)
+            return
+        for ev in self.filled[b]:
+            self.comm_stream.wait_event(ev)
+        with torch.cuda.stream(self.comm_stream):
+            self.work[b] = self.dist.all_reduce(self.flat[b], async_op=True)
 
     def finish(self, stop=False):
         """Call after backward().  Returns True if any rank asked to stop."""
@@ -126,7 +143,9 @@ class GradientExchange:
             for i in self.buckets[b]:
                 if not self.fired[i]:
                     self._slice(i).zero_()
-            self.work[b] = self.dist.all_reduce(self.flat[b], async_op=True)
+            if self.comm_stream is not None:
+                self.filled[b].append(torch.cuda.current_stream(dev).record_event())
+            self._send(b)
         self.next = len(self.buckets)
         seen = torch.tensor([1.0 if f else 0.0 for f in self.fired] + [1.0 if stop else 0.0], device=dev)
         seen_work = self.dist.all_reduce(seen, async_op=True)

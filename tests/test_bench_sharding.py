@@ -3,6 +3,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -127,11 +128,16 @@ class _StubRuntime:
         return False
 
 
-def _run_worker(rank, world, port, out):
+def _run_worker(rank, world, port, out, backend="gloo"):
     import argparse
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":   # RCCL: one GPU per rank, the aggregation's two scalar all-reduces on the device
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     args = argparse.Namespace(gpus=world, steps=3, warmup=1, size=64, n_steps=64, config="zju377_mono",
                               cpu_sample_rays=16, no_cpu_baseline=True, no_train=True, passes="default", streams=1, beta=None)
     rt = _StubRuntime(world, rank)
@@ -141,13 +147,25 @@ def _run_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_bench_run_two_ranks_rccl():
+    """bench.run()'s sharding and aggregation over RCCL (stub renderer, real collectives): needs two visible GPUs."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _check_bench_run("nccl")
+
+
 def test_bench_run_two_ranks_gloo():
     """bench.run() end to end on two ranks: disjoint frames per rank, value = all ranks' rays / the SLOWER rank's
     time, one JSON line on rank 0 only, with the fields the driver parses."""
+    _check_bench_run("gloo")
+
+
+def _check_bench_run(backend):
     world = 2
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_run_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.spawn(_run_worker, args=(world, _free_port(), out, backend), nprocs=world, join=True)
     line0, frames0 = out[0]
     line1, frames1 = out[1]
     assert line1 is None and line0 is not None

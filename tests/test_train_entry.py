@@ -82,16 +82,28 @@ def test_allreduce_gradients_two_ranks_gloo():
         assert torch.equal(g0, torch.full((3, 4), 1.5)) and torch.equal(g1, torch.arange(5.0) * 1.5) and g2 is None
 
 
-def _exchange_worker(rank, world, port, out):
+def _exchange_worker(rank, world, port, out, backend="gloo"):
     """Two replicas whose items touch DIFFERENT parameters (per-frame parameters under train_smpl): gradients arrive through
-    the hooks during backward(), small buckets force several collectives, one parameter is used by no rank."""
+    the hooks during backward(), small buckets force several collectives, one parameter is used by no rank.
+    backend "nccl" (= RCCL): one GPU per rank, the exchange on its own stream behind events."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cpu")
+    if backend == "nccl":
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dev = torch.device("cuda", rank)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    elif backend == "gloo_cuda":   # device tensors, both ranks on GPU 0, gloo moving them: the stream / event side of the exchange
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                              # replicas start from different draws ...
     net = torch.nn.ModuleDict({"shared": torch.nn.Linear(6, 5), "frames": torch.nn.ParameterDict(
         {"pose_0": torch.nn.Parameter(torch.randn(6)), "pose_1": torch.nn.Parameter(torch.randn(6)),
-         "pose_2": torch.nn.Parameter(torch.randn(6))}), "head": torch.nn.Linear(5, 1)})
+         "pose_2": torch.nn.Parameter(torch.randn(6))}), "head": torch.nn.Linear(5, 1)}).to(dev)
     train.broadcast_state(net, world, dist)                    # ... and are made equal, like Lightning's DDP does
     start = {k: v.clone() for k, v in net.state_dict().items()}
     params = list(net.parameters())
@@ -106,17 +118,40 @@ def _exchange_worker(rank, world, port, out):
         loss.backward()
         stops.append(ex.finish(stop=(rank == 1 and step == 2)))
         if step == 0:
-            grads = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+            grads = {n: (None if p.grad is None else p.grad.detach().cpu().clone()) for n, p in net.named_parameters()}
         opt.step()
-    out[rank] = (start, grads, {k: v.clone() for k, v in net.state_dict().items()}, stops, loss.item())
+    out[rank] = ({k: v.cpu() for k, v in start.items()}, grads, {k: v.cpu().clone() for k, v in net.state_dict().items()}, stops,
+                 loss.item())
     dist.barrier()
     dist.destroy_process_group()
 
 
+@pytest.mark.gpu
+def test_gradient_exchange_with_rank_dependent_parameter_sets_rccl():
+    """The same exchange over RCCL, one GPU per rank: runs wherever two GPUs are visible (the driver's scaling node), skips
+    on a one-GPU box.  tools/scale.sh launches the full-size counterparts (bench.py --gpus N, train_bench.py --exchange native)."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _check_exchange("nccl", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_gradient_exchange_on_device_tensors():
+    """The exchange with its parameters on the GPU (one GPU shared by both ranks, gloo as the transport): the collectives are
+    issued from the exchange's own stream behind events recorded after the bucket copies."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    _check_exchange("gloo_cuda", rtol=1e-5, atol=1e-6)
+
+
 def test_gradient_exchange_with_rank_dependent_parameter_sets():
+    _check_exchange("gloo", rtol=1e-6, atol=1e-7)
+
+
+def _check_exchange(backend, rtol, atol):
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_exchange_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_exchange_worker, args=(2, _free_port(), out, backend), nprocs=2, join=True)
     (s0, g0, e0, stop0, _), (s1, g1, e1, stop1, _) = out[0], out[1]
     for k in s0:
         assert torch.equal(s0[k], s1[k]), k                    # broadcast_state
@@ -139,7 +174,7 @@ def test_gradient_exchange_with_rank_dependent_parameter_sets():
                 want[n] += p.grad / 2
     for n in want:
         if g0[n] is not None:
-            torch.testing.assert_close(g0[n], want[n], rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(g0[n], want[n], rtol=rtol, atol=atol)
     assert not torch.equal(e0["frames.pose_0"], s0["frames.pose_0"]) and torch.equal(e0["frames.pose_2"], s0["frames.pose_2"])
     for k in e0:
         assert torch.equal(e0[k], e1[k]), k                    # replicas stay identical after three Adam steps
