@@ -2769,8 +2769,6 @@ int setup_attributes() {
 }
 
 // optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
-hipEvent_t g_shade_ev0 = nullptr, g_shade_ev1 = nullptr, g_density_ev0 = nullptr, g_density_ev1 = nullptr;
-hipEvent_t g_canon_ev0 = nullptr, g_canon_ev1 = nullptr;
 
 KnnData knn_of(const FrameDev& fd) {
     return KnnData{fd.knn.sorted4, fd.knn.spheres, reinterpret_cast<const GridInfo*>(fd.knn.grid), fd.knn.cells};
@@ -3222,15 +3220,10 @@ static B3Nets b3_of(const ArahFrame& f) {
     return b;
 }
 
-// ARAH_SHADE_ENGINE=fp32: normal sweep and colour MLP of loop D on the fp32 MFMA (rounds 1-2); default: bf16 x 3 for
-// frames prepared for the split engine (ARAH_PRECISION_FP32 frames are fp32 throughout)
-static bool shade_b3() {
-    static const bool on = [] {
-        const char* e = getenv("ARAH_SHADE_ENGINE");
-        return !(e && strcmp(e, "fp32") == 0);
-    }();
-    return on;
-}
+// Engine of loop D's normal sweep and colour MLP on a split-engine frame: bf16 x 3 (default), or the fp32 MFMA when the CALL
+// says so (ArahSampling::shade_engine / the argument of arah_shade_points; ARAH_PRECISION_FP32 frames are fp32 throughout).
+// Round 4: a field of the call, not an environment variable read into a process-wide static.
+static bool shade_b3(int32_t shade_engine) { return shade_engine != ARAH_SHADE_ENGINE_FP32; }
 
 // =============================================================================================
 // C ABI
@@ -3249,32 +3242,6 @@ int arah_prepare_body(const float* verts, int32_t n_verts, void* body_buf, size_
 }
 
 const char* arah_dominant_kernel(void) { return "k_canon_wave"; }   // largest single launch of the default path (loop C)
-
-int arah_set_shade_events(void* start_event, void* stop_event) {
-    g_shade_ev0 = reinterpret_cast<hipEvent_t>(start_event);
-    g_shade_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
-    return ARAH_OK;
-}
-
-int arah_set_density_events(void* start_event, void* stop_event) {
-    g_density_ev0 = reinterpret_cast<hipEvent_t>(start_event);
-    g_density_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
-    return ARAH_OK;
-}
-
-#ifdef CW_DEBUG
-float* g_cw_dbg = nullptr;   // debugging builds only (tools/jobs): 64 floats per point, written by k_canon_wave
-extern "C" int arah_debug_set_buffer(void* p) {
-    g_cw_dbg = reinterpret_cast<float*>(p);
-    return ARAH_OK;
-}
-#endif
-
-int arah_set_canon_events(void* start_event, void* stop_event) {
-    g_canon_ev0 = reinterpret_cast<hipEvent_t>(start_event);
-    g_canon_ev1 = reinterpret_cast<hipEvent_t>(stop_event);
-    return ARAH_OK;
-}
 
 size_t arah_frame_bytes(const ArahNets* h_nets, const ArahBody* h_body) {
     if (!h_nets || !h_body) return 0;
@@ -3376,7 +3343,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         jobs.add_copy(cb + 1152, nets->col_b[5], 3, 4);
     }
     // ---- bf16 hi/lo fragments for loop D's normal sweep (W^T of the trunk) and colour MLP
-    if (nets->precision == ARAH_PRECISION_SPLIT_F16 && shade_b3()) {
+    if (nets->precision == ARAH_PRECISION_SPLIT_F16) {   // always: the call decides whether it uses them
         const size_t src[kB3Count] = {L.sdf_wp[0], L.sdf_wp[1], L.sdf_wp[2], L.sdf_wp[3], L.sdf_wp[4],
                                       L.sdf_wpT[0], L.sdf_wpT[1], L.sdf_wpT[2], L.sdf_wpT[3], L.sdf_wpT[4],
                                       L.col_w0p, L.col_w1p, L.col_w2p, L.col_w3ap, L.col_w3bp, L.col_w4p,
@@ -3636,25 +3603,18 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
 // the target in row 3 -- written there by k_nearest_invlbs<SAMPLES>, or here from tgt); the results replace them.
 // w.counts: [0] = number of entries, [1] = head of the queue (zeroed by the caller's memset of w.counts).
 static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, CanonOut outp, long long max_pts,
-                        hipStream_t s) {
+                        hipStream_t s, int mode_arg = ARAH_CANON_KERNEL_WAVE, void* const* ev = nullptr) {
     int* cnt = w.counts;
     if (tgt)
         hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
                            (const int*)&cnt[0], tgt, outp.T);
-    // ARAH_CANON_KERNEL: wave (default: point-owning waves, hi fragments in LDS), wave_l2 (all fragments from L2),
-    // tile (round 2's channel-sliced tiles).  The exact engine always runs the tile kernel.
-    static const int mode = [] {
-        const char* e = getenv("ARAH_CANON_KERNEL");
-        if (e && !strcmp(e, "tile")) return 0;
-        if (e && !strcmp(e, "wave_l2")) return 2;
-        return 1;
-    }();
-    if (g_canon_ev0) hipEventRecord(g_canon_ev0, s);
-#ifdef CW_DEBUG
-    unsigned long long* const clk_arg = reinterpret_cast<unsigned long long*>(g_cw_dbg);
-#else
+    // mode: ARAH_CANON_KERNEL_WAVE (default: point-owning waves, hi fragments in LDS), _WAVE_L2 (all fragments from L2), _TILE
+    // (round 2's channel-sliced tiles).  The exact engine always runs the tile kernel.  A field of the call
+    // (ArahSampling::canon_kernel), like the profiling events recorded around the launch: nothing here is process-global.
+    const int mode = mode_arg == ARAH_CANON_KERNEL_TILE ? 0 : (mode_arg == ARAH_CANON_KERNEL_WAVE_L2 ? 2 : 1);
+    hipEvent_t ev0 = ev ? reinterpret_cast<hipEvent_t>(ev[0]) : nullptr, ev1 = ev ? reinterpret_cast<hipEvent_t>(ev[1]) : nullptr;
+    if (ev0 && ev1) hipEventRecord(ev0, s);
     unsigned long long* const clk_arg = w.ctr->clk;
-#endif
     if (fd.split && mode != 0) {
         long long gw = (max_pts + kCwWaves * kCwSlots - 1) / (kCwWaves * kCwSlots);
         const int cus = num_cus();
@@ -3682,12 +3642,12 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
                       kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
                       &w.ctr->n_skin_fwd, &w.ctr->n_canon, w.ctr->clk);
     }
-    if (g_canon_ev1) hipEventRecord(g_canon_ev1, s);
+    if (ev0 && ev1) hipEventRecord(ev1, s);
     return check_launch();
 }
 
 int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, const float* T0, int32_t n, float* x,
-                      float* T, float* err, uint8_t* conv, void* workspace, size_t wbytes, void* stream) {
+                      float* T, float* err, uint8_t* conv, int32_t canon_kernel, void* workspace, size_t wbytes, void* stream) {
     if (!f || !tgt || !x0 || !T0 || !x || !T || !conv || n < 0 || !workspace) return ARAH_E_BADARG;
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, n, 1);
@@ -3699,7 +3659,7 @@ int arah_broyden3_lbs(const ArahFrame* f, const float* tgt, const float* x0, con
     hipMemcpyAsync(T, T0, (size_t)n * 16 * 4, hipMemcpyDeviceToDevice, s);
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, n, w.listA, &w.counts[0]);
-    int rc = run_broyden3(fd, w, tgt, CanonOut{x, T, w.q_err}, n, s);
+    int rc = run_broyden3(fd, w, tgt, CanonOut{x, T, w.q_err}, n, s, canon_kernel);
     if (rc) return rc;
     hipLaunchKernelGGL(k_broyden3_finalize, dim3((n + 255) / 256), dim3(256), 0, s, n, (const float*)w.q_err, err, conv);
     return check_launch();
@@ -3848,7 +3808,7 @@ static int sample_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w
     // x0 -> pts (raw canonical, doubles as x_best), T0 -> T (doubles as T_best)
     launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)z, S, (const int*)w.listA,
                                 (const int*)&w.counts[0], 0, (int*)nullptr, pts, T, 1, &w.ctr->n_knn);
-    int rc = run_broyden3(fd, w, nullptr, CanonOut{pts, T, w.q_err}, Q, s);
+    int rc = run_broyden3(fd, w, nullptr, CanonOut{pts, T, w.q_err}, Q, s, cfg->canon_kernel, cfg->ev_canon);
     if (rc) return rc;
     hipLaunchKernelGGL(k_canon_finalize, dim3(gq), dim3(256), 0, s, fd, (int)Q, (const uint8_t*)w.q_smask,
                        (const float*)w.q_err, pts, T, mask);
@@ -3895,7 +3855,7 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     const int* slist = w.listA;
     const int* scount = &w.counts[0];
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
-        if (g_density_ev0) hipEventRecord(g_density_ev0, s);
+        if (cfg->ev_density[0] && cfg->ev_density[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[0]), s);
         // long lists on the split engine: 128-point tiles, one workgroup per CU (ARAH_DENSITY_TILE=64 keeps the 64-point kernel)
         static const bool wide = env_int("ARAH_DENSITY_TILE", 128) == 128;
         if (fd.split && wide && Q >= 128ll * 1024)
@@ -3906,13 +3866,13 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
             LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
                           (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd,
                           &w.ctr->n_density);
-        if (g_density_ev1) hipEventRecord(g_density_ev1, s);
+        if (cfg->ev_density[0] && cfg->ev_density[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[1]), s);
         slist = w.listB;
         scount = &w.counts[1];
     }
-    if (g_shade_ev0) hipEventRecord(g_shade_ev0, s);
+    if (cfg->ev_shade[0] && cfg->ev_shade[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_shade[0]), s);
     const B3Nets b3 = b3_of(*f);
-    if (fd.split && shade_b3()) {
+    if (fd.split && shade_b3(cfg->shade_engine)) {
         if (f->col_mode == ARAH_COLOR_IDR)
             hipLaunchKernelGGL((k_shade<true, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade_b3<true>()), s, fd, S,
                                cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill, &w.ctr->n_sdf_fwd,
@@ -3929,14 +3889,15 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
         LAUNCH_ENGINE(fd.split, (k_shade<false, true>), (k_shade<false, false>), dim3(g), dim3(kThreads),
                       lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill,
                       &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
-    if (g_shade_ev1) hipEventRecord(g_shade_ev1, s);
+    if (cfg->ev_shade[0] && cfg->ev_shade[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_shade[1]), s);
     hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);
     return check_launch();
 }
 
 int arah_shade_points(const ArahFrame* f, const float* x_norm, const float* T, const float* dirs, int32_t n,
-                      int32_t cano_view_dirs, float* rgbs, float* sdfn, void* workspace, size_t wbytes, void* stream) {
+                      int32_t cano_view_dirs, int32_t shade_engine, float* rgbs, float* sdfn, void* workspace, size_t wbytes,
+                      void* stream) {
     if (!f || !x_norm || !T || !dirs || !rgbs || !sdfn || n < 0 || !workspace) return ARAH_E_BADARG;
     if (n == 0) return ARAH_OK;
     Workspace w = carve(workspace, n, 1);
@@ -3949,7 +3910,7 @@ int arah_shade_points(const ArahFrame* f, const float* x_norm, const float* T, c
     f32x4* out = reinterpret_cast<f32x4*>(rgbs);
     f32x4* dbg = reinterpret_cast<f32x4*>(sdfn);
     // the kernels of shade_impl, one sample per "ray" (S = 1: dirs are per point), no list
-    if (fd.split && shade_b3()) {
+    if (fd.split && shade_b3(shade_engine)) {
         if (f->col_mode == ARAH_COLOR_IDR)
             hipLaunchKernelGGL((k_shade<true, true, true>), dim3(g), dim3(kThreads), split_lds(lds_shade_b3<true>()), s, fd, 1,
                                cano_view_dirs, dirs, x_norm, T, (const int*)nullptr, (const int*)nullptr, n, out, w.spill,
@@ -3987,13 +3948,16 @@ static ColNetT colT_of(const ArahFrame& f) {
     return ColNetT{f.col_w0pT, f.col_w1pT, f.col_w2pT, f.col_w3apT, f.col_w3bpT, f.col_w4pT};
 }
 
-// ARAH_TRAIN_ENGINE=fp32: every product of the training kernels on the fp32 MFMA (round 2); default: bf16 x 3
-static bool train_b3() {
-    static const bool on = [] {
+// Engine of the training kernels: bf16 x 3 backward-direction products and the f16 split forward trunk on a split-engine
+// frame; a frame prepared for ARAH_PRECISION_FP32 -- the caller's choice, or the renderer's after its range guard fired --
+// gets the all-fp32 kernels in training as in inference (round 4: it used to follow the environment only).
+// ARAH_TRAIN_ENGINE=fp32 (read once, immutable) forces them for split frames too.
+static bool train_b3(const ArahFrame& f) {
+    static const bool env_on = [] {
         const char* e = getenv("ARAH_TRAIN_ENGINE");
         return !(e && strcmp(e, "fp32") == 0);
     }();
-    return on;
+    return env_on && f.precision == ARAH_PRECISION_SPLIT_F16;
 }
 
 size_t arah_shade_train_slab_bytes(void) { return (size_t)kMaxGrid / 2 * kTrainSlabPerWg * sizeof(f32x4); }
@@ -4026,7 +3990,7 @@ int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* s
 #define ARAH_LAUNCH_TRAIN(IDR_, BWD_, B3_, SLAB_)                                                                        \
     hipLaunchKernelGGL((k_shade_train<IDR_, BWD_, B3_>), dim3(g), dim3(kThreads), lds_shade_train<IDR_>(), s, fd,        \
                        colT_of(*f), b3_of(*f), ti, to, w.spill, SLAB_)
-    if (train_b3()) {
+    if (train_b3(*f)) {
         if (idr) ARAH_LAUNCH_TRAIN(true, false, true, (f32x4*)nullptr);
         else ARAH_LAUNCH_TRAIN(false, false, true, (f32x4*)nullptr);
     } else {
@@ -4080,7 +4044,7 @@ int arah_shade_train_backward(const ArahFrame* f, const ArahTrainIn* in, const A
     const int g = min(grid_for(in->n, kTile), kMaxGrid / 2);
     const bool idr = f->col_mode == ARAH_COLOR_IDR;
     f32x4* slab4 = reinterpret_cast<f32x4*>(slab);
-    if (train_b3()) {
+    if (train_b3(*f)) {
         // bf16 hi/lo fragments of the matrices of the backward-direction products (W and W^T of the SDF trunk, W^T of the
         // colour MLP), made here from the frame's fp32 packings: sixteen small launches per training step, none in inference
         const int kc0 = (idr ? ColDims<true>::kInPad : ColDims<false>::kInPad) / 16;

@@ -7,10 +7,11 @@
 // workgroup adopts a 16-ray tile of the list and runs its rays to the end of the loop without leaving the kernel (the
 // same device functions in the same order as the per-iteration kernels: results are bit-identical per ray).
 // Measured on the MI355X (profiles/r03_*): the loop-B finisher replaces 48 launches (1.5 ms) by one of 1.36 ms and is
-// the default after three wide iterations.  The loop-A finisher is NOT: its step is bounded by the exact nearest-vertex
-// search of the straggler rays (25 us per one-wave-per-query search, measured in both forms), which the per-step
-// kernel runs for all rays at once while a tile's wave runs two of them back to back -- 95 us per step against 52
-// (3.6 ms against 1.9).  It stays available (ARAH_TRACE_BULK_STEPS < 50) for the day the search gets cheaper.
+// the default after three wide iterations.  The loop-A finisher takes over after ARAH_TRACE_BULK_STEPS = 24 wide steps of a
+// full frame (earlier hand-overs lose: too many rays left for sixteen-ray tiles, profiles/r03_ab_trace_finish.txt) and
+// runs the WHOLE loop for ray lists of at most ARAH_TRACE_SMALL = 4096 rays (a training view); its nearest-vertex search
+// is the sixteen-lane one (four slots per wave in one pass) -- with one wave per query its step was 95 us against 52 for
+// the per-step kernels and it was not the default.
 #pragma once
 
 constexpr int kFinTile = 16;

@@ -20,6 +20,20 @@ PRECISION_SPLIT_F16 = 0   # fp32 carried as hi + lo f16 pairs on the f16 matrix 
 PRECISION_FP32 = 1        # v_mfma_f32_16x16x4_f32 everywhere
 
 
+SHADE_ENGINE_DEFAULT, SHADE_ENGINE_FP32 = 0, 1
+CANON_KERNEL_WAVE, CANON_KERNEL_TILE, CANON_KERNEL_WAVE_L2 = 0, 1, 2
+
+
+def default_shade_engine():
+    """ARAH_SHADE_ENGINE=fp32: loop D's normal sweep and colour MLP on the fp32 MFMA; default bf16 x 3 (split frames)."""
+    return SHADE_ENGINE_FP32 if os.environ.get("ARAH_SHADE_ENGINE", "b3") == "fp32" else SHADE_ENGINE_DEFAULT
+
+
+def default_canon_kernel():
+    """ARAH_CANON_KERNEL = wave (default) | tile | wave_l2: loop C's solver on split-engine frames."""
+    return {"tile": CANON_KERNEL_TILE, "wave_l2": CANON_KERNEL_WAVE_L2}.get(os.environ.get("ARAH_CANON_KERNEL", "wave"), CANON_KERNEL_WAVE)
+
+
 def default_precision():
     """ARAH_PRECISION=fp32 selects the exact engine for every GEMM; default is the split engine."""
     v = os.environ.get("ARAH_PRECISION", "split").lower()
@@ -50,7 +64,9 @@ class ArahBody(C.Structure):
 class ArahSampling(C.Structure):
     _fields_ = [("n_steps", C.c_int32), ("n_near", C.c_int32), ("n_far", C.c_int32),
                 ("cano_view_dirs", C.c_int32), ("render_last_pt", C.c_int32), ("full_shading", C.c_int32),
-                ("lin_steps", _fp), ("lin_near", _fp), ("lin_far", _fp)]
+                ("lin_steps", _fp), ("lin_near", _fp), ("lin_far", _fp),
+                ("shade_engine", C.c_int32), ("canon_kernel", C.c_int32),
+                ("ev_canon", C.c_void_p * 2), ("ev_density", C.c_void_p * 2), ("ev_shade", C.c_void_p * 2)]
 
 
 class ArahFrame(C.Structure):
@@ -93,8 +109,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel", "arah_set_shade_events",
-           "arah_set_density_events", "arah_set_canon_events"]
+           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel"]
 
 _lib = None
 
@@ -260,6 +275,7 @@ class BodyTables:
         lib = load_library()
         dev = verts.device
         self.verts = _f32(verts)
+        self.verts_version = self.verts._version
         if self.verts.dim() != 2 or self.verts.shape[1] != 3:
             raise ValueError("verts must be (V, 3)")
         cur = torch.cuda.current_stream(dev)
@@ -343,7 +359,12 @@ class Frame:
         body.n_verts = int(verts.shape[0])
         self.body_tables = body_tables
         if body_tables is not None:
-            if body_tables.device != dev or tuple(body_tables.verts.shape) != tuple(self.verts.shape):
+            # the tables must be THESE vertices': same storage, untouched since (a reused inputs dict whose smpl_verts were
+            # replaced or modified in place after the tables were built would otherwise be searched with a stale body)
+            same = tuple(body_tables.verts.shape) == tuple(self.verts.shape) and (
+                (body_tables.verts.data_ptr() == self.verts.data_ptr() and body_tables.verts_version == self.verts._version)
+                or bool(torch.equal(body_tables.verts, self.verts)))
+            if body_tables.device != dev or not same:
                 raise ValueError("body_tables were built for another body / device")
             torch.cuda.current_stream(dev).wait_event(body_tables.done)
             body.prepared = body_tables.buf.data_ptr()
@@ -365,7 +386,7 @@ class Sampling:
     """ArahSampling + the device linspace tables (bit-identical to torch.linspace on the CPU)."""
 
     def __init__(self, device, n_steps=64, n_near=16, n_far=16, cano_view_dirs=True, render_last_pt=False,
-                 full_shading=False):
+                 full_shading=False, shade_engine=None, canon_kernel=None):
         if n_steps < n_near + n_far + 1 or n_steps > ARAH_MAX_STEPS:
             raise ValueError("need n_near + n_far + 1 <= n_steps <= %d (ARAH_E_SAMPLING)" % ARAH_MAX_STEPS)
         self.lin_steps = torch.linspace(0.0, 1.0, n_steps, dtype=torch.float32).to(device)
@@ -376,8 +397,24 @@ class Sampling:
         s.cano_view_dirs, s.render_last_pt = int(bool(cano_view_dirs)), int(bool(render_last_pt))
         s.full_shading = int(bool(full_shading))
         s.lin_steps, s.lin_near, s.lin_far = _ptr(self.lin_steps), _ptr(self.lin_near), _ptr(self.lin_far)
+        # per-call switches of the library (it reads no environment itself): None = this process's default
+        s.shade_engine = default_shade_engine() if shade_engine is None else int(shade_engine)
+        s.canon_kernel = default_canon_kernel() if canon_kernel is None else int(canon_kernel)
         self.handle = s
+        self._events = {}
         self.n_steps, self.n_near, self.n_far = n_steps, n_near, n_far
+
+    def set_events(self, which, start=None, stop=None):
+        """Profiling hook of THIS sampling object: every call that takes it records the torch.cuda.Event pair on its stream
+        around loop C's solver ("canon"), the density pre-pass ("density") or the shading kernel ("shade").  None switches
+        it off.  (Round 3 kept the handles in process-wide variables of the library.)"""
+        field = getattr(self.handle, {"canon": "ev_canon", "density": "ev_density", "shade": "ev_shade"}[which])
+        for ev in (start, stop):   # torch creates the hipEvent lazily, on the first record
+            if ev is not None and not ev.cuda_event:
+                ev.record()
+        field[0] = start.cuda_event if start is not None else None
+        field[1] = stop.cuda_event if stop is not None else None
+        self._events[which] = (start, stop)   # keep them alive
 
 
 # ------------------------------------------------------------------------------------------------
@@ -478,7 +515,7 @@ def color_eval(frame, ws, x_norm, normal, view, feat):
 
 
 @_guarded
-def shade_points(frame, ws, x_norm, T, dirs, cano_view_dirs=True):
+def shade_points(frame, ws, x_norm, T, dirs, cano_view_dirs=True, shade_engine=None):
     """The per-sample half of loop D on the frame's own engine (arah_shade_points): n normalised canonical points with their
     transforms (n,4,4) and ray directions (n,3) -> rgb (n,3), density (n,), sdf (n,), d sdf / d x_norm (n,3)."""
     lib = load_library()
@@ -487,8 +524,9 @@ def shade_points(frame, ws, x_norm, T, dirs, cano_view_dirs=True):
     buf = ws.ensure(n, 1)
     rgbs = torch.empty(n, 4, device=x.device)
     sdfn = torch.empty(n, 4, device=x.device)
+    eng = default_shade_engine() if shade_engine is None else int(shade_engine)
     _check(lib.arah_shade_points(C.byref(frame.handle), _ptr(x), _ptr(Tm), _ptr(d), C.c_int32(n), C.c_int32(int(bool(cano_view_dirs))),
-                                 _ptr(rgbs), _ptr(sdfn), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_shade_points")
+                                 C.c_int32(eng), _ptr(rgbs), _ptr(sdfn), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_shade_points")
     return rgbs[:, :3], rgbs[:, 3], sdfn[:, 0], sdfn[:, 1:]
 
 
@@ -507,8 +545,9 @@ def nearest_inverse_lbs(frame, ws, pts):
 
 
 @_guarded
-def broyden3_lbs(frame, ws, tgt, x0, T0):
+def broyden3_lbs(frame, ws, tgt, x0, T0, canon_kernel=None):
     lib = load_library()
+    kern = default_canon_kernel() if canon_kernel is None else int(canon_kernel)
     tgt, x0, T0 = _f32(tgt), _f32(x0), _f32(T0)
     n = tgt.shape[0]
     buf = ws.ensure(n, 1)
@@ -517,7 +556,7 @@ def broyden3_lbs(frame, ws, tgt, x0, T0):
     err = torch.empty(n, device=tgt.device)
     conv = torch.empty(n, dtype=torch.uint8, device=tgt.device)
     _check(lib.arah_broyden3_lbs(C.byref(frame.handle), _ptr(tgt), _ptr(x0), _ptr(T0), C.c_int32(n), _ptr(x), _ptr(T),
-                                 _ptr(err), _ptr(conv), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
+                                 _ptr(err), _ptr(conv), C.c_int32(kern), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
            "arah_broyden3_lbs")
     return x, T, err, conv.bool()
 
@@ -796,37 +835,6 @@ def gram_skinny(a, b):
                                     C.c_void_p(b.data_ptr()), C.c_int32(b.stride(0)),
                                     C.c_int32(n), C.c_int32(P), _ptr(partial), _stream()), "arah_gram_skinny")
     return partial.sum(0)
-
-
-def set_shade_events(start=None, stop=None):
-    """Record torch.cuda.Event `start`/`stop` around the dominant kernel of every following render."""
-    lib = load_library()
-    for ev in (start, stop):   # torch creates the hipEvent lazily, on the first record
-        if ev is not None:
-            ev.record()
-    a = C.c_void_p(start.cuda_event) if start is not None else None
-    b = C.c_void_p(stop.cuda_event) if stop is not None else None
-    _check(lib.arah_set_shade_events(a, b), "arah_set_shade_events")
-
-
-def set_canon_events(start=None, stop=None):
-    lib = load_library()
-    for ev in (start, stop):
-        if ev is not None:
-            ev.record()
-    a = C.c_void_p(start.cuda_event) if start is not None else None
-    b = C.c_void_p(stop.cuda_event) if stop is not None else None
-    _check(lib.arah_set_canon_events(a, b), "arah_set_canon_events")
-
-
-def set_density_events(start=None, stop=None):
-    lib = load_library()
-    for ev in (start, stop):
-        if ev is not None:
-            ev.record()
-    a = C.c_void_p(start.cuda_event) if start is not None else None
-    b = C.c_void_p(stop.cuda_event) if stop is not None else None
-    _check(lib.arah_set_density_events(a, b), "arah_set_density_events")
 
 
 @_guarded

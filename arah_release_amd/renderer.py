@@ -106,6 +106,10 @@ class BodyRayTracing(nn.Module):
         # False: exact lazy shading (normals/colours only where the VolSDF density is > 0); True: shade every
         # valid sample like the reference.  Same image either way (bit for bit); see DESIGN.md section 4.
         self.full_shading = os.environ.get("ARAH_FULL_SHADING", "0") == "1"
+        # per-call engine switches of the C ABI (None: the process default, hip.default_shade_engine / default_canon_kernel)
+        self.shade_engine = None
+        self.canon_kernel = None
+        self._events = {}
 
     def workspace(self, device):
         """Scratch of the C ABI for the CURRENT stream of `device` (render_sequence keeps several frames in flight, each
@@ -124,12 +128,25 @@ class BodyRayTracing(nn.Module):
         return list(self._ws.values())
 
     def sampling(self, device, cano_view_dirs=True, render_last_pt=False):
-        key = (str(device), bool(cano_view_dirs), bool(render_last_pt), bool(self.full_shading))
+        key = (str(device), bool(cano_view_dirs), bool(render_last_pt), bool(self.full_shading), self.shade_engine,
+               self.canon_kernel)
         if key not in self._sampling:
-            self._sampling[key] = hip.Sampling(device, self.n_steps, self.near_surface_vol_samples,
-                                               self.far_surface_vol_samples, cano_view_dirs, render_last_pt,
-                                               self.full_shading)
+            sm = hip.Sampling(device, self.n_steps, self.near_surface_vol_samples, self.far_surface_vol_samples,
+                              cano_view_dirs, render_last_pt, self.full_shading, self.shade_engine, self.canon_kernel)
+            for which, (a, b) in self._events.items():
+                sm.set_events(which, a, b)
+            self._sampling[key] = sm
         return self._sampling[key]
+
+    def set_events(self, which, start=None, stop=None):
+        """Profiling events ("canon" / "density" / "shade", hip.Sampling.set_events) on every sampling object of this tracer,
+        present and future: bench.py's kernel timing.  They belong to the objects, not to the library."""
+        if start is None or stop is None:
+            self._events.pop(which, None)
+        else:
+            self._events[which] = (start, stop)
+        for sm in self._sampling.values():
+            sm.set_events(which, start, stop)
 
     def forward(self, sdf_network, skinning_model, cam_loc, ray_directions, body_bounds_intersections, loc,
                 sc_factor, smpl_verts, smpl_verts_cano, skinning_weights, vol_feat, bone_transforms, trans,
@@ -179,7 +196,9 @@ class IDHRNetwork(nn.Module):
         # range guard of the split engine (ArahCounters.n_split_nonfinite): see _split_guard
         self.split_nonfinite = 0
         self._guard = {}
-        self._precision = None   # None: ARAH_PRECISION / default; becomes hip.PRECISION_FP32 once the guard has fired
+        self.precision = None    # GEMM engine frames are prepared for: None = the process default (ARAH_PRECISION, split),
+                                 # hip.PRECISION_FP32 / PRECISION_SPLIT_F16 = this renderer's own choice (bench.py's passes)
+        self._precision = None   # becomes hip.PRECISION_FP32 once the range guard has fired: overrides `precision`
 
     def forward_train(self, input):
         """Training forward (IDR:42-248): HIP kernels for the ray tracer (no_grad, like the reference), autograd
@@ -262,7 +281,8 @@ class IDHRNetwork(nn.Module):
         stream drain) and looked at when frame k + 1 starts: if it grew, every later frame of this renderer is prepared
         for the exact fp32 engine, with a warning (`split_nonfinite` holds the total; a caller that needs frame k itself
         exact re-renders it)."""
-        g = self._guard.get(dev)
+        key = (dev, id(ws))   # one record per scratch = per stream with a frame in flight: each has its own counter
+        g = self._guard.get(key)
         if g is not None and g["event"].query():
             now = int(g["host"].item())
             grew = now - g["seen"] if now >= g["seen"] else now      # the counters may have been reset in between
@@ -275,7 +295,9 @@ class IDHRNetwork(nn.Module):
                                   "use the exact fp32 engine (ARAH_PRECISION=fp32)" % grew)
                     self._precision = hip.PRECISION_FP32
         if g is None:
-            g = self._guard[dev] = {"host": torch.zeros(1, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(), "seen": 0}
+            if len(self._guard) >= 8:
+                self._guard.pop(next(iter(self._guard)))
+            g = self._guard[key] = {"host": torch.zeros(1, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(), "seen": 0}
         return g
 
     def _split_guard_arm(self, g, ws):
@@ -294,14 +316,15 @@ class IDHRNetwork(nn.Module):
         if N == 0:
             raise ValueError("No valid depth.")
         dev = ray_dirs.device
-        guard = self._split_guard(None, dev) if dev.type == "cuda" else None
+        ws = self.ray_tracer.workspace(dev)
+        guard = self._split_guard(ws, dev) if dev.type == "cuda" else None
         frame = build_frame(input["sdf_network"], self.skinning_model, self.rendering_network,
                             self.deviation_network, input["pose_cond"], input["smpl_verts"],
                             input["skinning_weights"], input["bone_transforms"], input["trans"],
-                            input["coord_min"], input["coord_max"], input["center"], precision=self._precision,
+                            input["coord_min"], input["coord_max"], input["center"],
+                            precision=self._precision if self._precision is not None else self.precision,
                             body_tables=input.get("_body_tables"))
         self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
-        ws = self.ray_tracer.workspace(dev)
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                       ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2),
@@ -428,7 +451,10 @@ class MetaAvatarRender(nn.Module):
                        "vol_feat": torch.empty(B, 0, device=dev), "sdf_network": out["decoder"]})
         if "latent_code_idx" in inputs["pose_cond"]:
             inputs["pose_cond"]["latent_code"] = self.latent(inputs["pose_cond"]["latent_code_idx"])
-        model_outputs = self.idhr_network(inputs)
+        try:
+            model_outputs = self.idhr_network(inputs)
+        finally:
+            inputs.pop("_body_tables", None)   # they belong to this call's vertices, not to the caller's dict
         model_outputs.update({"sdf_params": out["params"]})
         if gen_cano_mesh:   # models/__init__.py:203-311: canonical mesh + the three normal maps, all on the device
             from . import meshing

@@ -14,6 +14,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 
@@ -244,6 +245,11 @@ def main(argv=None, body=None, faces=None, log=print):
             opt.load_state_dict(ck["optimizer_states"][0])
         epoch0, step, ckpt_epoch = ck["epoch"], ck.get("global_step", 0), ck["epoch"]
     broadcast_state(lm.model, world, dist)
+    # From here on the global generators drive per-step draws only (eikonal probe points, stratified jitter, pose / view input
+    # noise): every rank and every resumed run gets its own stream, like the unseeded ranks of the reference.  (The common seed
+    # above only made construction repeatable; broadcast_state has made it redundant.)
+    torch.manual_seed(4321 + rank + 1000 * (ckpt_epoch or 0))
+    np.random.seed((4321 + rank + 1000 * (ckpt_epoch or 0)) % (2 ** 32))
     max_epochs = epochs_to_run(t_cfg["max_epochs"], args.epochs_per_run, ckpt_epoch)
     every = t_cfg.get("checkpoint_every_n_epochs", 1)
     params = [p for p in lm.model.parameters() if p.requires_grad]

@@ -247,9 +247,15 @@ class GpuRuntime:
         torch.cuda.synchronize()
 
     def set_events(self, full_shading, on):
-        setter = self.hip.set_shade_events if full_shading else self.hip.set_density_events
-        setter(self.ev0, self.ev1) if on else setter(None, None)
-        self.hip.set_canon_events(self.cv0, self.cv1) if on else self.hip.set_canon_events(None, None)
+        """HIP events around the dominant kernels, on the tracer's sampling objects (fields of the calls: the library keeps no
+        process-wide hooks since round 4)."""
+        which = "shade" if full_shading else "density"
+        self.tracer.set_events(which, self.ev0 if on else None, self.ev1 if on else None)
+        self.tracer.set_events("canon", self.cv0 if on else None, self.cv1 if on else None)
+
+    def set_precision(self, name):
+        """GEMM engine the following frames are prepared for: an attribute of this renderer, not the process environment."""
+        self.model.idhr_network.precision = {"split": self.hip.PRECISION_SPLIT_F16, "fp32": self.hip.PRECISION_FP32}[name]
 
     def event_ms(self):
         return self.ev0.elapsed_time(self.ev1)
@@ -358,7 +364,7 @@ def run(args, rt):
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
         # ARAH_FULL_SHADING=1 forces the shade-everything path in every pass (the profiler's full-shading PMC passes)
         tracer.full_shading = full_shading or os.environ.get("ARAH_FULL_SHADING") == "1"
-        os.environ["ARAH_PRECISION"] = precision
+        rt.set_precision(precision)
         n_streams = args.streams if n_streams is None else n_streams
         rt.render_many(warm_inputs, n_streams)
         sync()
@@ -378,7 +384,7 @@ def run(args, rt):
             ms.append(rt.event_ms())
             cms.append(rt.canon_ms())
         rt.set_events(full_shading, False)
-        os.environ["ARAH_PRECISION"] = default_engine
+        rt.set_precision(default_engine)
         canon_ms[(full_shading, precision)] = cms
         return dt, ctr, ms
 

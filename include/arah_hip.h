@@ -112,6 +112,10 @@ typedef struct ArahBody {
                                    frame, and order the stream that built it before the frame's stream) */
 } ArahBody;
 
+enum { ARAH_SHADE_ENGINE_DEFAULT = 0 /* bf16 x 3 on split frames */, ARAH_SHADE_ENGINE_FP32 = 1 };
+enum { ARAH_CANON_KERNEL_WAVE = 0 /* point-owning waves, hi fragments in LDS */, ARAH_CANON_KERNEL_TILE = 1,
+       ARAH_CANON_KERNEL_WAVE_L2 = 2 };
+
 typedef struct ArahSampling {
     int32_t n_steps, n_near, n_far;   /* configs/default.yaml:49-51 */
     int32_t cano_view_dirs;           /* model.cano_view_dirs */
@@ -124,6 +128,16 @@ typedef struct ArahSampling {
     const float* lin_steps;
     const float* lin_near;
     const float* lin_far;             /* may be NULL when n_far == 0 */
+    /* Per-call switches and profiling hooks (round 4: they were environment variables read into process-wide statics and
+     * process-wide event setters; the library now keeps no state between calls, so calls on different streams with different
+     * ArahSampling objects do not see each other). */
+    int32_t shade_engine;             /* ARAH_SHADE_ENGINE_*: loop D's normal sweep + colour MLP on a split-engine frame */
+    int32_t canon_kernel;             /* ARAH_CANON_KERNEL_*: loop C's solver on a split-engine frame */
+    /* pairs of hipEvent_t (start, stop), both non-NULL to take effect: recorded on the call's stream immediately before /
+     * after the launch of loop C's solver, of the density pre-pass and of the shading kernel */
+    void* ev_canon[2];
+    void* ev_density[2];
+    void* ev_shade[2];
 } ArahSampling;
 
 /* Opaque-ish handle filled by arah_prepare_frame: device pointers into the caller's frame
@@ -232,8 +246,8 @@ int arah_nearest_inverse_lbs(const ArahFrame* h_frame, const float* pts, int32_t
 /* Broyden on g(x) = LBS(x) - tgt from caller-supplied x0 [P,3], T0 [P,16];
  * J^-1_0 = (sum_j w_j(x0) A_j)[:3,:3]^-1.  -> x [P,3] raw canonical, T [P,16], err [P], conv [P] */
 int arah_broyden3_lbs(const ArahFrame* h_frame, const float* tgt, const float* x0, const float* T0,
-                      int32_t n_pts, float* x, float* T, float* err, uint8_t* conv, void* workspace,
-                      size_t workspace_bytes, void* stream);
+                      int32_t n_pts, float* x, float* T, float* err, uint8_t* conv, int32_t canon_kernel /* ARAH_CANON_KERNEL_* */,
+                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* joint root find on u = (x_hat, depth) from caller-supplied starts (search_iso_surface_depth, root_finding_utils.py:
  * 365-484): valid [N], x0 [N,3] raw canonical, z0 [N], T0 [N,16]  ->  x [N,3], z [N], T [N,16], conv [N].
@@ -355,13 +369,13 @@ int arah_shade_composite(const ArahFrame* h_frame, const ArahSampling* h_cfg, co
                          int32_t n_rays, float* rgb, float* acc, uint8_t* vol_mask, void* workspace,
                          size_t workspace_bytes, void* stream);
 /* Per-sample half of loop D as a seam of its own (IDR:291-368 before the compositing): the SHIPPED shading kernel -- on a
- * split-engine frame the bf16 x 3 normal sweep and colour MLP (ARAH_SHADE_ENGINE=fp32: the fp32 MFMA), on an fp32 frame the
+ * split-engine frame the bf16 x 3 normal sweep and colour MLP (shade_engine = ARAH_SHADE_ENGINE_FP32: the fp32 MFMA), on an fp32 frame the
  * exact engine -- on n normalised canonical points with their own blended transforms T [n,16] and ray directions dirs [n,3].
  * -> rgbs [n,4] = {rgb, VolSDF density}, sdfn [n,4] = {sdf (normalised units), d sdf / d x_norm}.  Needs a workspace of
  * arah_workspace_bytes(n, 1). */
 int arah_shade_points(const ArahFrame* h_frame, const float* x_norm, const float* T, const float* dirs, int32_t n_pts,
-                      int32_t cano_view_dirs, float* rgbs, float* sdfn, void* workspace, size_t workspace_bytes,
-                      void* stream);
+                      int32_t cano_view_dirs, int32_t shade_engine, float* rgbs, float* sdfn, void* workspace,
+                      size_t workspace_bytes, void* stream);
 /* whole eval forward.  pose34 = DEVICE [3][4] world->camera (R|t), read by the last kernel only (no host copy of
  * the pose, no stream drain).  Any of the optional outputs may be NULL, then they live in the workspace.
  * -> rgb [N,3], points_cam [N,3], vol_mask [N] */
@@ -373,15 +387,6 @@ int arah_render(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float
 
 /* name of the dominant kernel, for profilers */
 const char* arah_dominant_kernel(void);
-/* Profiling hook: when both are non-NULL hipEvent_t handles, every following arah_shade_composite /
- * arah_render records them on its stream immediately before / after the launch of the dominant
- * kernel (loop D's shading kernel).  Pass NULLs to switch it off.  Process-global, not thread safe. */
-int arah_set_shade_events(void* start_event, void* stop_event);
-/* same for the density pre-pass (k_density) of lazy shading */
-int arah_set_density_events(void* start_event, void* stop_event);
-/* same for loop C's resident solver (k_canon_solve), the largest launch of the default path */
-int arah_set_canon_events(void* start_event, void* stop_event);
-
 #ifdef __cplusplus
 }
 #endif

@@ -118,6 +118,9 @@ class _StubRuntime:
     def set_events(self, full_shading, on):
         pass
 
+    def set_precision(self, name):
+        pass
+
     def event_ms(self):
         return 1.0
 

@@ -57,9 +57,22 @@ def test_struct_sizes_match_header():
     assert C.sizeof(hip.ArahBody) == 8 * 7 + 8 + 8   # seven device pointers, n_verts (+ padding), prepared tables
     n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 2 + 8 + 6 + 22 + 4 + 3 + 1   # sdf, skin (+2: point-owning-wave operands), colour (+6 transposed, +22 bf16 x 3 operands), knn, body, scalars
     assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * 3 + 4   # three ints (+ padding)
-    assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3
+    assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6   # + two per-call switches, three event pairs
     assert C.sizeof(hip.ArahTrainIn) == 4 * 4 + 8 * (6 + 1 + 5 + 1)
     assert C.sizeof(hip.ArahCounters) == 72
+    # ... and what the C compiler makes of the header itself
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc"):
+        names = ["ArahNets", "ArahBody", "ArahFrame", "ArahSampling", "ArahTrainIn", "ArahCounters"]
+        prog = '#include <stdio.h>\n#include "arah_hip.h"\nint main(void) {' + "".join(
+            'printf("%%zu\\n", sizeof(%s));' % n for n in names) + "return 0;}\n"
+        with tempfile.TemporaryDirectory() as d:
+            open(os.path.join(d, "s.c"), "w").write(prog)
+            subprocess.run(["gcc", "-I", os.path.join(REPO, "include"), os.path.join(d, "s.c"), "-o", os.path.join(d, "s")], check=True)
+            sizes = [int(v) for v in subprocess.run([os.path.join(d, "s")], check=True, capture_output=True, text=True).stdout.split()]
+        assert sizes == [C.sizeof(getattr(hip, n)) for n in names], list(zip(names, sizes))
 
 
 @pytest.mark.parametrize("name", ["gemm_f16x3", "trunk_repro", "gemm_loop", "mfma_f32_peak", "mfma_valu_overlap"])

@@ -41,10 +41,10 @@ if density:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     ts = []
     for it in range(6):
-        hip.set_density_events(e0, e1)
+        samp.set_events("density", e0, e1)
         hip.shade_composite(frame, ws, samp, dirs, z, pts, Tm, mask)
         torch.cuda.synchronize()
-        hip.set_density_events(None, None)
+        samp.set_events("density", None, None)
         if it:
             ts.append(e0.elapsed_time(e1))
     ms = sorted(ts)[len(ts) // 2]
