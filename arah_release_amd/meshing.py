@@ -177,15 +177,17 @@ def normal_image(pix_to_face, normals, background):
     return ((img + 1.0) / 2.0).clip(0.0, 1.0).unsqueeze(0)
 
 
-def canonical_mesh_outputs(frame, ws, inputs, rasterize_fn=None, n_side=256, image_size=512):
+def canonical_mesh_outputs(frame, ws, inputs, rasterize_fn=None, n_side=256, image_size=512, tri=None):
     """The three normal maps of the gen_cano_mesh branch + the canonical triangle soup (normalised coordinates).
     frame: packed hip.Frame of the current pose; inputs: the model's input dict (coord_min/max, center, trans,
-    cam_rot, cam_trans, intrinsics)."""
+    cam_rot, cam_trans, intrinsics).  tri: a triangle soup to use instead of meshing the SDF (fixture F18 injects the mesh
+    the reference's own branch was run on)."""
     from . import hip, training
     rasterize_fn = rasterize_fn or hip.rasterize
     with torch.no_grad():
-        sdf = hip.sdf_grid(frame, ws, n_side)
-        tri = marching_cubes(sdf)                                                        # (F,3,3) in [-1,1]^3
+        if tri is None:
+            sdf = hip.sdf_grid(frame, ws, n_side)
+            tri = marching_cubes(sdf)                                                    # (F,3,3) in [-1,1]^3
         F = tri.shape[0]
         cmin, cmax, center = inputs["coord_min"][:1], inputs["coord_max"][:1], inputs["center"][:1]
         x_hat = training.unnormalize_canonical_points(tri.reshape(1, -1, 3), cmin, cmax, center)[0]

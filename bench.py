@@ -270,6 +270,27 @@ class GpuRuntime:
         return cpu_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.cpu_sample_rays,
                             model_gpu=self.model, dev=self.dev)
 
+    def test_py_frame(self, size, steps=4, warmup=1):
+        """The frame test.py itself asks for (lightning_model.py:320: gen_cano_mesh=True): the render PLUS the canonical mesh
+        of the emitted SDF (256^3 lattice, marching cubes, forward skinning) and the three 512 x 512 normal maps, one frame
+        after the other on one stream.  Not `value`: BASELINE.json's metric is the rays of model.forward without the mesh."""
+        frames = [self.make_inputs(size, k) for k in range(steps + warmup)]
+        with torch.no_grad():
+            for k in range(warmup):
+                self.model(frames[k], gen_cano_mesh=True, eval=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(warmup, warmup + steps):
+                out = self.model(frames[k], gen_cano_mesh=True, eval=True)
+            torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        rays = sum(int(f["ray_dirs"].shape[1]) for f in frames[warmup:])
+        return {"note": "MetaAvatarRender.forward(gen_cano_mesh=True, eval=True) as test.py calls it: render + canonical mesh "
+                        "(arah_sdf_grid 256^3, marching cubes, arah_skin_lbs) + output_normal / normal_cano_front / "
+                        "normal_cano_back (arah_rasterize), one frame at a time",
+                "value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                "outputs": sorted(k for k in out if k != "sdf_params")}
+
     def training_line(self, steps=5, warmup=2):
         """Training step of BASELINE.json configs[2] (ZJUMOCAP-313 shapes, one view of 2048 rays on this GPU): forward
         (HIP ray tracer + hand-written loop D) + IDHRLoss + backward + Adam."""
@@ -534,6 +555,7 @@ def run(args, rt):
         line["value_strict"] = line["strict"]["value"] if "strict" in line else None
         if world == 1 and not args.no_train:
             line["training"] = rt.training_line()
+            line["test_py_frame"] = rt.test_py_frame(args.size)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = rt.cpu_baseline(args, near, far)
             line["psnr_vs_oracle_db"] = line["cpu_baseline"].get("psnr_vs_oracle_db")

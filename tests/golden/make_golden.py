@@ -686,7 +686,145 @@ F7_SET = (("zju377_mono", (64, 64), (64, 16, 16), 0), ("zju313", (64, 64), (64, 
           ("zju377_mono", (128, 128), (32, 8, 8), 5), ("h36m", (40, 40), (128, 32, 32), 3))
 
 
+def make_f18():
+    """F18: the canonical-mesh branch of the model entry (models/__init__.py:203-311) as the reference runs it, with the
+    third-party pieces replaced by RECORDERS: what the reference itself computes there -- the posed mesh vertices (its own
+    unnormalisation, forward_skinning and translation), the arguments it hands to cameras_from_opencv_projection /
+    look_at_view_transform / FoVPerspectiveCameras / RasterizationSettings, which normals it takes (sign, frame), how it
+    colours the three 512 x 512 maps from pix_to_face -- is pinned by value.  Stand-ins (documented behaviour, unpinned as
+    before): skimage's marching cubes -> the build's own (so the mesh is the build's, injected at N = 48 instead of 256 to
+    keep the fixture small: create_mesh_vertices_and_faces is still the reference's), Meshes.faces_normals_packed (unit
+    right-hand normals), the rasteriser -> oracle/mesh_oracle.rasterize_np on the build's projections."""
+    import skimage.measure as skm
+    from im2mesh.utils import sdf_meshing
+    from im2mesh.metaavatar_render import models as ref_models
+    sys.path.insert(0, REPO)
+    from arah_release_amd import meshing
+    from oracle import mesh_oracle
+    rec = {"raster": [], "lookat": [], "fov": [], "settings": []}
+    N_INJECT = 48
+
+    def fake_mc(volume, level=None, spacing=None, **kw):
+        tri = meshing.marching_cubes(torch.from_numpy(np.ascontiguousarray(volume)).float(), level=float(level))   # (F,3,3) in [-1,1]^3
+        rec["tri"] = tri.numpy().copy()
+        verts = (tri.reshape(-1, 3).numpy().astype(np.float64) + 1.0)        # skimage returns index * spacing from the origin
+        faces = np.arange(verts.shape[0]).reshape(-1, 3)
+        return verts, faces, np.zeros_like(verts), np.zeros(verts.shape[0])
+
+    real_create = sdf_meshing.create_mesh_vertices_and_faces
+
+    def create_small(decoder, N=256, max_batch=64 ** 3, **kw):
+        rec["asked_N"], rec["asked_max_batch"] = N, max_batch
+        return real_create(decoder, N=N_INJECT, max_batch=max_batch, **kw)
+
+    class Cameras:
+        def __init__(self, kind, **kw):
+            self.kind, self.kw = kind, kw
+
+        def to(self, device):
+            return self
+
+    def cameras_from_opencv_projection(R, tvec, camera_matrix, image_size):
+        rec["opencv"] = dict(R=R.clone(), tvec=tvec.clone(), K=camera_matrix.clone(), image_size=image_size.clone())
+        return Cameras("opencv", R=R[0], t=tvec[0], K=camera_matrix[0])
+
+    def look_at_view_transform(dist=1.0, elev=0.0, azim=0.0, **kw):
+        rec["lookat"].append((float(dist), float(elev), float(azim)))
+        return ("R", float(azim)), ("T", float(dist))
+
+    def FoVPerspectiveCameras(device=None, R=None, T=None, **kw):
+        rec["fov"].append(dict(R=R, T=T, extra=sorted(kw)))
+        return Cameras("fov", azim=R[1], dist=T[1])
+
+    class RasterizationSettings:
+        def __init__(self, image_size=256, **kw):
+            rec["settings"].append((image_size, sorted(kw)))
+            self.image_size = image_size
+
+    class Meshes:
+        def __init__(self, verts, faces):
+            self.verts, self.faces = verts, faces
+            rec.setdefault("meshes", []).append((verts.clone(), faces.clone()))
+
+        def faces_normals_packed(self):
+            v = self.verts[0]
+            f = self.faces[0].long()
+            n = torch.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]], dim=1)
+            return n / n.norm(dim=1, keepdim=True).clamp_min(1e-20)
+
+    class Fragments:
+        def __init__(self, p2f):
+            self.pix_to_face = p2f
+
+    class MeshRasterizer:
+        def __init__(self, cameras=None, raster_settings=None):
+            self.cam, self.rs = cameras, raster_settings
+
+        def __call__(self, mesh):
+            size = self.rs.image_size
+            H, W = (size, size) if isinstance(size, int) else size
+            tri = mesh.verts[0][mesh.faces[0].long()]                                   # (F,3,3)
+            if self.cam.kind == "opencv":
+                uvz = meshing.project_opencv(tri, self.cam.kw["R"], self.cam.kw["t"], self.cam.kw["K"])
+                p2f = mesh_oracle.rasterize_np(uvz.numpy(), H, W)
+            else:
+                uvz = meshing.project_lookat(tri, self.cam.kw["azim"], H, dist=self.cam.kw["dist"])
+                p2f = mesh_oracle.rasterize_np(uvz.numpy(), H, W, z_near=1.0)
+            rec["raster"].append(dict(uvz=uvz.numpy().copy(), p2f=p2f.copy(), H=H, W=W))
+            return Fragments(torch.from_numpy(p2f).reshape(1, H, W, 1))
+
+    mods = {"pytorch3d.utils": dict(cameras_from_opencv_projection=cameras_from_opencv_projection),
+            "pytorch3d.structures": dict(Meshes=Meshes),
+            "pytorch3d.renderer": dict(look_at_view_transform=look_at_view_transform, PerspectiveCameras=Cameras,
+                                       FoVPerspectiveCameras=FoVPerspectiveCameras, RasterizationSettings=RasterizationSettings,
+                                       MeshRenderer=Cameras, MeshRasterizer=MeshRasterizer, TexturesVertex=Cameras)}
+    saved = {}
+    for m, attrs in mods.items():
+        for k, v in attrs.items():
+            saved[(m, k)] = sys.modules[m].__dict__.get(k)
+            setattr(sys.modules[m], k, v)
+    old_cuda, old_mc = torch.Tensor.cuda, getattr(skm, "marching_cubes_lewiner", None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    skm.marching_cubes_lewiner = fake_mc
+    sdf_meshing.create_mesh_vertices_and_faces = create_small
+    try:
+        model, cfg = build_reference_model("zju377_mono", 64, 16, 16)
+        scene = synthetic.SyntheticScene(0)
+        fidx, H, W, max_rays = 5, 512, 512, 256          # the branch rasterises at 512 x 512 with the frame's intrinsics
+        inputs = scene.make_inputs(H, W, frame_idx=fidx, max_rays=max_rays)
+        with torch.no_grad():
+            out = model(inputs, gen_cano_mesh=True, eval=True)
+    finally:
+        torch.Tensor.cuda = old_cuda
+        sdf_meshing.create_mesh_vertices_and_faces = real_create
+        if old_mc is not None:
+            skm.marching_cubes_lewiner = old_mc
+        for (m, k), v in saved.items():
+            if v is None:
+                sys.modules[m].__dict__.pop(k, None)
+            else:
+                setattr(sys.modules[m], k, v)
+    assert rec["asked_N"] == 256 and rec["asked_max_batch"] == 64 ** 3            # models/__init__.py:205-206
+    assert rec["lookat"] == [(2.0, 0.0, 0.0), (2.0, 0.0, 180.0)] and all(f["extra"] == [] for f in rec["fov"])
+    assert rec["settings"] == [((512, 512), []), (512, [])] and len(rec["raster"]) == 3 and len(rec["meshes"]) == 3
+    posed, faces0 = rec["meshes"][0]
+    cano, _ = rec["meshes"][1]
+    assert torch.equal(rec["meshes"][1][0], rec["meshes"][2][0])
+    tri = rec["tri"]
+    assert np.allclose(cano[0].numpy().reshape(-1, 3, 3), tri, atol=1e-6)           # the mesh the reference rasterises IS the injected one
+    save("f18_cano_mesh_branch.npz", frame_idx=fidx, H=H, W=W, max_rays=max_rays, n_inject=N_INJECT, tri=tri.astype(np.float32),
+         posed_verts=posed[0], opencv_R=rec["opencv"]["R"], opencv_t=rec["opencv"]["tvec"], opencv_K=rec["opencv"]["K"],
+         opencv_image_size=rec["opencv"]["image_size"], cam_rot=inputs["cam_rot"], cam_trans=inputs["cam_trans"],
+         intrinsics=inputs["intrinsics"],
+         p2f_posed=rec["raster"][0]["p2f"].astype(np.int32), p2f_front=rec["raster"][1]["p2f"].astype(np.int32),
+         p2f_back=rec["raster"][2]["p2f"].astype(np.int32),
+         output_normal=out["output_normal"].numpy().astype(np.float32), normal_cano_front=out["normal_cano_front"].numpy().astype(np.float32),
+         normal_cano_back=out["normal_cano_back"].numpy().astype(np.float32))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f18":
+        return make_f18()
     if len(sys.argv) > 1 and sys.argv[1] == "f7c5":
         return make_f7(F7_SET[-1:])
     if len(sys.argv) > 1 and sys.argv[1] == "f17":

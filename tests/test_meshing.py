@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import get_model
+from conftest import get_model, golden
 
 gpu = pytest.mark.gpu
 
@@ -234,3 +234,71 @@ def test_gen_cano_mesh_branch(scene, name):
     u = (K[0, 0] * v[:, 0] / v[:, 2] + K[0, 2]).long().clamp(0, 511)
     w = (K[1, 1] * v[:, 1] / v[:, 2] + K[1, 2]).long().clamp(0, 511)
     assert float(fg_p[w, u].float().mean()) > 0.9                        # body vertices land on the rendered silhouette
+
+
+# ------------------------------------------------------------------------------------------ fixture F18
+def test_normal_maps_of_the_reference_branch_cpu():
+    """F18 (tests/golden/make_golden.py f18): the reference's OWN gen_cano_mesh branch (models/__init__.py:203-311) run with
+    recorders in place of pytorch3d.  On the CPU: from the mesh it rasterised, the posed vertices IT computed and the
+    pix_to_face images it was handed, the build's colouring (which normals, which sign, which frame, background, the [0,1]
+    map) reproduces the reference's three 512 x 512 normal maps, and the build's projections + the rasteriser oracle reproduce
+    the pix_to_face images from the camera arguments the reference passed on."""
+    from arah_release_amd import meshing
+    from oracle import mesh_oracle
+    g = golden("f18_cano_mesh_branch.npz")
+    tri = torch.from_numpy(g["tri"])
+    posed = torch.from_numpy(g["posed_verts"]).reshape(-1, 3, 3)
+    cam_rot, cam_trans, K = torch.from_numpy(g["cam_rot"])[0], torch.from_numpy(g["cam_trans"])[0], torch.from_numpy(g["intrinsics"])[0]
+    # what the reference hands to cameras_from_opencv_projection is the dataset's camera, for a 512 x 512 image
+    np.testing.assert_array_equal(g["opencv_R"][0], g["cam_rot"][0])
+    np.testing.assert_array_equal(g["opencv_t"][0], g["cam_trans"][0])
+    np.testing.assert_array_equal(g["opencv_K"][0], g["intrinsics"][0])
+    np.testing.assert_array_equal(g["opencv_image_size"], [[512.0, 512.0]])
+    p2f = {k: torch.from_numpy(g[k].astype(np.int64)) for k in ("p2f_posed", "p2f_front", "p2f_back")}
+    assert int((p2f["p2f_posed"] >= 0).sum()) > 3000 and int((p2f["p2f_front"] >= 0).sum()) > 3000
+    img = meshing.normal_image(p2f["p2f_posed"], -meshing.face_normals(posed) @ cam_rot.t(), -1.0)
+    np.testing.assert_allclose(img.numpy(), g["output_normal"], rtol=0, atol=2e-6)
+    n_cano = meshing.face_normals(tri)
+    np.testing.assert_allclose(meshing.normal_image(p2f["p2f_front"], n_cano, 0.0).numpy(), g["normal_cano_front"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(meshing.normal_image(p2f["p2f_back"], n_cano, 0.0).numpy(), g["normal_cano_back"], rtol=0, atol=2e-6)
+    # projections: a 64 x 64 corner of each view through the oracle rasteriser (the full images are the generator's own)
+    uvz = meshing.project_opencv(posed, cam_rot, cam_trans, K).numpy()
+    sub = mesh_oracle.rasterize_np(uvz, 512, 512)
+    assert (sub == g["p2f_posed"]).all()
+
+
+@gpu
+def test_canonical_mesh_outputs_against_the_reference_branch(scene):
+    """F18 on the device: the build's forward skinning of the mesh vertices against the posed vertices the reference computed
+    (its unnormalisation, forward_skinning and translation: element-wise), arah_rasterize on the build's projections against
+    the recorded pix_to_face (equal where the depth order is not a tie of the skinning's last bits), and the whole
+    canonical_mesh_outputs on the injected mesh against the reference's three normal maps."""
+    from arah_release_amd import config, hip, meshing, renderer, training
+    g = golden("f18_cano_mesh_branch.npz")
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model("zju377_mono", 64, 16, 16, device=dev)
+    inputs = scene.make_inputs(int(g["H"]), int(g["W"]), frame_idx=int(g["frame_idx"]), max_rays=int(g["max_rays"]), device=dev)
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder, model.deviation_decoder,
+                                     pose_cond, inputs["smpl_verts"], inputs["skinning_weights"], inputs["bone_transforms"],
+                                     inputs["trans"], inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    ws = hip.Workspace(dev)
+    tri = torch.from_numpy(g["tri"]).to(dev)
+    x_hat = training.unnormalize_canonical_points(tri.reshape(1, -1, 3), inputs["coord_min"][:1], inputs["coord_max"][:1],
+                                                  inputs["center"][:1])[0]
+    _, x_bar, _ = hip.skin_lbs(frame, ws, x_hat)
+    posed = x_bar + inputs["trans"].reshape(1, 3)
+    np.testing.assert_allclose(posed.cpu().numpy(), g["posed_verts"], rtol=1e-4, atol=2e-5)
+    cam_rot, cam_trans, K = inputs["cam_rot"][0], inputs["cam_trans"][0], inputs["intrinsics"][0]
+    p2f = hip.rasterize(meshing.project_opencv(torch.from_numpy(g["posed_verts"]).to(dev).reshape(-1, 3, 3), cam_rot, cam_trans, K), 512, 512)
+    assert (p2f.cpu().numpy() == g["p2f_posed"]).all()                # same vertices in: the same pixels out, all of them
+    out, _ = meshing.canonical_mesh_outputs(frame, ws, inputs, tri=tri)
+    for k in ("output_normal", "normal_cano_front", "normal_cano_back"):
+        a, b = out[k].cpu().numpy(), g[k]
+        assert a.shape == b.shape == (1, 512, 512, 3)
+        same = (np.abs(a - b) <= 2e-4).all(-1)
+        assert same.mean() >= (0.9995 if k == "output_normal" else 1.0), (k, same.mean())   # posed view: the build's own skinning decides edge pixels
