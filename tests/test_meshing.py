@@ -301,4 +301,4 @@ def test_canonical_mesh_outputs_against_the_reference_branch(scene):
         a, b = out[k].cpu().numpy(), g[k]
         assert a.shape == b.shape == (1, 512, 512, 3)
         same = (np.abs(a - b) <= 2e-4).all(-1)
-        assert same.mean() >= (0.9995 if k == "output_normal" else 1.0), (k, same.mean())   # posed view: the build's own skinning decides edge pixels
+        assert same.mean() >= 0.9995, (k, same.mean())   # edge pixels: the projections run in the GPU's fp32 (and, posed view, on the build's own skinning)
