@@ -2381,18 +2381,20 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
                 e[8] = vz;
                 k = 9;
                 float f = 1.0f;
-                for (int o = 0; o < 4; ++o) {
-                    e[k + 0] = sinf(vx * f);
-                    e[k + 1] = sinf(vy * f);
-                    e[k + 2] = sinf(vz * f);
-                    e[k + 3] = cosf(vx * f);
-                    e[k + 4] = cosf(vy * f);
-                    e[k + 5] = cosf(vz * f);
-                    k += 6;
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {   // unrolled: e is a register array in the B3 instances, indexed by constants only
+                    e[9 + 6 * o + 0] = sinf(vx * f);
+                    e[9 + 6 * o + 1] = sinf(vy * f);
+                    e[9 + 6 * o + 2] = sinf(vz * f);
+                    e[9 + 6 * o + 3] = cosf(vx * f);
+                    e[9 + 6 * o + 4] = cosf(vy * f);
+                    e[9 + 6 * o + 5] = cosf(vz * f);
                     f *= 2.0f;
                 }
+                k = 33;
             }
-            for (; k < D::kInPad - 256; ++k) e[k] = 0.f;
+#pragma unroll
+            for (int kk = IDR ? 33 : 6; kk < D::kInPad - 256; ++kk) e[kk] = 0.f;
             if constexpr (B3) {
                 constexpr int n_extra = ((D::kInPad + 31) / 32) * 32 - 256;   // up to the end of the last 32-chunk
 #pragma unroll
