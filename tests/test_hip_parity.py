@@ -427,6 +427,26 @@ def test_broyden3(ctx):
 
 
 @gpu
+def test_broyden3_kernels_of_the_call(ctx):
+    """The solver is chosen per CALL (the canon_kernel argument / ArahSampling.canon_kernel; round 3 read an environment
+    variable into a process-wide static): the point-owning-wave kernel with its hi fragments in LDS (default), the same with
+    every fragment from L2, and round 2's tile kernel find the same roots of F1 -- the two wave kernels bit for bit (the same
+    arithmetic on operands delivered differently), the tile kernel within the known-answer tolerances."""
+    g = golden("f1_broyden3.npz")
+    hip = ctx["hip"]
+    args = (ctx["frame"], ctx["ws"], T(g["tgt"]), T(g["x0"]), T(g["T0"]))
+    xw, Tw, ew, okw = hip.broyden3_lbs(*args, canon_kernel=hip.CANON_KERNEL_WAVE)
+    xl, Tl, el, okl = hip.broyden3_lbs(*args, canon_kernel=hip.CANON_KERNEL_WAVE_L2)
+    xt, Tt, et, okt = hip.broyden3_lbs(*args, canon_kernel=hip.CANON_KERNEL_TILE)
+    assert torch.equal(xw, xl) and torch.equal(Tw, Tl) and torch.equal(okw, okl)
+    valid = g["valid"]
+    for x, ok in ((xw, okw), (xt, okt)):
+        ok = ok.cpu().numpy()
+        assert (ok == valid).mean() >= 0.995
+        assert_rows_close(x.cpu().numpy()[ok & valid], g["result"][ok & valid], atol=2e-5, frac=0.99)
+
+
+@gpu
 @pytest.mark.parametrize("eng", ENGINES)
 def test_joint_root_find(ctx, ctx_fp32, eng):
     """Loop B through its own seam (arah_joint_root_find) against the reference's search_iso_surface_depth
