@@ -50,7 +50,7 @@ struct FrameDev {
     KnnPtrs knn;
     const float* verts4;
     const float* verts_raw;   // caller's [n_verts][3]
-    const float* vert_weights;
+    const float* vert_T;      // [n_verts][16] blended bone transform of each vertex (k_vertex_transforms)
     const float* bones;
     const float* scal;   // [9] device: trans(3), center(3), coord_min, coord_max, |variance| -- the host never sees them
     int n_verts;
@@ -114,7 +114,7 @@ FrameDev to_dev(const ArahFrame& f) {
     d.knn.spheres = f.knn_spheres;
     d.knn.grid = f.knn_grid;
     d.knn.cells = reinterpret_cast<const unsigned char*>(f.knn_cells);
-    d.vert_weights = f.vert_weights;
+    d.vert_T = f.vert_T;
     d.bones = f.bones;
     d.scal = f.scalars;
     d.n_verts = f.n_verts;
@@ -353,6 +353,22 @@ __global__ void k_gather_scalars(float* __restrict__ dst, const float* trans, co
     else if (i == 6) dst[i] = cmin[0];
     else if (i == 7) dst[i] = cmax[0];
     else if (i == 8) dst[i] = beta ? beta[0] : 1e-3f;
+}
+
+// vert_T[v] = sum_j w_vj A_j, once per frame: every nearest-vertex query (loops A, B and the seeds of loop C) used to blend
+// the 24 bone transforms of its vertex again -- 6890 blends instead of ~1e7
+__global__ __launch_bounds__(64) void k_vertex_transforms(const float* __restrict__ weights, const float* __restrict__ bones,
+                                                          int n_verts, float* __restrict__ vert_T) {
+    __shared__ __attribute__((aligned(16))) float sb[24 * 16];
+    for (int i = threadIdx.x; i < 24 * 16; i += 64) sb[i] = bones[i];
+    __syncthreads();
+    const int v = blockIdx.x * 64 + threadIdx.x;
+    if (v >= n_verts) return;
+    float T[16];
+    blend(weights + (size_t)v * 24, sb, T);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        reinterpret_cast<f32x4*>(vert_T + (size_t)v * 16)[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
 }
 
 // dst[r][0..3] = {src[r][0..ncol-1], 0...}
@@ -728,12 +744,25 @@ __device__ __forceinline__ bool sphere_may_hold_nn(const f32x4 s, V3 p, float be
 // SRC_POINTS : id = i, p = pts[i]                 -> x raw canonical
 // SRC_RAYS   : id = list[i] (ray), p = o + t[ray] d -> x NORMALISED (sphere tracing evaluates the SDF there)
 // SRC_SAMPLES: id = list[i] (q = ray*S + s), p = o + z[q] d -> x raw canonical
-// blend the nearest vertex's weights, invert, write the outputs of one query
+// T of the nearest vertex, blended once per frame by k_vertex_transforms (same blend(), same bits)
+__device__ __forceinline__ void vertex_transform(const FrameDev& fr, int bi, float (&T)[16]) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(fr.vert_T + (size_t)bi * 16);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 v = q[c];
+        T[c * 4 + 0] = v[0];
+        T[c * 4 + 1] = v[1];
+        T[c * 4 + 2] = v[2];
+        T[c * 4 + 3] = v[3];
+    }
+}
+
+// the nearest vertex's transform, inverted; write the outputs of one query
 template <int SRC>
-__device__ __forceinline__ void nearest_finish(const FrameDev& fr, const BodyConst& bc, const float* sb, int i, int id, V3 p, int bi,
+__device__ __forceinline__ void nearest_finish(const FrameDev& fr, const BodyConst& bc, int i, int id, V3 p, int bi,
                                                int* idx_out, float* x_out, float* T_out, int as_seed) {
     float T[16];
-    blend(fr.vert_weights + (size_t)bi * 24, sb, T);
+    vertex_transform(fr, bi, T);
     V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
     V3 xh = inverse_affine_apply(T, y);
     if (SRC == SRC_RAYS) xh = normalize_pt(bc, xh);
@@ -751,11 +780,11 @@ __device__ __forceinline__ void nearest_finish(const FrameDev& fr, const BodyCon
         reinterpret_cast<f32x4*>(T_out + (size_t)id * 16)[c] = f32x4{T[c * 4], T[c * 4 + 1], T[c * 4 + 2], T[c * 4 + 3]};
 }
 
-// one query; sv / ssph / sb point either into LDS (STRIDE = kClusterLds) or straight at the frame buffer in
+// one query; sv / ssph point either into LDS (STRIDE = kClusterLds) or straight at the frame buffer in
 // global memory (STRIDE = kClusterSize), see k_nearest_invlbs
 template <int SRC, int STRIDE>
 __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const BodyConst& bc, const KnnData& kd, const GridInfo& g,
-                                                     const float* sv, const float* ssph, const float* sb, int i, int id,
+                                                     const float* sv, const float* ssph, int i, int id,
                                                      V3 p, int* idx_out, float* x_out, float* T_out, int as_seed) {
     float best = 3.4e38f;
     int bi = 0x7fffffff;
@@ -816,7 +845,7 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const B
             if (sphere_may_hold_nn(reinterpret_cast<const f32x4*>(ssph)[c], p, fminf(best, cap)))
                 scan_cluster<STRIDE>(sv, c, p, best, bi);
     }
-    nearest_finish<SRC>(fr, bc, sb, i, id, p, bi, idx_out, x_out, T_out, as_seed);
+    nearest_finish<SRC>(fr, bc, i, id, p, bi, idx_out, x_out, T_out, as_seed);
 }
 
 // (d2, index) minimum over the wave, lowest index on ties
@@ -1034,25 +1063,17 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_wave(FrameDev fr, K
             }
         }
         bi = nearest_vertex_wave(kd, g, p, best, bi, lane);
-        if (lane == 0) nearest_finish<SRC>(fr, bc, fr.bones, i, id, p, bi, idx_out, x_out, T_out, as_seed);
+        if (lane == 0) nearest_finish<SRC>(fr, bc, i, id, p, bi, idx_out, x_out, T_out, as_seed);
     }
 }
 
-// nearest_finish over a group of sixteen lanes: lane e accumulates entry e of T over the 24 bones in the serial order of
-// blend(); the entries then meet in every lane and lane 0 finishes the query
+// nearest_finish over a group of sixteen lanes: lane e loads entry e of the vertex's transform (64 contiguous bytes per
+// group); the entries then meet in every lane and lane 0 finishes the query
 template <int SRC>
-__device__ __forceinline__ void nearest_finish_group16(const FrameDev& fr, const BodyConst& bc, const float* sb, int id, V3 p, int bi,
+__device__ __forceinline__ void nearest_finish_group16(const FrameDev& fr, const BodyConst& bc, int id, V3 p, int bi,
                                                        int lane, int* idx_out, float* x_out, float* T_out, int as_seed) {
     const int sub = lane & 15;
-    float te = 0.f;
-    {
-        const float* w = fr.vert_weights + (size_t)bi * 24;
-        f32x4 wq[6];
-#pragma unroll
-        for (int q = 0; q < 6; ++q) wq[q] = reinterpret_cast<const f32x4*>(w)[q];
-#pragma unroll
-        for (int jn = 0; jn < 24; ++jn) te += wq[jn >> 2][jn & 3] * sb[jn * 16 + sub];
-    }
+    float te = fr.vert_T[(size_t)bi * 16 + sub];
     float T[16];
 #pragma unroll
     for (int e = 0; e < 16; ++e) T[e] = __shfl(te, (lane & 48) + e);
@@ -1099,7 +1120,7 @@ __global__ __launch_bounds__(kKnnWaveThreads) void k_nearest_group(FrameDev fr, 
             }
         }
         bi = nearest_vertex_group16<kClusterSize>(kd, kd.sorted4, kd.spheres, g, p, best, bi, lane);
-        nearest_finish_group16<SRC>(fr, bc, fr.bones, id, p, bi, lane, idx_out, x_out, T_out, as_seed);
+        nearest_finish_group16<SRC>(fr, bc, id, p, bi, lane, idx_out, x_out, T_out, as_seed);
     }
 }
 
@@ -1120,13 +1141,11 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
     if (blockIdx.x == 0 && threadIdx.x == 0) count_add(ctr, n);
     float* sv = smem;                              // [kMaxClusters][29][4] clustered vertices, one pad slot per cluster
     float* ssph = sv + (size_t)kMaxClusters * kClusterLds * 4;   // [kMaxClusters][4]
-    float* sb = ssph + kMaxClusters * 4;           // [24][16]
     for (int i = threadIdx.x; i < kMaxClusters * kClusterSize; i += blockDim.x)
         reinterpret_cast<f32x4*>(sv)[(i / kClusterSize) * kClusterLds + (i % kClusterSize)] =
             reinterpret_cast<const f32x4*>(kd.sorted4)[i];
     for (int i = threadIdx.x; i < kMaxClusters; i += blockDim.x)
         reinterpret_cast<f32x4*>(ssph)[i] = reinterpret_cast<const f32x4*>(kd.spheres)[i];
-    for (int i = threadIdx.x; i < 24 * 16; i += blockDim.x) sb[i] = fr.bones[i];
     __syncthreads();
     // Sample lists are ray-major (64 consecutive entries ~ one ray from near to far).  Within a block of 512 entries a
     // wave takes 8 runs of 8 consecutive entries, 64 apart: 8 neighbouring rays x 8 neighbouring depths instead of one
@@ -1137,7 +1156,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         for (int i = blockIdx.x * per + t; i < end; i += blockDim.x) {
             int id;
             const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
-            nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, as_seed);
+            nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, i, id, p, idx_out, x_out, T_out, as_seed);
         }
         return;
     }
@@ -1149,7 +1168,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         if (i >= n) continue;
         int id;
         const V3 p = knn_point_of<SRC>(pts, rs, depth, n_steps, list, i, id);
-        nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, sb, i, id, p, idx_out, x_out, T_out, as_seed);
+        nearest_invlbs_point<SRC, kClusterLds>(fr, bc, kd, g, sv, ssph, i, id, p, idx_out, x_out, T_out, as_seed);
     }
 }
 
@@ -2671,7 +2690,7 @@ constexpr size_t kLdsSdfGrad = kLdsSdfFwd + (size_t)64 * kSdfLd * 4;
 constexpr size_t kLdsDensityWide = (128 * 4 * 2 + 128) * 4 + (size_t)128 * kSdfLd * 4;
 constexpr size_t kLdsSkin = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSkinLd * 4;
 constexpr size_t kLdsJoint = (64 * 4 * 3 + 24 * 16 + 64 + 64 * kLogitLd + 32) * 4 + (size_t)64 * kSdfLd * 4;
-constexpr size_t kLdsKnn = ((size_t)kMaxClusters * kClusterLds * 4 + kMaxClusters * 4 + 24 * 16) * 4;
+constexpr size_t kLdsKnn = ((size_t)kMaxClusters * kClusterLds * 4 + kMaxClusters * 4) * 4;
 template <bool IDR>
 constexpr size_t lds_shade() {
     return (64 * 4 * 3 + 64) * 4 + (size_t)64 * ColDims<IDR>::kLdA * 4 + (size_t)64 * kSdfLd * 4;
@@ -3036,7 +3055,7 @@ struct FrameLayout {
     size_t col_w0p, col_w1p, col_w2p, col_w3ap, col_w3bp, col_w4p, col_w5, col_bias;
     size_t col_w0pT, col_w1pT, col_w2pT, col_w3apT, col_w3bpT, col_w4pT;   // transposed packings (training backward)
     size_t b3[kB3Count];   // bf16 hi/lo fragments of 22 of the packed matrices (training: gemm_acc_b3), order of B3Src
-    size_t verts4, knn_spheres, knn_grid, knn_cells, scalars;
+    size_t verts4, knn_spheres, knn_grid, knn_cells, scalars, vert_T;
     size_t bytes;
 };
 
@@ -3092,6 +3111,7 @@ FrameLayout frame_layout(int col_mode) {
         L.b3[i] = take((size_t)e.m_tiles * ((e.kc16 + 1) / 2) * 512);
     }
     L.verts4 = take((size_t)kMaxClusters * kClusterSize * 4);
+    L.vert_T = take((size_t)kMaxVerts * 16);
     L.knn_spheres = take((size_t)kMaxClusters * 4);
     L.knn_grid = take(sizeof(GridInfo) / 4);
     L.knn_cells = take((size_t)kMaxCells * kCellBytes / 4);
@@ -3380,6 +3400,8 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
         bt.cells = reinterpret_cast<unsigned char*>(base + L.knn_cells);
         launch_body_tables(body->verts, body->n_verts, bt, s);
     }
+    hipLaunchKernelGGL(k_vertex_transforms, dim3((body->n_verts + 63) / 64), dim3(64), 0, s, body->vert_weights, body->bones,
+                       body->n_verts, P(L.vert_T));
     memset(out, 0, sizeof(*out));
     out->sdf_w0 = P(L.sdf_w0);
     for (int i = 0; i < 5; ++i) {
@@ -3423,7 +3445,7 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     out->knn_grid = bt.grid;
     out->knn_cells = bt.cells;
     out->verts = body->verts;
-    out->vert_weights = body->vert_weights;
+    out->vert_T = P(L.vert_T);
     out->bones = body->bones;
     out->sdf_b6 = P(L.sdf_b6);
     out->scalars = P(L.scalars);

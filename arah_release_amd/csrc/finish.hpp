@@ -15,7 +15,7 @@
 #pragma once
 
 constexpr int kFinTile = 16;
-constexpr size_t kLdsTraceFinish = (kFinTile * 4 * 2 + kFinTile * 16 + 24 * 16 + kFinTile * 8) * 4 + (size_t)kFinTile * kSdfLd * 4;
+constexpr size_t kLdsTraceFinish = (kFinTile * 4 * 2 + kFinTile * 16 + kFinTile * 8) * 4 + (size_t)kFinTile * kSdfLd * 4;
 constexpr size_t kLdsJointFinish = (kFinTile * 4 * 3 + 24 * 16 + kFinTile * 2 + kFinTile * kLogitLd + 32) * 4 + (size_t)kFinTile * kSdfLd * 4;
 
 // ---- loop A: the remaining sphere-tracing steps of the rays in list[0 .. *count)
@@ -28,8 +28,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
     float* xin = smem;                                   // [16][4] normalised canonical point of the step
     float* outv = xin + kFinTile * 4;                    // [16][4]
     float* Tl = outv + kFinTile * 4;                     // [16][16] inverse-LBS transform of the step
-    float* sbones = Tl + kFinTile * 16;                  // [24][16]
-    int* ids = reinterpret_cast<int*>(sbones + 24 * 16); // [16] ray id, -1 = slot done
+    int* ids = reinterpret_cast<int*>(Tl + kFinTile * 16);   // [16] ray id, -1 = slot done
     float* tl = reinterpret_cast<float*>(ids + kFinTile);   // [16] depth
     float* farl = tl + kFinTile;                         // [16]
     int* nnl = reinterpret_cast<int*>(farl + kFinTile);  // [16] nearest vertex of the previous step
@@ -42,7 +41,6 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
     const float scale = sdf_scale(bc);
     int n_done = 0;   // evaluations of this workgroup (one atomic at the end: a counter bumped every step by every tile is the
                       // most contended word of the launch, and the waves' next loads queue behind it)
-    for (int i = tid; i < 24 * 16; i += kThreads) sbones[i] = fr.bones[i];
     for (int tile = blockIdx.x; tile * kFinTile < n; tile += gridDim.x) {
         __syncthreads();
         if (tid < kFinTile) {
@@ -82,7 +80,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_trace_finish(FrameDev fr, KnnDa
                     bi = nearest_vertex_group16<kClusterSize>(kd, kd.sorted4, kd.spheres, g, p, best, bi, lane);
                     if ((lane & 15) == 0) {
                         float T[16];
-                        blend(fr.vert_weights + (size_t)bi * 24, sbones, T);
+                        vertex_transform(fr, bi, T);
                         const V3 y = V3{p.x - bc.trans[0], p.y - bc.trans[1], p.z - bc.trans[2]};
                         const V3 xh = normalize_pt(bc, inverse_affine_apply(T, y));
                         store_T(Tl + s * 16, T);

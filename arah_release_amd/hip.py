@@ -80,7 +80,7 @@ class ArahFrame(C.Structure):
                 ("col_w0pT", _fp), ("col_w1pT", _fp), ("col_w2pT", _fp), ("col_w3apT", _fp), ("col_w3bpT", _fp),
                 ("col_w4pT", _fp), ("b3", C.c_void_p * 22),
                 ("verts4", _fp), ("knn_spheres", _fp), ("knn_grid", _fp), ("knn_cells", _fp),
-                ("verts", _fp), ("vert_weights", _fp), ("bones", _fp),
+                ("verts", _fp), ("vert_T", _fp), ("bones", _fp),
                 ("scalars", _fp), ("n_verts", C.c_int32),
                 ("col_mode", C.c_int32), ("precision", C.c_int32)]
 

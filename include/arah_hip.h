@@ -184,7 +184,7 @@ typedef struct ArahFrame {
     const void* knn_grid;       /* grid geometry (device) */
     const void* knn_cells;      /* [n_cells][64] candidate clusters per cell */
     const float* verts;         /* caller's [n_verts][3] */
-    const float* vert_weights;  /* caller's */
+    const float* vert_T;        /* [n_verts][16] blended bone transform of each vertex, sum_j w_vj A_j (frame buffer) */
     const float* bones;         /* caller's [24][16] */
     const float* scalars;       /* [9] device: trans(3), center(3), coord_min, coord_max, |variance| */
     int32_t n_verts;
