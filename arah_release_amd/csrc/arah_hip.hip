@@ -124,6 +124,7 @@ FrameDev to_dev(const ArahFrame& f) {
 struct Counters {
     unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, n_density, n_canon, n_split_nonfinite;
     unsigned long long clk[8 * 16];   // instrumented builds (-DARAH_CLOCKS): s_memtime ticks per wave slot and phase
+    unsigned long long clk_shade[8 * 16];   // the same for k_shade
 };
 #ifdef ARAH_CLOCKS
 typedef PhaseClk KernelClk;
@@ -2336,6 +2337,10 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
     const float scale = sdf_scale(bc);
     const float beta = fminf(fmaxf(fabsf(load_beta(fr)), 1e-6f), 1e6f);   // IDR:366
     const float inv_beta = 1.0f / beta;
+    // phases: 0 tile load, 1 forward trunk (7 its products, 8 its epilogues, 9 its barriers; 1 the rest), 2 head + resplit,
+    // 3 reverse sweep (10 products, 11 epilogues, 12 barriers), 4 colour input, 5 colour MLP, 6 store
+    KernelClk clk;
+    clk.start();
     for (int tile = blockIdx.x; tile * kTile < n; tile += gridDim.x) {
         if (tid < kTile) {
             const int i = tile * kTile + tid;
@@ -2346,17 +2351,21 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
             reinterpret_cast<f32x4*>(xin)[tid] = x;
         }
         __syncthreads();
+        clk.mark(0);
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane);
+        sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane, NoTap(), &clk);
+        clk.mark(1);
         sdf_head<SPLIT>(fr.sdf, actA, ldA, outv, 4, tid);
         if constexpr (B3) {
             resplit_rows_bf16(actA, ldA, loA, tid);   // the feature: f16 split planes -> bf16 planes
-            sdf_backward_bp(fr.sdf, b3, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
+            clk.mark(2);
+            sdf_backward_bp(fr.sdf, b3, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid, &clk);
         } else {
             if (SPLIT) unsplit_rows(actA, ldA, tid);   // the colour MLP (exact engine) reads the feature as fp32
             sdf_backward(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);
         }
         __syncthreads();
+        clk.mark(3);
         if (tid < kTile) {   // colour-input extras behind the feature: x(3), n(3), [PE4(view) 27], zero pad
             const int id = ids[tid];
             float ebuf[64];   // B3: staged here, written as planes below
@@ -2421,9 +2430,11 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
             }
         }
         __syncthreads();
+        clk.mark(4);
         if constexpr (B3) color_mlp_bp<IDR>(fr.col, b3, actA, ldA, loA, actB, rgbv, 4, wave, lane, tid);
         else color_mlp<IDR>(fr.col, actA, actB, rgbv, 4, wave, lane, tid);
         __syncthreads();
+        clk.mark(5);
         if (tid == 0) {
             const int cnt = min(kTile, n - tile * kTile);
             count_add(ctr_fwd, cnt);
@@ -2436,7 +2447,13 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
             if (sdfn_out) sdfn_out[ids[tid]] = reinterpret_cast<const f32x4*>(outv)[tid];
         }
         __syncthreads();
+        clk.mark(6);
     }
+#ifdef ARAH_CLOCKS
+    if (lane == 0 && ctr_fwd)   // ctr_fwd is the first counter of the workspace's Counters
+        for (int i = 0; i < 16; ++i)
+            atomicAdd(&reinterpret_cast<Counters*>(ctr_fwd)->clk_shade[wave * 16 + i], (unsigned long long)clk.acc[i]);
+#endif
 }
 
 // unit seam of the colour MLP alone
@@ -3467,12 +3484,13 @@ int arah_counters_reset(void* workspace, void* stream) {
 }
 
 #ifdef ARAH_CLOCKS
-// instrumented builds only (tools/phase_clocks.py): the 8 x 16 phase clocks behind the counters; syncs the stream
+// instrumented builds only (tools/phase_clocks.py): the 2 x 8 x 16 phase clocks (loop C, k_shade) behind the counters;
+// syncs the stream
 int arah_debug_clocks(const void* workspace, unsigned long long* h_out, void* stream) {
     if (!workspace || !h_out) return ARAH_E_BADARG;
     Workspace w = carve(const_cast<void*>(workspace), 1, 1);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (hipMemcpyAsync(h_out, w.ctr->clk, sizeof(w.ctr->clk), hipMemcpyDeviceToHost, s) != hipSuccess) return ARAH_E_LAUNCH;
+    if (hipMemcpyAsync(h_out, w.ctr->clk, sizeof(w.ctr->clk) + sizeof(w.ctr->clk_shade), hipMemcpyDeviceToHost, s) != hipSuccess) return ARAH_E_LAUNCH;
     return hipStreamSynchronize(s) == hipSuccess ? ARAH_OK : ARAH_E_LAUNCH;
 }
 #endif

@@ -66,7 +66,19 @@ __device__ __forceinline__ void no_pack(f32x4& v) {
 // (global_load_dwordx4 v, v_off, s[base:base+1] offset:imm).
 template <typename Tp>
 __device__ __forceinline__ Tp ld_frag(const void* __restrict__ base, unsigned lane_off, int const_off) {
+#ifdef ARAH_FRAG_FLAT
     return *reinterpret_cast<const Tp*>(reinterpret_cast<const char*>(base) + const_off + (size_t)lane_off);
+#else
+    // a buffer load: the base is four scalar registers, the lane's offset one vector register, the constant part an
+    // immediate (+ a scalar for the 4 KB window) -- whatever the unroller and the invariant-code motion make of the loop.
+    // (The flat form left 64-bit vector addresses per 4 KB window, hoisted out of the tile loop and spilled: 154 scratch
+    // reloads in front of as many fragment loads in round 4's k_shade.)
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    static_assert(sizeof(Tp) == 16, "fragments are 16 bytes per lane");
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)lane_off + (const_off & 4095), const_off & ~4095, 0);
+    return __builtin_bit_cast(Tp, v);
+#endif
 }
 
 constexpr float kActScale = 1024.0f;       // activations are stored as f16 pairs of 1024 h
@@ -75,6 +87,7 @@ constexpr float kInvActScale = 1.0f / 1024.0f;
 // Phase clocks for the instrumented build (tools/phase_clocks.py, -DARAH_CLOCKS): a wave accumulates the s_memtime
 // ticks it spends between consecutive marks.  NoClk compiles to nothing.
 struct NoClk {
+    __device__ __forceinline__ void start() {}
     __device__ __forceinline__ void mark(int) {}
 };
 struct PhaseClk {
@@ -551,7 +564,10 @@ __device__ __forceinline__ float load_bsplit(const float* act, int ld, int lo_of
     return (float)*reinterpret_cast<const __bf16*>(row) + (float)*reinterpret_cast<const __bf16*>(row + lo_off);
 }
 
-// acc[m][n] += W(M-tiles mt0.., KC32 32-chunks) * planes(16 NT points): A one chunk ahead, B at the top of the chunk
+// acc[m][n] += W(M-tiles mt0.., KC32 32-chunks) * planes(16 NT points).  Loop D runs two waves per SIMD: as in
+// gemm_acc_split<DEEP> the chunk loop is fully unrolled with BOTH operands one chunk ahead and a scheduling fence per chunk
+// (the rolled form, B read at the top of its chunk and the A loads sunk next to their use, cost the reverse sweep 1.8 x the
+// forward trunk's time for the same MFMAs: profiles/r04_shade_phases.txt).  Same MFMA order per accumulator.
 template <int KC32, int MT, int NT = kNT>
 __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, int mt0, const float* act, int ld, int lo_off,
                                                 f32x4 (&acc)[MT][NT], int lane) {
@@ -559,6 +575,7 @@ __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, i
     const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
     const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
     auto lda = [&](int idx) { return ld_frag<bf16x8>(wp, aoff, idx * 1024); };
+#ifdef ARAH_BSPLIT_ROLLED   // round 3's form (A/B reference for the measurement)
     bf16x8 ah[MT], al[MT], ahn[MT], aln[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -597,6 +614,51 @@ __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, i
             al[m] = aln[m];
         }
     }
+#else
+    bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        ah[0][m] = lda((m * KC32) * 2 + 0);
+        al[0][m] = lda((m * KC32) * 2 + 1);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        bh[0][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4);
+        bl[0][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + lo_off);
+    }
+#pragma unroll
+    for (int kc = 0; kc < KC32; ++kc) {
+        const int c = kc & 1, x = c ^ 1;
+        if (kc + 1 < KC32) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[x][m] = lda((m * KC32 + kc + 1) * 2 + 0);
+                al[x][m] = lda((m * KC32 + kc + 1) * 2 + 1);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[x][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + (kc + 1) * 64);
+                bl[x][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + lo_off + (kc + 1) * 64);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)   // small terms first
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c][m], bl[c][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c][m], bh[c][n], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);   // the next chunk's loads stay above this chunk's MFMAs
+    }
+#endif
 }
 
 // 4 consecutive channels of one point, already multiplied by kActScale -> hi/lo planes
@@ -843,9 +905,12 @@ __device__ __forceinline__ void stream_rows_split(const float* lds, int ld, floa
 // receives h6 -- as fp32 [256] (exact engine) or as split planes (hi at byte 0, lo at byte 512; SPLIT).
 // GRAD: dact factors of layers 1..5 go to `spill` (global, this workgroup's private slab of
 // 5*8*8*64 f32x4), layer 6's stay in `dlast`.
-template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap>
+// pc: phase clocks of an instrumented build (tools/phase_clocks.py), nothing otherwise
+#define ARAH_PC_MARK(i) do { if (pc) pc->mark(i); } while (0)
+template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap, typename CLK = NoClk>
 __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
-                                          f32x4 (&dlast)[kSdfMT][NT], int wave, int lane, const TAP& tap = TAP()) {
+                                          f32x4 (&dlast)[kSdfMT][NT], int wave, int lane, const TAP& tap = TAP(),
+                                          CLK* pc = nullptr) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
     constexpr float amp = SPLIT ? kActScale : 1.0f;
@@ -875,7 +940,9 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
                 film_sine<GRAD>(v, fw, pw, f, amp, h, d);
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
+#ifndef ARAH_ABL_NO_SLAB
                 if (GRAD) spill[((0 * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
+#endif
             }
         }
     }
@@ -898,6 +965,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
 #endif
         if (SPLIT) gemm_acc_split<8, kSdfMT, NT, GRAD>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);   // GRAD kernels: 2 waves/SIMD
         else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
+        ARAH_PC_MARK(7);
         // forward-only kernels: the epilogue's per-channel constants travel (L2 latency) while the workgroup gathers at the
         // barrier (the gradient kernels sit at the VGPR cap and load them afterwards)
         f32x4 fwm[kSdfMT], pwm[kSdfMT];
@@ -910,6 +978,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
             }
         }
         ARAH_SYNC();   // everyone is done reading the layer input
+        ARAH_PC_MARK(9);
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
@@ -937,12 +1006,18 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
                 if (GRAD) {
+#ifdef ARAH_ABL_NO_SLAB   //   ARAH_ABL_NO_SLAB   timing only: the derivative factors neither leave nor come back
+                    dlast[m][n] = d;
+#else
                     if (k < 5) spill[((k * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
                     else dlast[m][n] = d;
+#endif
                 }
             }
         }
+        ARAH_PC_MARK(8);
         ARAH_SYNC();
+        ARAH_PC_MARK(9);
     }
 }
 
@@ -1479,9 +1554,10 @@ __device__ __forceinline__ void resplit_rows_bf16(float* act, int ld, int lo_off
 }
 
 // sdf_backward with the sweep's activations as bf16 planes in `bwd` (rows of ld floats, lo plane at byte 512)
+template <typename CLK = NoClk>
 __device__ __forceinline__ void sdf_backward_bp(const SdfNet& net, const B3Nets& b3, float* bwd, int ld, const f32x4* spill,
                                                 const f32x4 (&dlast)[kSdfMT][kNT], float* out, int ostride, int wave,
-                                                int lane, int tid) {
+                                                int lane, int tid, CLK* pc = nullptr) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
 #pragma unroll
@@ -1505,16 +1581,25 @@ __device__ __forceinline__ void sdf_backward_bp(const SdfNet& net, const B3Nets&
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m)
 #pragma unroll
-            for (int n = 0; n < kNT; ++n) dk[m][n] = spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane];
+            for (int n = 0; n < kNT; ++n)
+#ifdef ARAH_ABL_NO_SLAB
+                dk[m][n] = dlast[m][n];
+#else
+                dk[m][n] = spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane];
+#endif
         gemm_acc_bsplit<8, kSdfMT>(b3.sdf_wpT[k], mt0, bwd, ld, 512, acc, lane);
+        ARAH_PC_MARK(10);
         ARAH_SYNC();
+        ARAH_PC_MARK(12);
 #pragma unroll
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
 #pragma unroll
             for (int n = 0; n < kNT; ++n) store_bsplit4(bwd, ld, 512, n * 16 + j, ch0, acc[m][n] * dk[m][n]);
         }
+        ARAH_PC_MARK(11);
         ARAH_SYNC();
+        ARAH_PC_MARK(12);
     }
     const int pt = tid >> 3, part = tid & 7;
     float gx = 0.f, gy = 0.f, gz = 0.f;

@@ -19,6 +19,7 @@ NAMES_TILE = ["refill", "bar0", "layer0", "gemm1", "epi1", "gemm2", "epi2", "gem
 # k_canon_wave (the default): 0 refill + claim, 1 first chunk of the input layer, 2..4 hidden layers 1..3 (MFMA steps with the
 # epilogue parts that ride along), 5 output layer, 6 per-point tail
 NAMES_WAVE = ["refill", "layer0.0", "layer1", "layer2", "layer3", "out", "tail"]
+NAMES_SHADE = ["load", "trunk", "head", "sweep", "colin", "colour", "store", "tr.gemm", "tr.epi", "tr.bar", "sw.gemm", "sw.epi", "sw.bar"]
 NAMES = NAMES_TILE if os.environ.get("ARAH_CANON_KERNEL") == "tile" else NAMES_WAVE
 
 
@@ -46,7 +47,7 @@ def run(frames):
         for f in range(frames):
             model(scene.make_inputs(512, 512, frame_idx=1 + f, device=dev), eval=True)
     torch.cuda.synchronize()
-    out = (C.c_ulonglong * 128)()
+    out = (C.c_ulonglong * 256)()
     rc = lib.arah_debug_clocks(C.c_void_p(ws.buf.data_ptr()), out, C.c_void_p(torch.cuda.current_stream().cuda_stream))
     assert rc == 0, rc
     ctr = ws.counters()
@@ -56,6 +57,14 @@ def run(frames):
     for i, nm in enumerate(NAMES):
         print("%-8s" % nm + "".join("%9.1f" % (100.0 * out[w * 16 + i] / max(tot[w], 1)) for w in range(8)))
     print("%-8s" % "Gticks" + "".join("%9.2f" % (tot[w] / 1e9) for w in range(8)))
+    # k_shade (all of it with ARAH_FULL_SHADING=1): the second block of clocks
+    sh = out[128:]
+    tot = [sum(sh[w * 16 + i] for i in range(16)) for w in range(8)]
+    if sum(tot):
+        print("k_shade, shaded samples %d" % ctr["n_col"])
+        for i, nm in enumerate(NAMES_SHADE):
+            print("%-8s" % nm + "".join("%9.1f" % (100.0 * sh[w * 16 + i] / max(tot[w], 1)) for w in range(8)))
+        print("%-8s" % "Gticks" + "".join("%9.2f" % (tot[w] / 1e9) for w in range(8)))
 
 
 if __name__ == "__main__":
