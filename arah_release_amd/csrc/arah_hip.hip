@@ -2353,7 +2353,7 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
         __syncthreads();
         clk.mark(0);
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<true, kNT, SPLIT>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane, NoTap(), &clk);
+        sdf_trunk<true, kNT, SPLIT, NoTap, KernelClk, 2>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane, NoTap(), &clk);
         clk.mark(1);
         sdf_head<SPLIT>(fr.sdf, actA, ldA, outv, 4, tid);
         if constexpr (B3) {

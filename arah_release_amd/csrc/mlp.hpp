@@ -363,15 +363,23 @@ __device__ __forceinline__ void static_for(F&& f) {
 // in a chunk's first stage, the A fragments of the next chunk (2 MT global loads) are in flight, and
 // sched_group_barrier pins the interleaving: one memory instruction between every two MFMAs.  Registers: two stages of B
 // (4 NT/H quads) + two chunks of A (4 MT quads) next to the MT NT accumulators.
-template <int KC32, int MT, int NT, int H>
-__device__ __forceinline__ void gemm_acc_split_pipe(const f16x8* __restrict__ wp, int mt0, const float* act, int ld,
+// FR: f16x8 (the f16 split) or bf16x8 (bf16 x 3, loop D's reverse sweep and colour MLP)
+typedef __bf16 bf16x8_fr __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma_frag(const f16x8 a, const f16x8 b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_frag(const bf16x8_fr a, const bf16x8_fr b, const f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+template <int KC32, int MT, int NT, int H, typename FR = f16x8>
+__device__ __forceinline__ void gemm_acc_split_pipe(const FR* __restrict__ wp, int mt0, const float* act, int ld,
                                                     int lo_off, f32x4 (&acc)[MT][NT], int lane) {
     constexpr int NH = NT / H, S = KC32 * H;
     const int j = lane & 15, g = lane >> 4;
     const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
     const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
-    auto lda = [&](int idx) { return ld_frag<f16x8>(wp, aoff, idx * 1024); };
-    f16x8 ah[2][MT], al[2][MT], bh[2][NH], bl[2][NH];
+    auto lda = [&](int idx) { return ld_frag<FR>(wp, aoff, idx * 1024); };
+    FR ah[2][MT], al[2][MT], bh[2][NH], bl[2][NH];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         ah[0][m] = lda((m * KC32) * 2 + 0);
@@ -379,8 +387,8 @@ __device__ __forceinline__ void gemm_acc_split_pipe(const f16x8* __restrict__ wp
     }
 #pragma unroll
     for (int n = 0; n < NH; ++n) {
-        bh[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4);
-        bl[0][n] = *reinterpret_cast<const f16x8*>(bptr + n * 16 * ld * 4 + lo_off);
+        bh[0][n] = *reinterpret_cast<const FR*>(bptr + n * 16 * ld * 4);
+        bl[0][n] = *reinterpret_cast<const FR*>(bptr + n * 16 * ld * 4 + lo_off);
     }
     __builtin_amdgcn_sched_barrier(0);
     static_for<0, S>([&](auto Sc) {
@@ -406,25 +414,25 @@ __device__ __forceinline__ void gemm_acc_split_pipe(const f16x8* __restrict__ wp
 #endif
 #pragma unroll
             for (int n = 0; n < NH; ++n) {
-                bh[cb ^ 1][n] = *reinterpret_cast<const f16x8*>(bptr + (h1 * NH + n) * 16 * ld * 4 + k1 * 64);
-                bl[cb ^ 1][n] = *reinterpret_cast<const f16x8*>(bptr + (h1 * NH + n) * 16 * ld * 4 + lo_off + k1 * 64);
+                bh[cb ^ 1][n] = *reinterpret_cast<const FR*>(bptr + (h1 * NH + n) * 16 * ld * 4 + k1 * 64);
+                bl[cb ^ 1][n] = *reinterpret_cast<const FR*>(bptr + (h1 * NH + n) * 16 * ld * 4 + lo_off + k1 * 64);
             }
         }
 #pragma unroll
         for (int m = 0; m < MT; ++m)   // small terms first
 #pragma unroll
             for (int n = 0; n < NH; ++n)
-                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[ca][m], bh[cb][n], acc[m][h * NH + n], 0, 0, 0);
+                acc[m][h * NH + n] = mfma_frag(al[ca][m], bh[cb][n], acc[m][h * NH + n]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NH; ++n)
-                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ca][m], bl[cb][n], acc[m][h * NH + n], 0, 0, 0);
+                acc[m][h * NH + n] = mfma_frag(ah[ca][m], bl[cb][n], acc[m][h * NH + n]);
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < NH; ++n)
-                acc[m][h * NH + n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[ca][m], bh[cb][n], acc[m][h * NH + n], 0, 0, 0);
+                acc[m][h * NH + n] = mfma_frag(ah[ca][m], bh[cb][n], acc[m][h * NH + n]);
         // order inside the stage: MFMA, load, MFMA, MFMA, load, ... (0x008 MFMA, 0x020 VMEM read, 0x100 DS read)
         constexpr int n_vm = more_a ? 2 * MT : 0, n_ds = more_b ? 2 * NH : 0, n_mf = 3 * MT * NH;
         constexpr int per = (n_vm + n_ds) > 0 ? (n_mf - 2) / (n_vm + n_ds) : n_mf;   // MFMAs between two loads
@@ -564,18 +572,21 @@ __device__ __forceinline__ float load_bsplit(const float* act, int ld, int lo_of
     return (float)*reinterpret_cast<const __bf16*>(row) + (float)*reinterpret_cast<const __bf16*>(row + lo_off);
 }
 
-// acc[m][n] += W(M-tiles mt0.., KC32 32-chunks) * planes(16 NT points).  Loop D runs two waves per SIMD: as in
-// gemm_acc_split<DEEP> the chunk loop is fully unrolled with BOTH operands one chunk ahead and a scheduling fence per chunk
-// (the rolled form, B read at the top of its chunk and the A loads sunk next to their use, cost the reverse sweep 1.8 x the
-// forward trunk's time for the same MFMAs: profiles/r04_shade_phases.txt).  Same MFMA order per accumulator.
+// acc[m][n] += W(M-tiles mt0.., KC32 32-chunks) * planes(16 NT points).  Loop D runs two waves per SIMD: the explicit
+// pipeline of gemm_acc_split_pipe, half a chunk's N-tiles per stage.  (Round 3's rolled form -- B read at the top of its
+// chunk, the A loads sunk next to their use -- cost the reverse sweep 1.8 x the forward trunk's time for the same MFMAs;
+// fully unrolled with both operands a chunk ahead: 85.0 -> 67.8 ms per shade-everything frame together with the buffer
+// loads of ld_frag; the pinned interleaving another 1.2 ms: profiles/r04_shade_phases.txt.)  Same MFMA order per accumulator.
 template <int KC32, int MT, int NT = kNT>
 __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, int mt0, const float* act, int ld, int lo_off,
                                                 f32x4 (&acc)[MT][NT], int lane) {
+#ifndef ARAH_BSPLIT_ROLLED
+    gemm_acc_split_pipe<KC32, MT, NT, NT % 2 == 0 ? 2 : 1, bf16x8>(wp, mt0, act, ld, lo_off, acc, lane);
+#else   // round 3's form (A/B reference for the measurement)
     const int j = lane & 15, g = lane >> 4;
     const char* bptr = reinterpret_cast<const char*>(act) + j * ld * 4 + split_slot(j, g) * 16;
     const unsigned aoff = (unsigned)(mt0 * KC32 * 2 * 64 + lane) * 16u;
     auto lda = [&](int idx) { return ld_frag<bf16x8>(wp, aoff, idx * 1024); };
-#ifdef ARAH_BSPLIT_ROLLED   // round 3's form (A/B reference for the measurement)
     bf16x8 ah[MT], al[MT], ahn[MT], aln[MT];
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
@@ -613,50 +624,6 @@ __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, i
             ah[m] = ahn[m];
             al[m] = aln[m];
         }
-    }
-#else
-    bf16x8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        ah[0][m] = lda((m * KC32) * 2 + 0);
-        al[0][m] = lda((m * KC32) * 2 + 1);
-    }
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        bh[0][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4);
-        bl[0][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + lo_off);
-    }
-#pragma unroll
-    for (int kc = 0; kc < KC32; ++kc) {
-        const int c = kc & 1, x = c ^ 1;
-        if (kc + 1 < KC32) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[x][m] = lda((m * KC32 + kc + 1) * 2 + 0);
-                al[x][m] = lda((m * KC32 + kc + 1) * 2 + 1);
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                bh[x][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + (kc + 1) * 64);
-                bl[x][n] = *reinterpret_cast<const bf16x8*>(bptr + n * 16 * ld * 4 + lo_off + (kc + 1) * 64);
-            }
-        }
-#pragma unroll
-        for (int m = 0; m < MT; ++m)   // small terms first
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[c][m], bh[c][n], acc[m][n], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c][m], bl[c][n], acc[m][n], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c][m], bh[c][n], acc[m][n], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);   // the next chunk's loads stay above this chunk's MFMAs
     }
 #endif
 }
@@ -907,7 +874,8 @@ __device__ __forceinline__ void stream_rows_split(const float* lds, int ld, floa
 // 5*8*8*64 f32x4), layer 6's stay in `dlast`.
 // pc: phase clocks of an instrumented build (tools/phase_clocks.py), nothing otherwise
 #define ARAH_PC_MARK(i) do { if (pc) pc->mark(i); } while (0)
-template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap, typename CLK = NoClk>
+// PIPE > 0 (k_shade, two waves per SIMD): the gradient trunk's products on the explicit pipeline too, NT / PIPE N-tiles per stage
+template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap, typename CLK = NoClk, int PIPE = 0>
 __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
                                           f32x4 (&dlast)[kSdfMT][NT], int wave, int lane, const TAP& tap = TAP(),
                                           CLK* pc = nullptr) {
@@ -963,18 +931,23 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         if constexpr (SPLIT && !GRAD && NT == 8) gemm_acc_split_pipe<8, kSdfMT, NT, 2>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
         else
 #endif
+        if constexpr (SPLIT && PIPE > 0) gemm_acc_split_pipe<8, kSdfMT, NT, PIPE>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);
+        else
         if (SPLIT) gemm_acc_split<8, kSdfMT, NT, GRAD>(net.wps[k - 1], mt0, act, ld, 512, acc, lane);   // GRAD kernels: 2 waves/SIMD
         else gemm_acc<16, kSdfMT, NT>(net.wp[k - 1], mt0, act, ld, acc, lane);
         ARAH_PC_MARK(7);
-        // forward-only kernels: the epilogue's per-channel constants travel (L2 latency) while the workgroup gathers at the
-        // barrier (the gradient kernels sit at the VGPR cap and load them afterwards)
-        f32x4 fwm[kSdfMT], pwm[kSdfMT];
-        if constexpr (!GRAD) {
+        // the epilogue's per-channel constants travel (L2 latency) while the workgroup gathers at the barrier -- in the
+        // forward-only kernels and in k_shade (PIPE; two waves per SIMD); the other gradient kernels sit at their VGPR cap
+        // and load them afterwards
+        constexpr bool kEarly = !GRAD || (SPLIT && PIPE > 0);
+        f32x4 fwm[kSdfMT], pwm[kSdfMT], fm[kSdfMT];
+        if constexpr (kEarly) {
 #pragma unroll
             for (int m = 0; m < kSdfMT; ++m) {
                 const int ch0 = (mt0 + m) * 16 + 4 * g;
                 fwm[m] = *reinterpret_cast<const f32x4*>((SPLIT ? net.fws : net.fw) + k * 256 + ch0);
                 pwm[m] = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
+                if constexpr (GRAD) fm[m] = *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0);
             }
         }
         ARAH_SYNC();   // everyone is done reading the layer input
@@ -983,13 +956,14 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
         for (int m = 0; m < kSdfMT; ++m) {
             const int ch0 = (mt0 + m) * 16 + 4 * g;
             f32x4 fw, pw, f = zero4;
-            if constexpr (GRAD) {
+            if constexpr (!kEarly) {
                 fw = *reinterpret_cast<const f32x4*>((SPLIT ? net.fws : net.fw) + k * 256 + ch0);
                 pw = *reinterpret_cast<const f32x4*>(net.pw + k * 256 + ch0);
                 f = *reinterpret_cast<const f32x4*>(net.freq + k * 256 + ch0);
             } else {
                 fw = fwm[m];
                 pw = pwm[m];
+                if constexpr (GRAD) f = fm[m];
             }
 #pragma unroll
             for (int n = 0; n < NT; ++n) {
@@ -1722,19 +1696,25 @@ __device__ __forceinline__ void color_mlp(const ColNet& net, const float* A, flo
 // The colour MLP on the bf16 x 3 engine with every activation as bf16 planes.
 // A: planes of the full input, rows of ldA floats, lo plane at byte loA, ceil(kInPad / 32) chunks of which the channels
 // beyond kIn are zero; B: planes of the hidden activations, rows of kSdfLd floats, lo plane at byte 512.
+// the bias of a wave's channels, requested BEFORE the barrier that precedes relu_store_bp (an L2 round trip otherwise)
 template <int MT>
-__device__ __forceinline__ void relu_store_bp(const f32x4 (&acc)[MT][kNT], const float* bias, float* dst, int ld,
+__device__ __forceinline__ void load_bias(const float* bias, int mt0, int lane, f32x4 (&b)[MT]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) b[m] = *reinterpret_cast<const f32x4*>(bias + (mt0 + m) * 16 + 4 * g);
+}
+template <int MT>
+__device__ __forceinline__ void relu_store_bp(const f32x4 (&acc)[MT][kNT], const f32x4 (&b)[MT], float* dst, int ld,
                                               int mt0, int lane) {
     const int j = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         const int ch0 = (mt0 + m) * 16 + 4 * g;
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + ch0);
 #pragma unroll
         for (int n = 0; n < kNT; ++n) {
             f32x4 h;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[m][n][r] + b[r], 0.f);
+            for (int r = 0; r < 4; ++r) h[r] = fmaxf(acc[m][n][r] + b[m][r], 0.f);
             store_bsplit4(dst, ld, 512, n * 16 + j, ch0, h);
         }
     }
@@ -1752,8 +1732,10 @@ __device__ __forceinline__ void color_mlp_bp(const ColNet& net, const B3Nets& b3
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        f32x4 bias[2];
+        load_bias<2>(net.bias, wave * 2, lane, bias);
         gemm_acc_bsplit<KCA, 2>(b3.col[0], wave * 2, A, ldA, loA, acc, lane);
-        relu_store_bp<2>(acc, net.bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
+        relu_store_bp<2>(acc, bias, B, ldB, wave * 2, lane);   // B is not read by this GEMM
     }
     ARAH_SYNC();
     {
@@ -1762,18 +1744,22 @@ __device__ __forceinline__ void color_mlp_bp(const ColNet& net, const B3Nets& b3
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        f32x4 bias[2];
+        load_bias<2>(net.bias + 256, wave * 2, lane, bias);
         gemm_acc_bsplit<8, 2>(b3.col[1], wave * 2, B, ldB, 512, acc, lane);
         ARAH_SYNC();
-        relu_store_bp<2>(acc, net.bias + 256, B, ldB, wave * 2, lane);
+        relu_store_bp<2>(acc, bias, B, ldB, wave * 2, lane);
     }
     ARAH_SYNC();
     {
         f32x4 acc[1][kNT];
 #pragma unroll
         for (int n = 0; n < kNT; ++n) zero_acc(acc[0][n]);
+        f32x4 bias[1];
+        load_bias<1>(net.bias + 512, wave, lane, bias);
         gemm_acc_bsplit<8, 1>(b3.col[2], wave, B, ldB, 512, acc, lane);
         ARAH_SYNC();
-        relu_store_bp<1>(acc, net.bias + 512, B, ldB, wave, lane);   // channels 0..127
+        relu_store_bp<1>(acc, bias, B, ldB, wave, lane);   // channels 0..127
     }
     ARAH_SYNC();
     {
@@ -1782,10 +1768,12 @@ __device__ __forceinline__ void color_mlp_bp(const ColNet& net, const B3Nets& b3
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        f32x4 bias[2];
+        load_bias<2>(net.bias + 640, wave * 2, lane, bias);
         gemm_acc_bsplit<KCA, 2>(b3.col[3], wave * 2, A, ldA, loA, acc, lane);
         gemm_acc_bsplit<4, 2>(b3.col[4], wave * 2, B, ldB, 512, acc, lane);
         ARAH_SYNC();
-        relu_store_bp<2>(acc, net.bias + 640, B, ldB, wave * 2, lane);
+        relu_store_bp<2>(acc, bias, B, ldB, wave * 2, lane);
     }
     ARAH_SYNC();
     {
@@ -1794,9 +1782,11 @@ __device__ __forceinline__ void color_mlp_bp(const ColNet& net, const B3Nets& b3
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int n = 0; n < kNT; ++n) zero_acc(acc[m][n]);
+        f32x4 bias[2];
+        load_bias<2>(net.bias + 896, wave * 2, lane, bias);
         gemm_acc_bsplit<8, 2>(b3.col[5], wave * 2, B, ldB, 512, acc, lane);
         ARAH_SYNC();
-        relu_store_bp<2>(acc, net.bias + 896, B, ldB, wave * 2, lane);
+        relu_store_bp<2>(acc, bias, B, ldB, wave * 2, lane);
     }
     ARAH_SYNC();
     {
