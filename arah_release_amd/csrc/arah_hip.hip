@@ -14,6 +14,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "../../include/arah_hip.h"
 #include "pointwise.hpp"
 #include "mlp.hpp"
@@ -2668,37 +2671,67 @@ Workspace carve(void* base, int n_rays, int n_steps) {
     return w;
 }
 
+// The library's only process-wide data: tuning / diagnostic knobs, read from the environment ONCE (first use, thread-safe
+// static initialisation) and immutable afterwards.  Nothing an entry point does depends on mutable global state; what a
+// caller may want to change per call (engines, solver, events, shading mode) travels in ArahSampling / ArahFrame.
+struct Knobs {
+    int max_grid;        // ARAH_MAX_GRID          cap of the persistent grids (<= kMaxGrid, the spill slab is sized for it)
+    bool split_solo;     // ARAH_SPLIT_SOLO=1      every split-engine workgroup owns its CU (diagnostic, see split_lds)
+    int knn_group;       // ARAH_KNN_GROUP         sixteen-lane search for the ray lists
+    int knn_below[3];    // ARAH_KNN_WAVE_{POINTS,RAYS,SAMPLES}  list lengths below which a wave per query is used
+    int joint_bulk;      // ARAH_JOINT_BULK_ITERS  loop B iterations launched wide before the finisher
+    int trace_bulk;      // ARAH_TRACE_BULK_STEPS  loop A steps launched wide before the finisher
+    int trace_small;     // ARAH_TRACE_SMALL       ray lists up to this length go to the finisher at once
+    bool density_wide;   // ARAH_DENSITY_TILE=128  128-point tiles in the density pass
+    bool train_b3;       // ARAH_TRAIN_ENGINE!=fp32  bf16 x 3 / f16 split training kernels on split frames
+};
+inline const Knobs& knobs() {
+    static const Knobs k = [] {
+        auto env_int = [](const char* name, int dflt) {
+            const char* e = getenv(name);
+            return e ? atoi(e) : dflt;
+        };
+        Knobs v;
+        const int g = env_int("ARAH_MAX_GRID", kMaxGrid);
+        v.max_grid = g >= 1 && g <= kMaxGrid ? g : kMaxGrid;
+        v.split_solo = env_int("ARAH_SPLIT_SOLO", 0) == 1;
+        v.knn_group = env_int("ARAH_KNN_GROUP", 1);
+        v.knn_below[0] = env_int("ARAH_KNN_WAVE_POINTS", 4096);
+        v.knn_below[1] = env_int("ARAH_KNN_WAVE_RAYS", v.knn_group ? (1 << 30) : 32768);
+        v.knn_below[2] = env_int("ARAH_KNN_WAVE_SAMPLES", 32768);
+        v.joint_bulk = max(1, min(kBroydenSteps + 1, env_int("ARAH_JOINT_BULK_ITERS", 3)));
+        v.trace_bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 24)));
+        v.trace_small = env_int("ARAH_TRACE_SMALL", 4096);
+        v.density_wide = env_int("ARAH_DENSITY_TILE", 128) == 128;
+        const char* e = getenv("ARAH_TRAIN_ENGINE");
+        v.train_b3 = !(e && strcmp(e, "fp32") == 0);
+        return v;
+    }();
+    return k;
+}
+
 inline int grid_for(long long n_items, int per_block) {
     long long g = (n_items + per_block - 1) / per_block;
     if (g < 1) g = 1;
-    static const int cap = [] {   // ARAH_MAX_GRID: debugging / tuning knob (<= kMaxGrid, the spill slab is sized for it)
-        const char* e = getenv("ARAH_MAX_GRID");
-        const int v = e ? atoi(e) : kMaxGrid;
-        return v >= 1 && v <= kMaxGrid ? v : kMaxGrid;
-    }();
+    const int cap = knobs().max_grid;
     if (g > cap) g = cap;
     return (int)g;
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? ARAH_OK : ARAH_E_LAUNCH; }
 
-inline int env_int(const char* name, int dflt) {
-    const char* e = getenv(name);
-    return e ? atoi(e) : dflt;
-}
-
 // compute units of the current device (grid of the resident one-workgroup-per-CU kernels)
 inline int num_cus() {
     constexpr int kMaxDevices = 64;
-    static int cus[kMaxDevices] = {};
+    static std::atomic<int> cus[kMaxDevices];   // 0 = not asked yet; every thread that asks stores the same value
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 256;
-    if (cus[dev] == 0) {
-        int v = 0;
+    int v = cus[dev].load(std::memory_order_relaxed);
+    if (v == 0) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        cus[dev] = v;
+        cus[dev].store(v, std::memory_order_relaxed);
     }
-    return cus[dev];
+    return v;
 }
 
 // dynamic LDS sizes (bytes)
@@ -2726,12 +2759,8 @@ constexpr size_t lds_color() {
 // the workaround that was in place until the irreproducibility of co-resident workgroups was traced to the packed
 // K = 3 input layer (no_pack in mlp.hpp); kept as a diagnostic switch.
 inline size_t split_lds(size_t lds) {
-    static const bool solo = [] {
-        const char* e = getenv("ARAH_SPLIT_SOLO");
-        return e && e[0] == '1';
-    }();
     constexpr size_t kSolo = 84 * 1024;
-    return solo && lds < kSolo ? kSolo : lds;
+    return knobs().split_solo && lds < kSolo ? kSolo : lds;
 }
 constexpr size_t kLdsSplitSolo = 84 * 1024;
 #define LAUNCH_ENGINE(split, KS, KE, GRID, BLOCK, LDS, ...)                              \
@@ -2741,8 +2770,9 @@ constexpr size_t kLdsSplitSolo = 84 * 1024;
     } while (0)
 
 // hipFuncSetAttribute is per DEVICE: the raised dynamic-LDS limits are set once for every device ordinal a call
-// arrives on (the current device at the time of the call -- the host binding makes the buffers' device current).
-bool g_attr_failed = false;
+// arrives on (the current device at the time of the call -- the host binding makes the buffers' device current), under a
+// std::call_once per device: first calls may arrive on several host threads at the same time.
+thread_local bool g_attr_failed = false;   // of the thread that runs the once-block
 template <typename K>
 inline void allow_lds(K kernel, size_t bytes) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2750,12 +2780,18 @@ inline void allow_lds(K kernel, size_t bytes) {
         g_attr_failed = true;
 }
 
+int setup_attributes_once();
 int setup_attributes() {
     constexpr int kMaxDevices = 64;
-    static bool done[kMaxDevices] = {};
+    static std::once_flag once[kMaxDevices];
+    static int rc[kMaxDevices];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return ARAH_E_LAUNCH;
-    if (done[dev]) return ARAH_OK;
+    std::call_once(once[dev], [dev] { rc[dev] = setup_attributes_once(); });
+    return rc[dev];
+}
+
+int setup_attributes_once() {
     g_attr_failed = false;
     allow_lds(k_nearest_invlbs<SRC_POINTS>, kLdsKnn);
     allow_lds(k_nearest_invlbs<SRC_RAYS>, kLdsKnn);
@@ -2801,9 +2837,7 @@ int setup_attributes() {
     allow_lds(k_shade_train<false, true, true>, lds_shade_train<false>());
     allow_lds(k_shade_train<true, false, true>, lds_shade_train<true>());
     allow_lds(k_shade_train<true, true, true>, lds_shade_train<true>());
-    if (g_attr_failed) return ARAH_E_LAUNCH;
-    done[dev] = true;
-    return ARAH_OK;
+    return g_attr_failed ? ARAH_E_LAUNCH : ARAH_OK;
 }
 
 // optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
@@ -2822,10 +2856,8 @@ void launch_nearest(hipStream_t s, const FrameDev& fd, long long n_max, const fl
     // 16k..64k entries; the 8.6e6-sample list of loop C wants the LDS table (86 ms when forced onto the wave kernel)
     // round 3: the sixteen-lane kernel takes the ray lists at every length (47.2 vs 48.0 ms per frame against handing
     // lists above 32k rays to the LDS-table kernel, gpurun_out r3n), so sphere tracing launches one search kernel per step
-    static const int group = env_int("ARAH_KNN_GROUP", 1);
-    static const int below[3] = {env_int("ARAH_KNN_WAVE_POINTS", 4096), env_int("ARAH_KNN_WAVE_RAYS", group ? (1 << 30) : 32768),
-                                 env_int("ARAH_KNN_WAVE_SAMPLES", 32768)};
-    const int wave_below = below[SRC];
+    const int group = knobs().knn_group;
+    const int wave_below = knobs().knn_below[SRC];
     long long gw = (n_max * 64 + kKnnWaveThreads - 1) / kKnnWaveThreads;
     if (gw > 4096) gw = 4096;
     if (gw < 1) gw = 1;
@@ -3726,7 +3758,7 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
                        (const float*)w.t, w.x0raw);
     // the first iterations as one launch each over the compacted list; then the finisher adopts what is left
     // (ARAH_JOINT_BULK_ITERS >= 51: every iteration as its own launch, round 2's schedule)
-    static const int bulk = max(1, min(kBroydenSteps + 1, env_int("ARAH_JOINT_BULK_ITERS", 3)));
+    const int bulk = knobs().joint_bulk;
     for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
@@ -3770,9 +3802,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     // Full frames: 24 wide steps, then the finisher adopts the stragglers (a few thousand rays: 52 launches of tens of
     // microseconds each become one; 43.15 -> 42.75 ms per frame one at a time, 41.7 -> 41.0 with three in flight; handing
     // over after 8 or 12 steps loses: too many rays left for sixteen-ray tiles -- profiles/r03_ab_trace_finish.txt)
-    static const int bulk_env = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 24)));
-    static const int small = env_int("ARAH_TRACE_SMALL", 4096);
-    const int bulk = n <= small ? 0 : bulk_env;
+    const int bulk = n <= knobs().trace_small ? 0 : knobs().trace_bulk;
     for (int it = 0; it < bulk; ++it) {
         int* lin = (it & 1) ? w.listB : w.listA;
         int* lout = (it & 1) ? w.listA : w.listB;
@@ -3899,8 +3929,7 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
         if (cfg->ev_density[0] && cfg->ev_density[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[0]), s);
         // long lists on the split engine: 128-point tiles, one workgroup per CU (ARAH_DENSITY_TILE=64 keeps the 64-point kernel)
-        static const bool wide = env_int("ARAH_DENSITY_TILE", 128) == 128;
-        if (fd.split && wide && Q >= 128ll * 1024)
+        if (fd.split && knobs().density_wide && Q >= 128ll * 1024)
             hipLaunchKernelGGL((k_density<true, 8>), dim3(min(num_cus(), grid_for(Q, 128))), dim3(kThreads), kLdsDensityWide, s, fd,
                                pts, (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1],
                                &w.ctr->n_sdf_fwd, &w.ctr->n_density);
@@ -3995,11 +4024,7 @@ static ColNetT colT_of(const ArahFrame& f) {
 // gets the all-fp32 kernels in training as in inference (round 4: it used to follow the environment only).
 // ARAH_TRAIN_ENGINE=fp32 (read once, immutable) forces them for split frames too.
 static bool train_b3(const ArahFrame& f) {
-    static const bool env_on = [] {
-        const char* e = getenv("ARAH_TRAIN_ENGINE");
-        return !(e && strcmp(e, "fp32") == 0);
-    }();
-    return env_on && f.precision == ARAH_PRECISION_SPLIT_F16;
+    return knobs().train_b3 && f.precision == ARAH_PRECISION_SPLIT_F16;
 }
 
 size_t arah_shade_train_slab_bytes(void) { return (size_t)kMaxGrid / 2 * kTrainSlabPerWg * sizeof(f32x4); }

@@ -48,6 +48,33 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_library_keeps_no_mutable_process_state():
+    """Re-entrancy: the shared object's writable data is the kernel stubs of the HIP runtime plus a short list of
+    write-once items (tuning knobs read at first use, per-device attribute setup under call_once, the CU-count cache)."""
+    import subprocess
+    import __graft_entry__ as g
+    g.build()
+    so = os.path.join(REPO, "arah_release_amd", "libarah_hip.so")
+    out = subprocess.run(["nm", "-C", so], capture_output=True, text=True, check=True).stdout
+    allowed = ("knobs()::k", "setup_attributes()::once", "setup_attributes()::rc", "num_cus()::cus", "g_attr_failed",
+               "guard variable for (anonymous namespace)::knobs()::k")
+    runtime = ("__hip", "__do_init", "__do_fini", "__init", "__fini", "_GLOBAL_OFFSET_TABLE_", "DW.ref", "__dso_handle",
+               "completed", "__TMC_END__", "_DYNAMIC", "__bss_start", "_edata", "_end", "__data_start")
+    stray = []
+    for line in out.splitlines():
+        parts = line.split(None, 2)
+        if len(parts) < 3 or parts[1] not in "bBdD":
+            continue
+        name = parts[2]
+        if any(name.startswith(r) or name == r for r in runtime):
+            continue
+        if re.search(r"\bk_[a-z0-9_]+(<.*>)?(\(|$)", name):   # kernel handles registered with the HIP runtime
+            continue
+        if not any(a in name for a in allowed):
+            stray.append(name)
+    assert not stray, stray
+
+
 def test_struct_sizes_match_header():
     """ctypes mirrors of the POD structs must have the C layout (pointer + int32/float fields)."""
     import ctypes as C
