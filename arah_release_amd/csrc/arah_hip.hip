@@ -2523,6 +2523,12 @@ __global__ __launch_bounds__(kThreads) void k_color_eval(FrameDev fr, const floa
 }
 
 // IDR:284-289, 370-394: left-pack the valid samples of a ray and integrate.
+// A thread owns a ray and walks its S samples in order (the products of the transmittance are sequential).  CHUNK (S a
+// multiple of 8): the 8 samples of a 128-byte line of `shaded` (and their depths and mask bytes) are requested together
+// and then consumed -- sample by sample every lane touched its own line 8 times with the other 63 lanes' lines in
+// between, and the lines did not survive in L1: 1.1 GB of fetches per frame for 0.18 GB of operands
+// (profiles/r04b_pmc_traffic.json).  Same arithmetic in the same order.
+template <bool CHUNK>
 __global__ void k_composite(int n, int S, int render_last_pt, const float* z, const uint8_t* mask,
                             const f32x4* shaded, float* rgb, float* acc, uint8_t* vol_mask) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2533,12 +2539,11 @@ __global__ void k_composite(int n, int S, int render_last_pt, const float* z, co
     f32x4 ps = {0.f, 0.f, 0.f, 0.f};
     float pz = 0.f;
     bool any = false;
-    for (int s = 0; s <= S; ++s) {
-        const bool valid = s < S && mask[(size_t)i * S + s] != 0;
-        if (!(valid || s == S)) continue;
+    // one valid sample (s < S: its depth zs and shaded value sh) or the end of the ray (s == S)
+    auto step = [&](int s, float zs, const f32x4 sh) {
         if (prev >= 0) {
             float delta;
-            if (s < S) delta = z[(size_t)i * S + s] - pz;
+            if (s < S) delta = zs - pz;
             else delta = render_last_pt ? 1e10f : inv_steps;           // last valid sample (IDR:379-385)
             const float alpha = 1.0f - expf(-ps[3] * delta);
             const float w = alpha * trans;
@@ -2550,11 +2555,29 @@ __global__ void k_composite(int n, int S, int render_last_pt, const float* z, co
         }
         if (s < S) {
             prev = s;
-            ps = shaded[(size_t)i * S + s];
-            pz = z[(size_t)i * S + s];
+            ps = sh;
+            pz = zs;
             any = true;
         }
+    };
+    const size_t base = (size_t)i * S;
+    if (CHUNK) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        for (int s0 = 0; s0 < S; s0 += 8) {
+            const u32x2 m8 = *reinterpret_cast<const u32x2*>(mask + base + s0);
+            const f32x4 z0 = *reinterpret_cast<const f32x4*>(z + base + s0), z1 = *reinterpret_cast<const f32x4*>(z + base + s0 + 4);
+            f32x4 sh[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sh[u] = shaded[base + s0 + u];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (((u < 4 ? m8[0] : m8[1]) >> (8 * (u & 3))) & 0xffu) step(s0 + u, u < 4 ? z0[u & 3] : z1[u & 3], sh[u]);
+        }
+    } else {
+        for (int s = 0; s < S; ++s)
+            if (mask[base + s] != 0) step(s, z[base + s], shaded[base + s]);
     }
+    step(S, 0.f, ps);
     rgb[(size_t)i * 3] = any ? r : 0.f;
     rgb[(size_t)i * 3 + 1] = any ? g : 0.f;
     rgb[(size_t)i * 3 + 2] = any ? b : 0.f;
@@ -3961,7 +3984,10 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
                       lds_shade<false>(), s, fd, S, cfg->cano_view_dirs, dirs, pts, T, slist, scount, 0, w.shaded, w.spill,
                       &w.ctr->n_sdf_fwd, &w.ctr->n_sdf_grad, &w.ctr->n_col, b3);
     if (cfg->ev_shade[0] && cfg->ev_shade[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_shade[1]), s);
-    hipLaunchKernelGGL(k_composite, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
+    const bool chunk = S % 8 == 0 && (reinterpret_cast<uintptr_t>(z) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 7) == 0;
+    if (chunk) hipLaunchKernelGGL(k_composite<true>, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
+                       (const f32x4*)w.shaded, rgb, acc, vol_mask);
+    else hipLaunchKernelGGL(k_composite<false>, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->render_last_pt, z, mask,
                        (const f32x4*)w.shaded, rgb, acc, vol_mask);
     return check_launch();
 }
