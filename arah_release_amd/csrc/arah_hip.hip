@@ -2356,13 +2356,13 @@ __global__ __launch_bounds__(kThreads) void k_shade(FrameDev fr, int S, int cano
         __syncthreads();
         clk.mark(0);
         f32x4 dlast[kSdfMT][kNT];
-        sdf_trunk<true, kNT, SPLIT, NoTap, KernelClk, 2>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane, NoTap(), &clk);
+        sdf_trunk<true, kNT, SPLIT, NoTap, KernelClk, 2, !B3>(fr.sdf, xin, actA, ldA, spill, dlast, wave, lane, NoTap(), &clk);
         clk.mark(1);
         sdf_head<SPLIT>(fr.sdf, actA, ldA, outv, 4, tid);
         if constexpr (B3) {
             resplit_rows_bf16(actA, ldA, loA, tid);   // the feature: f16 split planes -> bf16 planes
             clk.mark(2);
-            sdf_backward_bp(fr.sdf, b3, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid, &clk);
+            sdf_backward_bp(fr.sdf, b3, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid, &clk, xin);
         } else {
             if (SPLIT) unsplit_rows(actA, ldA, tid);   // the colour MLP (exact engine) reads the feature as fp32
             sdf_backward(fr.sdf, actB, kSdfLd, spill, dlast, outv, 4, wave, lane, tid);

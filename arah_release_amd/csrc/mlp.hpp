@@ -875,7 +875,9 @@ __device__ __forceinline__ void stream_rows_split(const float* lds, int ld, floa
 // pc: phase clocks of an instrumented build (tools/phase_clocks.py), nothing otherwise
 #define ARAH_PC_MARK(i) do { if (pc) pc->mark(i); } while (0)
 // PIPE > 0 (k_shade, two waves per SIMD): the gradient trunk's products on the explicit pipeline too, NT / PIPE N-tiles per stage
-template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap, typename CLK = NoClk, int PIPE = 0>
+// KEEP0 = false (k_shade's bf16 x 3 sweep): the first layer's derivative factors are not written to the slab, the sweep
+// recomputes them from x (layer0_dfactor: three FMAs and a sine/cosine per channel, the same instructions, the same bits)
+template <bool GRAD, int NT = kNT, bool SPLIT = false, typename TAP = NoTap, typename CLK = NoClk, int PIPE = 0, bool KEEP0 = true>
 __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, float* act, int ld, f32x4* spill,
                                           f32x4 (&dlast)[kSdfMT][NT], int wave, int lane, const TAP& tap = TAP(),
                                           CLK* pc = nullptr) {
@@ -909,7 +911,7 @@ __device__ __forceinline__ void sdf_trunk(const SdfNet& net, const float* xin, f
                 if (SPLIT) store_split4(act, ld, 512, n * 16 + j, ch0, h);
                 else *reinterpret_cast<f32x4*>(act + (n * 16 + j) * ld + ch0) = h;
 #ifndef ARAH_ABL_NO_SLAB
-                if (GRAD) spill[((0 * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
+                if (GRAD && KEEP0) spill[((0 * kWaves + wave) * (kSdfMT * NT) + m * NT + n) * 64 + lane] = d;
 #endif
             }
         }
@@ -1527,11 +1529,30 @@ __device__ __forceinline__ void resplit_rows_bf16(float* act, int ld, int lo_off
     }
 }
 
+// d_0 = 30 f cos(z_0) of the wave's channels (M-tile m) at N-tile n, exactly as sdf_trunk's first layer computes it
+__device__ __forceinline__ f32x4 layer0_dfactor(const SdfNet& net, const float* xin, int mt0, int m, int n, int lane) {
+    const int j = lane & 15, g = lane >> 4;
+    const int ch0 = (mt0 + m) * 16 + 4 * g;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(xin + (n * 16 + j) * 4);
+    const f32x4 fw = *reinterpret_cast<const f32x4*>(net.fw + ch0);
+    const f32x4 pw = *reinterpret_cast<const f32x4*>(net.pw + ch0);
+    const f32x4 f = *reinterpret_cast<const f32x4*>(net.freq + ch0);
+    f32x4 v, h, d;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(net.w0 + (ch0 + r) * 4);
+        v[r] = fmaf(w[2], x[2], fmaf(w[1], x[1], w[0] * x[0]));
+    }
+    no_pack(v);
+    film_sine<true>(v, fw, pw, f, 1.0f, h, d);
+    return d;
+}
+
 // sdf_backward with the sweep's activations as bf16 planes in `bwd` (rows of ld floats, lo plane at byte 512)
 template <typename CLK = NoClk>
 __device__ __forceinline__ void sdf_backward_bp(const SdfNet& net, const B3Nets& b3, float* bwd, int ld, const f32x4* spill,
                                                 const f32x4 (&dlast)[kSdfMT][kNT], float* out, int ostride, int wave,
-                                                int lane, int tid, CLK* pc = nullptr) {
+                                                int lane, int tid, CLK* pc = nullptr, const float* xin = nullptr) {
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
 #pragma unroll
@@ -1559,7 +1580,8 @@ __device__ __forceinline__ void sdf_backward_bp(const SdfNet& net, const B3Nets&
 #ifdef ARAH_ABL_NO_SLAB
                 dk[m][n] = dlast[m][n];
 #else
-                dk[m][n] = spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane];
+                dk[m][n] = k == 0 && xin ? layer0_dfactor(net, xin, mt0, m, n, lane)
+                                         : spill[((k * kWaves + wave) * (kSdfMT * kNT) + m * kNT + n) * 64 + lane];
 #endif
         gemm_acc_bsplit<8, kSdfMT>(b3.sdf_wpT[k], mt0, bwd, ld, 512, acc, lane);
         ARAH_PC_MARK(10);
