@@ -364,11 +364,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 // sched_group_barrier pins the interleaving: one memory instruction between every two MFMAs.  Registers: two stages of B
 // (4 NT/H quads) + two chunks of A (4 MT quads) next to the MT NT accumulators.
 // FR: f16x8 (the f16 split) or bf16x8 (bf16 x 3, loop D's reverse sweep and colour MLP)
-typedef __bf16 bf16x8_fr __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x4 mfma_frag(const f16x8 a, const f16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ f32x4 mfma_frag(const bf16x8_fr a, const bf16x8_fr b, const f32x4 c) {
+__device__ __forceinline__ f32x4 mfma_frag(const bf16x8 a, const bf16x8 b, const f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 template <int KC32, int MT, int NT, int H, typename FR = f16x8>
@@ -458,7 +458,6 @@ __device__ __forceinline__ void gemm_acc_split_pipe(const FR* __restrict__ wp, i
 // fp32 in LDS exactly where the fp32 engine reads them; a lane converts its eight consecutive k of a point as it loads them
 // (three vector instructions per element), so a call site only swaps gemm_acc for gemm_any<true, ..>.  Rate: 3 x 16
 // cycles per 16x16x32 product against 8 x 32 on the fp32 MFMA.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct B3Nets {                 // bf16 hi/lo fragments of the packed matrices (k_b3_from_packed), same M-tile / K order
     const bf16x8* sdf_wp[5];    // W_2..W_6 (tangent pass)
