@@ -509,7 +509,7 @@ def render_sequence(model, frames, n_streams=3, **forward_kwargs):
     # The caller's stream is drained once, here, and a stream takes its next frame only when its previous one has
     # finished: at most n_streams frames (~250 launches each) are ever queued.  Not a nicety -- with the caller's stream
     # still busy and a thousand launches queued behind a cross-stream wait, the HIP runtime (ROCm 7.2) stops accepting
-    # launches and never resumes (the host blocks inside hipLaunchKernel; reproduced by tools/_seq_debug.py "prenosync").
+    # launches and never resumes (the host blocks inside hipLaunchKernel; reproduced by tools/probes/seq_debug.py "prenosync").
     cur.synchronize()
     outs, done = [], []
     with torch.no_grad():
