@@ -45,6 +45,7 @@ if [ "$2" = "pmc" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     ARAH_FULL_SHADING=1 timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmcfull_$C -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/pmcfull_$C.log 2>&1
   done
+  ARAH_FULL_SHADING=1 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmcfull_SQ -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/pmcfull_SQ.log 2>&1
   cd $ROOT
   big() { ls -S $(find $1 -name "*.db") 2>/dev/null | head -1; }
   F=$(big $OUT/pmc_FETCH_SIZE); W=$(big $OUT/pmc_WRITE_SIZE)
@@ -53,7 +54,9 @@ if [ "$2" = "pmc" ]; then
   [ -n "$F" ] && [ -n "$W" ] && python tools/rocpd_pmc.py $F $W > $OUT/pmc_traffic_full.json
   S=$(big $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES)
   [ -n "$S" ] && python tools/rocpd_sq.py $S > $OUT/pmc_sq.json
+  S=$(big $OUT/pmcfull_SQ)
+  [ -n "$S" ] && python tools/rocpd_sq.py $S > $OUT/pmc_sq_full.json
   # the databases are large: keep the summaries only
-  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmcfull_FETCH_SIZE $OUT/pmcfull_WRITE_SIZE
+  rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_VALU_MFMA_BUSY_CYCLES $OUT/pmcfull_FETCH_SIZE $OUT/pmcfull_WRITE_SIZE $OUT/pmcfull_SQ
 fi
 rm -rf $OUT/prof
