@@ -196,6 +196,11 @@ class IDHRNetwork(nn.Module):
         # range guard of the split engine (ArahCounters.n_split_nonfinite): see _split_guard
         self.split_nonfinite = 0
         self._guard = {}
+        # "lazy" (default): the count of frame k is looked at when frame k + 1 starts -- no stream drain, frame k itself is
+        # returned as rendered (with a warning).  "strict" (ARAH_SPLIT_GUARD=strict): the count is read behind every frame
+        # (one synchronisation per frame) and a frame that tripped it is rendered AGAIN on the exact fp32 engine before it
+        # is returned.
+        self.guard_mode = os.environ.get("ARAH_SPLIT_GUARD", "lazy")
         self.precision = None    # GEMM engine frames are prepared for: None = the process default (ARAH_PRECISION, split),
                                  # hip.PRECISION_FP32 / PRECISION_SPLIT_F16 = this renderer's own choice (bench.py's passes)
         self._precision = None   # becomes hip.PRECISION_FP32 once the range guard has fired: overrides `precision`
@@ -326,10 +331,28 @@ class IDHRNetwork(nn.Module):
                             body_tables=input.get("_body_tables"))
         self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
+        pose34 = pose[0, :3, :4].detach().float().contiguous()
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
-                                                      ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2),
-                                                      pose[0, :3, :4].detach().float().contiguous())
-        if guard is not None:
+                                                      ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
+        if guard is not None and self.guard_mode == "strict" and frame.precision != hip.PRECISION_FP32:
+            now = int(ws.buf[64:72].view(torch.int64).item())   # ArahCounters.n_split_nonfinite; synchronises the stream
+            grew = now - guard["seen"] if now >= guard["seen"] else now
+            guard["seen"] = now
+            if grew > 0:
+                import warnings
+                warnings.warn("split-f16 engine: %d loop-C samples met activations outside the f16 range; this frame is rendered "
+                              "again on the exact fp32 engine, and so are the following ones" % grew)
+                self.split_nonfinite += grew
+                self._precision = hip.PRECISION_FP32
+                frame = build_frame(input["sdf_network"], self.skinning_model, self.rendering_network,
+                                    self.deviation_network, input["pose_cond"], input["smpl_verts"],
+                                    input["skinning_weights"], input["bone_transforms"], input["trans"],
+                                    input["coord_min"], input["coord_max"], input["center"],
+                                    precision=hip.PRECISION_FP32, body_tables=input.get("_body_tables"))
+                self.last_frame = frame
+                rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
+                                                              ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
+        elif guard is not None:
             self._split_guard_arm(guard, ws)
         pcam = pcam.reshape(B, N, 3)
         if B > 1:   # per-view camera pose for the remaining batch elements (IDR:114-115)

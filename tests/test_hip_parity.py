@@ -812,6 +812,44 @@ def test_split_engine_matches_exact_fp32_engine(scene):
 
 
 @gpu
+def test_strict_range_guard_renders_the_frame_again(scene, monkeypatch):
+    """guard_mode "strict": a frame whose loop C counted activations outside the f16 range is rendered again on the exact
+    fp32 engine before it is returned.  The counter is tripped by hand behind the first render (no network of the synthetic
+    subject leaves the range): the returned image must be the fp32 engine's, bit for bit, and later frames stay on it."""
+    import warnings
+    from arah_release_amd import config, hip
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model("zju377_mono", device=dev)
+    model.eval()
+    net = model.idhr_network
+    inputs = scene.make_inputs(96, 96, frame_idx=2, device=dev)
+    with torch.no_grad():
+        net.precision = hip.PRECISION_FP32
+        want = model(dict(inputs), eval=True)["rgb_values"].clone()
+        net.precision = None
+        plain = model(dict(inputs), eval=True)["rgb_values"].clone()
+    assert not torch.equal(plain, want)   # the two engines differ in the last bits
+    real, calls = hip.render, []
+
+    def tripping(frame, ws, *a, **k):
+        out = real(frame, ws, *a, **k)
+        if not calls:
+            ws.buf[64:72].view(torch.int64).add_(7)   # ArahCounters.n_split_nonfinite
+        calls.append(frame.precision)
+        return out
+
+    monkeypatch.setattr(hip, "render", tripping)
+    net.guard_mode = "strict"
+    with torch.no_grad(), warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        got = model(dict(inputs), eval=True)["rgb_values"]
+        again = model(dict(inputs), eval=True)["rgb_values"]
+    assert calls == [hip.PRECISION_SPLIT_F16, hip.PRECISION_FP32, hip.PRECISION_FP32]
+    assert net.split_nonfinite == 7 and any("fp32" in str(w.message) for w in caught)
+    assert torch.equal(got, want) and torch.equal(again, want)
+
+
+@gpu
 @pytest.mark.parametrize("engine", ["split", "fp32"])
 @pytest.mark.parametrize("name", ["zju377_mono", "h36m"])
 def test_render_is_reproducible_under_load(scene, engine, name):
