@@ -502,7 +502,17 @@ def _walk_tensors(obj):
             yield from _walk_tensors(v)
 
 
-def render_sequence(model, frames, n_streams=3, **forward_kwargs):
+def frames_in_flight(n_frames):
+    """How many frames of a sequence render_sequence keeps in flight by default: every further frame hides more of the
+    kernels' tails and of the latency-bound finishers under other frames' wide kernels (512x512, 20-frame passes on one
+    MI355X: 36.4 / 35.4 / 34.7 / 34.3 ms per frame with 3 / 4 / 5 / 6 in flight), but a short sequence must still fill the
+    streams evenly (8 frames: 36.2 / 34.9 / 35.4 with 3 / 4 / 5).  Five from fifteen frames on, four below; 150
+    consecutive eight-frame passes with 4, 5 and 6 in flight came back clean and bit-identical
+    (tools/stress_streams.py, profiles/r04c_streams_soak.txt)."""
+    return max(1, min(5 if n_frames >= 15 else 4, n_frames))
+
+
+def render_sequence(model, frames, n_streams=None, **forward_kwargs):
     """Render independent frames (a test sequence, reference test.py / lightning_model.py:320) with `n_streams` of them in
     flight: frame k runs on HIP stream k mod n_streams with its own scratch, so that the latency-bound stretches of one
     frame (the tails of sphere tracing and of the joint root find: a few hundred live rays, ~60 us of kernel latency per
@@ -511,16 +521,17 @@ def render_sequence(model, frames, n_streams=3, **forward_kwargs):
     on the caller's stream.
     Round 2 saw the HIP runtime of this image (ROCm 7.2) stop accepting launches with a thousand launches queued behind
     a cross-stream wait; the loop below never lets that state arise (the caller's stream is drained once at the start,
-    a stream takes its next frame only when its previous one has finished: at most n_streams frames, ~450 launches
+    a stream takes its next frame only when its previous one has finished: at most n_streams frames, ~270 launches
     each, are ever queued), and three frames in flight became the default after 200 consecutive eight-frame passes
-    (1600 frames, bit-identical images) came back clean (tools/stress_streams.py, profiles/r03_streams_soak.txt).
+    (1600 frames, bit-identical images) came back clean (tools/stress_streams.py, profiles/r03_streams_soak.txt);
+    round 4: n_streams=None = frames_in_flight(len(frames)), four or five.
     frames: iterable of input dicts (resident on one GPU); returns the list of output dicts, usable on the caller's
     current stream.  model(inputs, **forward_kwargs) is called under torch.no_grad()."""
     frames = list(frames)
     if not frames:
         return []
     dev = next((t.device for t in _walk_tensors(frames[0]) if t.is_cuda), None)
-    n_streams = max(1, int(n_streams))
+    n_streams = frames_in_flight(len(frames)) if n_streams is None else max(1, int(n_streams))
     if n_streams == 1 or dev is None:   # (host-resident inputs: the model raises for want of a GPU, as it always does)
         with torch.no_grad():
             return [model(f, **forward_kwargs) for f in frames]

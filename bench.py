@@ -131,11 +131,12 @@ def main():
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight in the timed region of every pass (renderer.render_sequence: frame k on HIP stream "
-                         "k mod N, own scratch each) -- the product's default since the 200-pass soak of round 3 "
-                         "(profiles/r03_streams_soak.txt); 1 = strictly one frame after the other (also measured, first, "
-                         "and reported as 'one_frame_at_a_time')")
+                         "k mod N, own scratch each); 0 = the product's default for a sequence of --steps frames "
+                         "(renderer.frames_in_flight: four, five from fifteen frames on; soaks in profiles/r03_streams_soak.txt, "
+                         "r04c_streams_soak.txt); 1 = strictly one frame after the other (also measured, first, and reported "
+                         "as 'one_frame_at_a_time')")
     ap.add_argument("--pipelined-streams", type=int, default=0,
                     help="with --streams 1 only: after everything else, the default path once more with this many frames in "
                          "flight, under a watchdog (object 'frames_in_flight'); 0 = skip")
@@ -166,8 +167,10 @@ def main():
         __graft_entry__.build()
     if world > 1:
         dist.barrier()
-    from arah_release_amd import config, hip, synthetic
+    from arah_release_amd import config, hip, renderer, synthetic
 
+    if args.streams <= 0:
+        args.streams = renderer.frames_in_flight(args.steps)
     near = far = args.n_steps // 4
     model, cfg = config.build_synthetic_model(args.config, args.n_steps, near, far, device=dev)
     if args.beta is not None:

@@ -9,7 +9,7 @@ gpu = pytest.mark.gpu
 
 @gpu
 @pytest.mark.timeout(150)
-@pytest.mark.parametrize("n_streams", [2, 3])
+@pytest.mark.parametrize("n_streams", [2, 3, None])
 def test_render_sequence_matches_frame_by_frame(scene, n_streams):
     """renderer.render_sequence keeps several frames in flight (frame k on stream k mod n, own scratch): every frame's
     outputs are bit-identical to rendering the frames one after the other, in order, for ragged frame sizes."""
@@ -30,4 +30,4 @@ def test_render_sequence_matches_frame_by_frame(scene, n_streams):
     assert renderer.render_sequence(model, [], n_streams=n_streams) == []
     one = renderer.render_sequence(model, [dict(frames[0])], n_streams=1, eval=True)
     assert torch.equal(one[0]["rgb_values"], ref[0]["rgb_values"])
-    assert len(model.idhr_network.ray_tracer.workspaces()) >= n_streams
+    assert len(model.idhr_network.ray_tracer.workspaces()) >= (n_streams or renderer.frames_in_flight(len(frames)))
