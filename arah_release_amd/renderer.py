@@ -527,15 +527,23 @@ def render_sequence(model, frames, n_streams=None, **forward_kwargs):
     round 4: n_streams=None = frames_in_flight(len(frames)), four or five.
     frames: iterable of input dicts (resident on one GPU); returns the list of output dicts, usable on the caller's
     current stream.  model(inputs, **forward_kwargs) is called under torch.no_grad()."""
-    frames = list(frames)
-    if not frames:
+    return map_in_flight(lambda f: model(f, **forward_kwargs), frames, n_streams=n_streams, owner=model)
+
+
+def map_in_flight(fn, items, n_streams=None, owner=None):
+    """[fn(item) for item in items] with `n_streams` of the calls in flight: call k runs on HIP stream k mod n_streams (the
+    renderer's scratch is per stream), under torch.no_grad().  The loop of render_sequence, for any per-frame function --
+    the test sequence's test_step (render + canonical mesh + normal maps) goes through it too.  `owner`: the object the
+    streams are cached on."""
+    items = list(items)
+    if not items:
         return []
-    dev = next((t.device for t in _walk_tensors(frames[0]) if t.is_cuda), None)
-    n_streams = frames_in_flight(len(frames)) if n_streams is None else max(1, int(n_streams))
+    dev = next((t.device for t in _walk_tensors(items[0]) if t.is_cuda), None)
+    n_streams = frames_in_flight(len(items)) if n_streams is None else max(1, int(n_streams))
     if n_streams == 1 or dev is None:   # (host-resident inputs: the model raises for want of a GPU, as it always does)
         with torch.no_grad():
-            return [model(f, **forward_kwargs) for f in frames]
-    cache = model.__dict__.setdefault("_sequence_streams", {})
+            return [fn(f) for f in items]
+    cache = (owner.__dict__ if owner is not None else globals()).setdefault("_sequence_streams", {})
     if (dev, n_streams) not in cache:
         cache[(dev, n_streams)] = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     streams = cache[(dev, n_streams)]
@@ -547,7 +555,7 @@ def render_sequence(model, frames, n_streams=None, **forward_kwargs):
     cur.synchronize()
     outs, done = [], []
     with torch.no_grad():
-        for k, inp in enumerate(frames):
+        for k, inp in enumerate(items):
             st = streams[k % n_streams]
             if k >= n_streams:
                 done[k - n_streams].synchronize()
@@ -555,7 +563,7 @@ def render_sequence(model, frames, n_streams=None, **forward_kwargs):
                 if t.is_cuda:
                     t.record_stream(st)
             with torch.cuda.stream(st):
-                outs.append(model(inp, **forward_kwargs))
+                outs.append(fn(inp))
                 ev = torch.cuda.Event()
                 ev.record(st)
                 done.append(ev)

@@ -47,8 +47,13 @@ def apply_overrides(cfg, args):
 def render(lm, dataset, device, rank=0, world=1):
     """Frames rank, rank + world, ... of the dataset through test_step; returns the written files.  A single process
     replaces an existing vis directory like the reference; with several, rank 0 has done that before anyone renders."""
+    from . import renderer
     lm = lm.to(device).eval()
-    outs = [lm.test_step(dataset.item(i, device)) for i in range(rank, len(dataset), world)]
+    mine = list(range(rank, len(dataset), world))
+    outs = []
+    for c in range(0, len(mine), 20):   # twenty frames resident at a time, renderer.frames_in_flight of them in flight
+        items = [dataset.item(i, device) for i in mine[c:c + 20]]
+        outs += renderer.map_in_flight(lm.test_step, items, owner=lm.model)
     return lm.test_epoch_end(outs, first_index=rank, index_stride=world, clear=(world == 1))
 
 
