@@ -288,11 +288,23 @@ class GpuRuntime:
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         rays = sum(int(f["ray_dirs"].shape[1]) for f in frames[warmup:])
-        return {"note": "MetaAvatarRender.forward(gen_cano_mesh=True, eval=True) as test.py calls it: render + canonical mesh "
+        line = {"note": "MetaAvatarRender.forward(gen_cano_mesh=True, eval=True) as test.py calls it: render + canonical mesh "
                         "(arah_sdf_grid 256^3, marching cubes, arah_skin_lbs) + output_normal / normal_cano_front / "
                         "normal_cano_back (arah_rasterize), one frame at a time",
                 "value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                 "outputs": sorted(k for k in out if k != "sdf_params")}
+        # the same frames the way arah_release_amd.test_sequence renders them: several in flight (renderer.map_in_flight)
+        from arah_release_amd import renderer
+        fn = lambda f: self.model(f, gen_cano_mesh=True, eval=True)   # noqa: E731
+        renderer.map_in_flight(fn, frames[:warmup], owner=self.model)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        renderer.map_in_flight(fn, frames[warmup:], owner=self.model)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        line["in_flight"] = {"frames_in_flight": renderer.frames_in_flight(steps), "value": rays / dt, "unit": "rays/s",
+                             "ms_per_step": 1e3 * dt / steps}
+        return line
 
     def training_line(self, steps=5, warmup=2):
         """Training step of BASELINE.json configs[2] (ZJUMOCAP-313 shapes, one view of 2048 rays on this GPU): forward
