@@ -502,13 +502,16 @@ def _walk_tensors(obj):
             yield from _walk_tensors(v)
 
 
+_FREE_STREAMS = {}   # streams of map_in_flight calls without an owner, per (device, count)
+
+
 def frames_in_flight(n_frames):
     """How many frames of a sequence render_sequence keeps in flight by default: every further frame hides more of the
     kernels' tails and of the latency-bound finishers under other frames' wide kernels (512x512, 20-frame passes on one
     MI355X: 36.4 / 35.4 / 34.7 / 34.3 ms per frame with 3 / 4 / 5 / 6 in flight), but a short sequence must still fill the
     streams evenly (8 frames: 36.2 / 34.9 / 35.4 with 3 / 4 / 5).  Five from fifteen frames on, four below; 150
     consecutive eight-frame passes with 4, 5 and 6 in flight came back clean and bit-identical
-    (tools/stress_streams.py, profiles/r04c_streams_soak.txt)."""
+    (tools/stress_streams.py, profiles/r04d_streams_soak.txt)."""
     return max(1, min(5 if n_frames >= 15 else 4, n_frames))
 
 
@@ -543,7 +546,7 @@ def map_in_flight(fn, items, n_streams=None, owner=None):
     if n_streams == 1 or dev is None:   # (host-resident inputs: the model raises for want of a GPU, as it always does)
         with torch.no_grad():
             return [fn(f) for f in items]
-    cache = (owner.__dict__ if owner is not None else globals()).setdefault("_sequence_streams", {})
+    cache = owner.__dict__.setdefault("_sequence_streams", {}) if owner is not None else _FREE_STREAMS
     if (dev, n_streams) not in cache:
         cache[(dev, n_streams)] = [torch.cuda.Stream(dev) for _ in range(n_streams)]
     streams = cache[(dev, n_streams)]
