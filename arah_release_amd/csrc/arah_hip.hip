@@ -663,7 +663,7 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_clusters(const GridInfo* 
                 const float d = fmaxf(fabsf(s[k] - lo[k]), fabsf(s[k] - hi[k]));
                 far2 += d * d;
             }
-            U = fminf(U, sqrtf(far2) + s[3]);
+            U = fminf(U, __builtin_amdgcn_sqrtf(far2) + s[3]);   // 1 ulp: the slack below covers it
         }
         U = U * 1.0001f + 1e-6f;
         int cnt = 0;
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(kCellThreads) void k_cell_clusters(const GridInfo* 
                 const float d = fmaxf(fmaxf(lo[k] - s[k], s[k] - hi[k]), 0.f);
                 near2 += d * d;
             }
-            const float lb = fmaxf(sqrtf(near2) - s[3], 0.f);
+            const float lb = fmaxf(__builtin_amdgcn_sqrtf(near2) - s[3], 0.f);
             if (lb <= U) {
                 if (cnt == 63) {
                     overflow = true;
@@ -739,9 +739,21 @@ __device__ __forceinline__ void scan_cluster(const float* sv, int c, V3 p, float
     }
 }
 
+// Distances of the search kernels' sphere tests.  sqrtf() is the correctly rounded sequence (~15 vector instructions) and
+// these kernels are vector-ALU bound (SQ_ACTIVE_INST_VALU of k_nearest_invlbs, profiles/r04c_pmc_sq.json); the tests only
+// need BOUNDS.  v_sqrt_f32 is good to 1 ulp, the sum of squares under it to another 1.5: a factor of 1 -+ 5e-7 brackets
+// the true distance, so a lower bound made from norm_lo never exceeds the true one (no cluster that can hold the nearest
+// vertex is skipped: the search stays exact) and an upper bound made from norm_hi never falls below it.
+__device__ __forceinline__ float norm_lo(float dx, float dy, float dz) {
+    return __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * 0.9999995f;
+}
+__device__ __forceinline__ float norm_hi(float dx, float dy, float dz) {
+    return __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz) * 1.0000005f;
+}
+
 __device__ __forceinline__ bool sphere_may_hold_nn(const f32x4 s, V3 p, float best) {
     const float dx = s[0] - p.x, dy = s[1] - p.y, dz = s[2] - p.z;
-    const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - s[3], 0.f);
+    const float lb = fmaxf(norm_lo(dx, dy, dz) - s[3], 0.f);
     return lb * lb <= best * 1.00001f + 1e-12f;   // slack covers the rounding of the bound itself
 }
 
@@ -823,7 +835,7 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const B
             for (int u = 0; u < 4; ++u) {
                 const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c[u]];
                 const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
-                const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - sp[3], 0.f);
+                const float lb = fmaxf(norm_lo(dx, dy, dz) - sp[3], 0.f);
                 lb2[u] = lb * lb;
             }
 #pragma unroll
@@ -841,7 +853,7 @@ __device__ __forceinline__ void nearest_invlbs_point(const FrameDev& fr, const B
         for (int c = 0; c < g.n_clusters; ++c) {
             const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c];
             const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
-            const float ub = sqrtf(dx * dx + dy * dy + dz * dz) + sp[3];
+            const float ub = norm_hi(dx, dy, dz) + sp[3];
             cap = fminf(cap, ub * ub * 1.00001f);
         }
 #pragma unroll 1
@@ -891,8 +903,7 @@ __device__ __forceinline__ int nearest_vertex_wave(const KnnData& kd, const Grid
         if (c >= 0) {
             const f32x4 sp = reinterpret_cast<const f32x4*>(kd.spheres)[c];
             const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
-            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-            const float lb = fmaxf(d - sp[3], 0.f), ub = d + sp[3];
+            const float lb = fmaxf(norm_lo(dx, dy, dz) - sp[3], 0.f), ub = norm_hi(dx, dy, dz) + sp[3];
             lb2 = lb * lb;
             ub2 = ub * ub * 1.00001f;   // some vertex of the cluster is at most this far
         }
@@ -964,7 +975,7 @@ __device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const f
             const int c = all ? k : (int)cl[1 + k];
             const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c];
             const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
-            const float ub = sqrtf(dx * dx + dy * dy + dz * dz) + sp[3];
+            const float ub = norm_hi(dx, dy, dz) + sp[3];
             cap = fminf(cap, ub * ub * 1.00001f);
         }
         if (!all) break;   // inside the grid the lists are ordered by distance: the first 16 spheres are bound enough
@@ -979,7 +990,7 @@ __device__ __forceinline__ int nearest_vertex_group16(const KnnData& kd, const f
             c = all ? k : (int)cl[1 + k];
             const f32x4 sp = reinterpret_cast<const f32x4*>(ssph)[c];
             const float dx = sp[0] - p.x, dy = sp[1] - p.y, dz = sp[2] - p.z;
-            const float lb = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz) - sp[3], 0.f);
+            const float lb = fmaxf(norm_lo(dx, dy, dz) - sp[3], 0.f);
             lb2 = lb * lb;
         }
         const unsigned long long m = __ballot(c >= 0 && lb2 <= fminf(best, cap) * 1.00001f + 1e-12f);
