@@ -722,21 +722,24 @@ struct KnnData {
     const unsigned char* cells;    // [n_cells][64]
 };
 
-// scan one cluster's vertices; lowest original index wins exact ties
+// scan one cluster's vertices; lowest original index wins exact ties.  (distance, index) travel as ONE 64-bit key -- the
+// bits of a non-negative float order like the float, so "d2 < best || (d2 == best && o < bi)" is a single unsigned 64-bit
+// compare and two selects instead of three compares, mask arithmetic and two selects: the kernels that walk clusters lane
+// by lane are vector-ALU bound on exactly this loop.
 template <int STRIDE>
 __device__ __forceinline__ void scan_cluster(const float* sv, int c, V3 p, float& best, int& bi) {
     const f32x4* v = reinterpret_cast<const f32x4*>(sv) + c * STRIDE;
+    unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)bi;
 #pragma unroll 7
     for (int u = 0; u < kClusterSize; ++u) {
         const f32x4 q = v[u];
         const float dx = q[0] - p.x, dy = q[1] - p.y, dz = q[2] - p.z;
         const float d2 = dx * dx + dy * dy + dz * dz;
-        const int o = __float_as_int(q[3]);
-        if (d2 < best || (d2 == best && o < bi)) {
-            best = d2;
-            bi = o;
-        }
+        const unsigned long long k = ((unsigned long long)__float_as_uint(d2) << 32) | __float_as_uint(q[3]);
+        key = k < key ? k : key;
     }
+    best = __uint_as_float((unsigned)(key >> 32));
+    bi = (int)(unsigned)key;
 }
 
 // Distances of the search kernels' sphere tests.  sqrtf() is the correctly rounded sequence (~15 vector instructions) and
