@@ -743,7 +743,7 @@ __device__ __forceinline__ void scan_cluster(const float* sv, int c, V3 p, float
 }
 
 // Distances of the search kernels' sphere tests.  sqrtf() is the correctly rounded sequence (~15 vector instructions) and
-// these kernels are vector-ALU bound (SQ_ACTIVE_INST_VALU of k_nearest_invlbs, profiles/r04c_pmc_sq.json); the tests only
+// these kernels are vector-ALU bound (SQ_ACTIVE_INST_VALU of k_nearest_invlbs, profiles/r04e_pmc_sq.json); the tests only
 // need BOUNDS.  v_sqrt_f32 is good to 1 ulp, the sum of squares under it to another 1.5: a factor of 1 -+ 5e-7 brackets
 // the true distance, so a lower bound made from norm_lo never exceeds the true one (no cluster that can hold the nearest
 // vertex is skipped: the search stays exact) and an upper bound made from norm_hi never falls below it.
