@@ -201,3 +201,11 @@ def test_pipelined_extra_adds_its_object_and_leaves_the_line_alone():
     assert abs(fi["value"] - rays / (fi["ms_per_step"] * 3 / 1e3)) < 1e-6 * fi["value"]
     # warm-up + one round of the streams, then the timed frames
     assert rt.rendered == [0, 1, 2, 3, 1, 2, 3]
+
+
+def test_frames_in_flight_default():
+    """renderer.frames_in_flight: never more streams than frames, four for short sequences, five from fifteen frames on."""
+    from arah_release_amd import renderer
+    assert [renderer.frames_in_flight(n) for n in (0, 1, 3, 4, 8, 14, 15, 20, 400)] == [1, 1, 3, 4, 4, 4, 5, 5, 5]
+    assert renderer.map_in_flight(lambda x: x + 1, []) == []
+    assert renderer.map_in_flight(lambda x: x + 1, [1, 2, 3]) == [2, 3, 4]      # host-resident items: plain map
