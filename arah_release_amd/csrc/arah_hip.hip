@@ -1178,7 +1178,7 @@ __global__ __launch_bounds__(kKnnThreads) void k_nearest_invlbs(FrameDev fr, Knn
         }
         return;
     }
-    // (sixteen lanes per query against this table: 5.2 ms for the 8.6e6-sample list, against 2.6 ms with a thread per query --
+    // (sixteen lanes per query against this table: 5.2 ms for the 8.6e6-sample list, against 2.6 ms with a thread per query (round 3; 1.15 ms since round 4's key compare) --
     // neighbouring samples walk the same clusters, so the serial walk's LDS reads are broadcasts; gpurun_out r3q)
     const int slot = (t & ~511) + ((t >> 3) & 7) * 64 + ((t >> 6) & 7) * 8 + (t & 7);
     for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
