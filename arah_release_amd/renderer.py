@@ -288,7 +288,7 @@ class IDHRNetwork(nn.Module):
         exact re-renders it)."""
         key = (dev, id(ws))   # one record per scratch = per stream with a frame in flight: each has its own counter
         g = self._guard.get(key)
-        if g is not None and g["event"].query():
+        if g is not None and self.guard_mode != "strict" and g["event"].query():   # (strict: read behind the frame itself)
             now = int(g["host"].item())
             grew = now - g["seen"] if now >= g["seen"] else now      # the counters may have been reset in between
             g["seen"] = now
@@ -352,7 +352,7 @@ class IDHRNetwork(nn.Module):
                 self.last_frame = frame
                 rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                               ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
-        elif guard is not None:
+        elif guard is not None and self.guard_mode != "strict":
             self._split_guard_arm(guard, ws)
         pcam = pcam.reshape(B, N, 3)
         if B > 1:   # per-view camera pose for the remaining batch elements (IDR:114-115)
