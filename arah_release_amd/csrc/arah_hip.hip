@@ -3470,7 +3470,9 @@ int arah_prepare_frame(const ArahNets* nets, const ArahBody* body, void* frame_b
     hipLaunchKernelGGL(k_skin_wave_consts, dim3(1), dim3(128), 0, s, raw, nets->skin_w[4], nets->skin_b[4],
                        (const unsigned*)amax_skin, P(L.skin_wconsts));
     // ---- body
-    if (!body->trans || !body->center || !body->coord_min || !body->coord_max) return ARAH_E_BADARG;
+    if (!body->trans || !body->center || !body->coord_min || !body->coord_max || !body->verts || !body->vert_weights ||
+        !body->bones)
+        return ARAH_E_BADARG;
     hipLaunchKernelGGL(k_gather_scalars, dim3(1), dim3(64), 0, s, P(L.scalars), body->trans, body->center, body->coord_min,
                        body->coord_max, nets->beta);
     // ---- body: k-d clustered vertices, cluster spheres, per-cell candidate clusters (exact 1-NN acceleration).  A caller
