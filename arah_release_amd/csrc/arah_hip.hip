@@ -1565,9 +1565,14 @@ struct CanonOut {
 constexpr int kSeedChunk = 64;   // seeds a wave takes from the queue per atomic
 
 // 25 gates (sigmoids; entries 1..3 and 12..14 unused) + the two 3-way softmaxes -> 24 weights along the SMPL tree
-// (utils/utils.py:138-181).  A gate q splits a parent's weight into child = parent q and parent (1 - q); the second is
-// written parent - child: one operation instead of two, and parent + child stays the weight that came in to the last bit
-// (the weights sum to one as exactly as the reference's do; each differs from its own (1 - q) product by one rounding).
+// (utils/utils.py:138-181).  A gate q splits a parent's weight into child = parent q and parent (1 - q).
+// SUB = false (the tile kernel k_canon_solve, i.e. the exact fp32 engine's loop C and the range guard's fallback): the
+// remaining parent weight is parent * (1 - q), the reference's own expression and the arithmetic of hsoftmax<T> /
+// hsoftmax_row (pointwise.hpp: loop B, arah_skin_lbs) -- every fp32-engine kernel blends with the same weights.
+// SUB = true (k_canon_wave only): parent - child, one operation instead of two; parent + child stays the weight that came in
+// to the last bit (the weights sum to one as exactly as the reference's do; each differs from its own (1 - q) product by
+// one rounding, up to ~6e-8 absolute where q is close to one).
+template <bool SUB>
 __device__ __forceinline__ void hsoftmax_tree(const float (&sgm)[25], float ra, float rb, float rc, float sa, float sb, float sc,
                                               float (&w)[24]) {
     const float g0 = sgm[0];
@@ -1577,7 +1582,7 @@ __device__ __forceinline__ void hsoftmax_tree(const float (&sgm)[25], float ra, 
     w[0] = 1.0f - g0;
     auto split = [&](int parent, int child, float q) {
         w[child] = w[parent] * q;
-        w[parent] = w[parent] - w[child];
+        w[parent] = SUB ? w[parent] - w[child] : w[parent] * (1.0f - q);
     };
 #pragma unroll
     for (int k = 0; k < 3; ++k) split(1 + k, 4 + k, sgm[4 + k]);     // hips / spine1 -> knees / spine2
@@ -1589,7 +1594,7 @@ __device__ __forceinline__ void hsoftmax_tree(const float (&sgm)[25], float ra, 
     w[12] = up * sa;
     w[13] = up * sb;
     w[14] = up * sc;
-    w[9] = w[9] - up;
+    w[9] = SUB ? w[9] - up : w[9] * (1.0f - sgm[24]);
     split(12, 15, sgm[15]);                                            // neck -> head
 #pragma unroll
     for (int lvl = 0; lvl < 4; ++lvl)   // 13,14 -> 16,17 -> 18,19 -> 20,21 -> 22,23
@@ -1598,7 +1603,8 @@ __device__ __forceinline__ void hsoftmax_tree(const float (&sgm)[25], float ra, 
 }
 
 // 25 raw logits of a slot -> 24 weights in registers; the four lanes of the slot share the 25 sigmoids through the
-// slot's LDS row (in place).  Same arithmetic as hsoftmax<float>(20 * logits).
+// slot's LDS row (in place).  Same arithmetic as hsoftmax<float>(20 * logits), the remaining parent weights included
+// (hsoftmax_tree<false>).
 // X20: the row already holds 20 x logit (k_canon_wave folds the factor into the accumulator's conversion).
 template <bool X20 = false>
 __device__ __forceinline__ void hsoftmax_quad(float* row, int g, float (&w)[24]) {
@@ -1620,7 +1626,7 @@ __device__ __forceinline__ void hsoftmax_quad(float* row, int g, float (&w)[24])
     float sgm[25];
 #pragma unroll
     for (int i = 0; i < 25; ++i) sgm[i] = row[i];
-    hsoftmax_tree(sgm, ra, rb, rc, sa, sb, sc, w);
+    hsoftmax_tree<false>(sgm, ra, rb, rc, sa, sb, sc, w);
 }
 
 // per-slot state block in LDS (floats): the Broyden state of the point in the slot between two passes
@@ -2720,6 +2726,9 @@ struct Knobs {
     int trace_bulk;      // ARAH_TRACE_BULK_STEPS  loop A steps launched wide before the finisher
     int trace_small;     // ARAH_TRACE_SMALL       ray lists up to this length go to the finisher at once
     bool density_wide;   // ARAH_DENSITY_TILE=128  128-point tiles in the density pass
+    int canon_lds_min;   // ARAH_CANON_LDS_MIN     loop C's point-owning-wave kernel asks for at least this much LDS (bytes): with
+                         //                        more than half of the CU's 160 KB a half-size build (-DCW_WAVES=4) owns one slot per CU
+    int canon_wg_per_cu; // ARAH_CANON_WG_PER_CU   resident workgroups of that kernel per CU (grid = this x CUs; 1)
     bool train_b3;       // ARAH_TRAIN_ENGINE!=fp32  bf16 x 3 / f16 split training kernels on split frames
 };
 inline const Knobs& knobs() {
@@ -2740,6 +2749,8 @@ inline const Knobs& knobs() {
         v.trace_bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 24)));
         v.trace_small = env_int("ARAH_TRACE_SMALL", 4096);
         v.density_wide = env_int("ARAH_DENSITY_TILE", 128) == 128;
+        v.canon_lds_min = max(0, min((int)kLdsCanonWave, env_int("ARAH_CANON_LDS_MIN", 0)));
+        v.canon_wg_per_cu = max(1, min(4, env_int("ARAH_CANON_WG_PER_CU", 1)));
         const char* e = getenv("ARAH_TRAIN_ENGINE");
         v.train_b3 = !(e && strcmp(e, "fp32") == 0);
         return v;
@@ -3730,7 +3741,7 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
     unsigned long long* const clk_arg = w.ctr->clk;
     if (fd.split && mode != 0) {
         long long gw = (max_pts + kCwWaves * kCwSlots - 1) / (kCwWaves * kCwSlots);
-        const int cus = num_cus();
+        const int cus = num_cus() * knobs().canon_wg_per_cu;
         if (gw > cus) gw = cus;
         if (gw < 1) gw = 1;
         // two instances are launched, one returns at once: whether the activations of this frame's skinning MLP need scaling
@@ -3743,10 +3754,11 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
                                (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
                                &w.ctr->n_split_nonfinite, clk_arg);
         } else {
-            hipLaunchKernelGGL((k_canon_wave<false, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
+            const size_t lds_l2 = max(kLdsCanonWave - kCwHiBytes, (size_t)knobs().canon_lds_min);
+            hipLaunchKernelGGL((k_canon_wave<false, false>), dim3((int)gw), dim3(kCwThreads), lds_l2, s, fd,
                                (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
                                &w.ctr->n_canon, &w.ctr->n_split_nonfinite, clk_arg);
-            hipLaunchKernelGGL((k_canon_wave<false, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave - kCwHiBytes, s, fd,
+            hipLaunchKernelGGL((k_canon_wave<false, true>), dim3((int)gw), dim3(kCwThreads), lds_l2, s, fd,
                                (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
                                &w.ctr->n_canon, &w.ctr->n_split_nonfinite, clk_arg);
         }

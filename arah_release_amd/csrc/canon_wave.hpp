@@ -99,7 +99,7 @@ __host__ __device__ constexpr CwParts cw_parts(int NT, int L, int kc, int mp) {
 constexpr int kCwLoDist = CW_LO_DIST, kCwHiDist = CW_HI_DIST;
 
 template <bool HI_LDS, bool SCALED>
-__global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
+__global__ __launch_bounds__(kCwThreads, kCwWaves >= 8 ? kCwWaves / 4 : 2) void k_canon_wave(FrameDev fr, const int* __restrict__ list, const int* count,
                                                               int* queue_head, CanonOut outp, unsigned long long* ctr,
                                                               unsigned long long* ctr_canon,
                                                               unsigned long long* ctr_bad, unsigned long long* clk_out) {
@@ -560,7 +560,7 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves / 4) void k_canon_wave(FrameDe
             float sgm[25];
 #pragma unroll
             for (int c = 0; c < 25; ++c) sgm[c] = c < 16 ? G0[c & 3][c >> 2] : G1[c & 3][(c & 15) >> 2];
-            hsoftmax_tree(sgm, GP[0][0], GP[1][0], GP[2][0], GP[0][3], GP[1][3], GP[2][3], w[t]);
+            hsoftmax_tree<true>(sgm, GP[0][0], GP[1][0], GP[2][0], GP[0][3], GP[1][3], GP[2][3], w[t]);
         }
         // (c) T on the matrix pipe: D[entry][point] += bones[joint][entry] w[joint][point] in six fp32 steps of four joints
         //     (an fmaf chain in joint order, like the loop it replaces) -- lane (j, g) supplies bones[4 s + g][entry j] and

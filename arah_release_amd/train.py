@@ -255,7 +255,7 @@ def main(argv=None, body=None, faces=None, log=print):
     params = [p for p in lm.model.parameters() if p.requires_grad]
     exchange = GradientExchange(params, world, dist)
     gen = torch.Generator(device=device)
-    gen.manual_seed(1234 + rank)
+    gen.manual_seed(1234 + rank + 1000 * (ckpt_epoch or 0) + 7919 * step)   # pixel sampling: a resumed run (also one stopped mid-epoch: same epoch, later step) draws a new sequence
     t_start = time.time()
     for epoch in range(epoch0, max_epochs):
         for idx in epoch_indices(len(dataset), epoch, rank, world):

@@ -269,6 +269,39 @@ class GpuRuntime:
     def split_engine(self):
         return self.hip.default_precision() == self.hip.PRECISION_SPLIT_F16
 
+    def beta_sweep(self, timed_inputs, warm_inputs, n_streams, n_steps, betas=(1e-3, 1e-2, 3e-2)):
+        """What exact lazy shading saves depends on the VolSDF beta, a LEARNED parameter (|deviation_decoder.variance|; 1e-3
+        is the reference's initial value, metaavatar_render/models/decoder.py:127-133): density is exactly 0 beyond 16.6 beta
+        from the surface, so the share of samples that need a normal and a colour grows with beta.  The same frames, the
+        product's default path (frames in flight), one short pass per beta; rays/s and shaded samples per ray."""
+        var = self.model.deviation_decoder.variance
+        keep = var.detach().clone()
+        rays = sum(int(i["ray_dirs"].shape[1]) for i in timed_inputs)
+        rows = []
+        try:
+            for b in betas:
+                with torch.no_grad():
+                    var.fill_(b)
+                    self.render_many(warm_inputs[:1] + timed_inputs[:n_streams], n_streams)
+                    self.device_sync()
+                    self.reset_counters()
+                    self.device_sync()
+                    t0 = time.perf_counter()
+                    self.render_many(timed_inputs, n_streams)
+                    self.device_sync()
+                    dt = time.perf_counter() - t0
+                c = self.counters()
+                rows.append({"beta": b, "value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / max(len(timed_inputs), 1),
+                             "shaded_samples_per_ray": c["n_col"] / max(rays, 1),
+                             "valid_samples_per_ray": c["n_density"] / max(rays, 1)})
+        finally:
+            with torch.no_grad():
+                var.copy_(keep)
+        return {"note": "the default path (exact lazy shading, %d frames in flight) on the same %d frames with the VolSDF beta "
+                        "overridden; beta = 1e-3 is the subject's own value (the reference's initial value).  With every valid "
+                        "sample shaded (value_full_shading) the figure does not depend on beta" % (n_streams, len(timed_inputs)),
+                "sweep": rows}
+
     def cpu_baseline(self, args, near, far):
         return cpu_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.cpu_sample_rays,
                             model_gpu=self.model, dev=self.dev)
@@ -568,6 +601,8 @@ def run(args, rt):
         # the reference shades every valid sample in fp32: the two reference-equivalent figures next to the headline
         line["value_full_shading"] = line["full_shading"]["value"] if "full_shading" in line else None
         line["value_strict"] = line["strict"]["value"] if "strict" in line else None
+        if world == 1 and args.passes == "all" and getattr(args, "beta", None) is None and hasattr(rt, "beta_sweep"):
+            line["beta_sweep"] = rt.beta_sweep(timed_inputs, warm_inputs, args.streams, args.n_steps)
         if world == 1 and not args.no_train:
             line["training"] = rt.training_line()
             line["test_py_frame"] = rt.test_py_frame(args.size)
