@@ -1373,8 +1373,11 @@ __global__ __launch_bounds__(kThreads, 4) void k_sdf_march(FrameDev fr, TraceSta
 // ------------------------------------------------------------------------------------------
 // unit seam: skinning weights / forward LBS
 // ------------------------------------------------------------------------------------------
+// n_items / per_item (arah_skin_lbs_counted): the number of points is min(n, *n_items * per_item), known on the device only
 __global__ __launch_bounds__(kThreads, 4) void k_skin_eval(FrameDev fr, const float* x_hat, int n, float* w_out,
-                                                         float* xbar_out, float* T_out, unsigned long long* ctr) {
+                                                         float* xbar_out, float* T_out, unsigned long long* ctr,
+                                                         const int* n_items = nullptr, int per_item = 1) {
+    if (n_items) n = (int)min((long long)n, (long long)max(*n_items, 0) * per_item);
     const BodyConst bc = load_bc(fr);
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [64][4] normalised
@@ -1851,6 +1854,7 @@ __global__ __launch_bounds__(kThreads, 4) void k_canon_solve(FrameDev fr, const 
 #endif
 }
 
+#include "mcubes.hpp"
 #include "canon_wave.hpp"
 
 // explicit targets (arah_broyden3_lbs): file them where k_canon_solve expects them, in row 3 of the start transform
@@ -2328,6 +2332,41 @@ __global__ __launch_bounds__(kThreads, NT > 4 ? 2 : 4) void k_density(FrameDev f
     }
 }
 
+// The SDF on the N^3 lattice of [-1,1]^3 (arah_sdf_grid) as 128-point tiles of the split engine: the trunk of k_density<true, 8>
+// (one workgroup per CU, the weight fragments fetched once per 128 points, the pipelined GEMM) with the lattice coordinates
+// formed in the kernel as k_sdf_eval forms them.  16.8 M points per test.py frame: 30.7 ms through k_sdf_eval's 64-point tiles.
+__global__ __launch_bounds__(kThreads, 2) void k_sdf_lattice(FrameDev fr, int grid_n, int n, float* __restrict__ sdf_out,
+                                                             unsigned long long* ctr_fwd) {
+    constexpr int NT = 8, TW = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;                                   // [TW][4]
+    float* outv = xin + TW * 4;                          // [TW][4]
+    float* actA = outv + TW * 4 + TW;                    // [TW][kSdfLd] (k_density's layout: an id array sits in between there)
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const float vs = (float)(2.0 / (double)(grid_n - 1));   // voxel_size is a Python float, rounded once (sdf_meshing.py:21)
+    for (int tile = blockIdx.x; tile * TW < n; tile += gridDim.x) {
+        if (tid < TW) {
+            const int id = tile * TW + tid;
+            f32x4 x = {0.f, 0.f, 0.f, 0.f};
+            if (id < n) {
+                const int iz = id % grid_n, iy = (id / grid_n) % grid_n, ix = id / (grid_n * grid_n);
+                float px = (float)ix * vs, py = (float)iy * vs, pz = (float)iz * vs;   // product and sum rounded separately: see k_sdf_eval
+                asm volatile("" : "+v"(px), "+v"(py), "+v"(pz));
+                x = f32x4{px + -1.0f, py + -1.0f, pz + -1.0f, 0.f};
+            }
+            reinterpret_cast<f32x4*>(xin)[tid] = x;
+        }
+        __syncthreads();
+        f32x4 dlast[kSdfMT][NT];
+        sdf_trunk<false, NT, true>(fr.sdf, xin, actA, kSdfLd, nullptr, dlast, wave, lane);
+        sdf_head<true>(fr.sdf, actA, kSdfLd, outv, 4, tid, TW);
+        __syncthreads();
+        if (tid == 0) count_add(ctr_fwd, min(TW, n - tile * TW));
+        if (tid < TW && tile * TW + tid < n) sdf_out[tile * TW + tid] = outv[tid * 4];
+        __syncthreads();
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // loop D: SDF value + normal (reverse sweep) + colour MLP + VolSDF density per valid sample
 // (IDR:291-368), then per-ray compositing (IDR:370-394)
@@ -2547,7 +2586,7 @@ __global__ __launch_bounds__(kThreads) void k_color_eval(FrameDev fr, const floa
 // multiple of 8): the 8 samples of a 128-byte line of `shaded` (and their depths and mask bytes) are requested together
 // and then consumed -- sample by sample every lane touched its own line 8 times with the other 63 lanes' lines in
 // between, and the lines did not survive in L1: 1.1 GB of fetches per frame for 0.18 GB of operands
-// (profiles/r04b_pmc_traffic.json).  Same arithmetic in the same order.
+// (profiles/r04a_pmc_traffic.json against r04e_pmc_traffic.json).  Same arithmetic in the same order.
 template <bool CHUNK>
 __global__ void k_composite(int n, int S, int render_last_pt, const float* z, const uint8_t* mask,
                             const f32x4* shaded, float* rgb, float* acc, uint8_t* vol_mask) {
@@ -2818,74 +2857,80 @@ constexpr size_t kLdsSplitSolo = 84 * 1024;
     } while (0)
 
 // hipFuncSetAttribute is per DEVICE: the raised dynamic-LDS limits are set once for every device ordinal a call
-// arrives on (the current device at the time of the call -- the host binding makes the buffers' device current), under a
-// std::call_once per device: first calls may arrive on several host threads at the same time.
-thread_local bool g_attr_failed = false;   // of the thread that runs the once-block
+// arrives on (the current device at the time of the call -- the host binding makes the buffers' device current), under
+// a mutex: first calls may arrive on several host threads at the same time.
+// A failure is NOT latched: a first call that arrives behind an earlier sticky HIP error fails, the next one tries again;
+// only success is remembered (one atomic flag per device, the setup itself under a mutex).
 template <typename K>
-inline void allow_lds(K kernel, size_t bytes) {
+inline void allow_lds(K kernel, size_t bytes, bool& failed) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)bytes) != hipSuccess)
-        g_attr_failed = true;
+        failed = true;
 }
 
 int setup_attributes_once();
 int setup_attributes() {
     constexpr int kMaxDevices = 64;
-    static std::once_flag once[kMaxDevices];
-    static int rc[kMaxDevices];
+    static std::atomic<bool> done[kMaxDevices];
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return ARAH_E_LAUNCH;
-    std::call_once(once[dev], [dev] { rc[dev] = setup_attributes_once(); });
-    return rc[dev];
+    if (done[dev].load(std::memory_order_acquire)) return ARAH_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done[dev].load(std::memory_order_relaxed)) return ARAH_OK;
+    const int rc = setup_attributes_once();
+    if (rc == ARAH_OK) done[dev].store(true, std::memory_order_release);
+    return rc;
 }
 
 int setup_attributes_once() {
-    g_attr_failed = false;
-    allow_lds(k_nearest_invlbs<SRC_POINTS>, kLdsKnn);
-    allow_lds(k_nearest_invlbs<SRC_RAYS>, kLdsKnn);
-    allow_lds(k_nearest_invlbs<SRC_SAMPLES>, kLdsKnn);
-    allow_lds(k_sdf_eval<false, false>, kLdsSdfFwd);
-    allow_lds(k_sdf_eval<false, true>, kLdsSplitSolo);
-    allow_lds(k_sdf_eval<true, false>, kLdsSdfGrad);
-    allow_lds(k_sdf_eval<true, true>, kLdsSdfGrad);
-    allow_lds(k_sdf_march<false>, kLdsSdfFwd);
-    allow_lds(k_sdf_march<true>, kLdsSplitSolo);
-    allow_lds(k_density<false>, kLdsSdfFwd);
-    allow_lds(k_density<true>, kLdsSplitSolo);
-    allow_lds(k_density<true, 8>, kLdsDensityWide);
-    allow_lds(k_skin_eval, kLdsSkin);
-    allow_lds(k_skin_jac, kLdsSkin);
-    allow_lds(k_canon_solve<false>, kLdsCanonSolve);
-    allow_lds(k_canon_solve<true>, kLdsSplitSolo);
-    allow_lds((k_canon_wave<true, false>), kLdsCanonWave);
-    allow_lds((k_canon_wave<true, true>), kLdsCanonWave);
-    allow_lds((k_canon_wave<false, false>), kLdsCanonWave);
-    allow_lds((k_canon_wave<false, true>), kLdsCanonWave);
-    allow_lds(k_joint_iter<true, false>, kLdsJoint);
-    allow_lds(k_joint_iter<true, true>, kLdsSplitSolo);
-    allow_lds(k_joint_iter<false, false>, kLdsJoint);
-    allow_lds(k_joint_iter<false, true>, kLdsSplitSolo);
-    allow_lds(k_trace_finish<true>, kLdsTraceFinish);
-    allow_lds(k_trace_finish<false>, kLdsTraceFinish);
-    allow_lds(k_joint_finish<true>, kLdsJointFinish);
-    allow_lds(k_joint_finish<false>, kLdsJointFinish);
-    allow_lds(k_shade<false, false>, lds_shade<false>());
-    allow_lds(k_shade<false, true>, lds_shade<false>());
-    allow_lds(k_shade<true, false>, lds_shade<true>());
-    allow_lds(k_shade<true, true>, lds_shade<true>());
-    allow_lds((k_shade<false, true, true>), lds_shade_b3<false>());
-    allow_lds((k_shade<true, true, true>), lds_shade_b3<true>());
-    allow_lds(k_color_eval<false>, lds_color<false>());
-    allow_lds(k_color_eval<true>, lds_color<true>());
-    allow_lds(k_shade_train<false, false, false>, lds_shade_train<false>());
-    allow_lds(k_shade_train<false, true, false>, lds_shade_train<false>());
-    allow_lds(k_shade_train<true, false, false>, lds_shade_train<true>());
-    allow_lds(k_shade_train<true, true, false>, lds_shade_train<true>());
-    allow_lds(k_shade_train<false, false, true>, lds_shade_train<false>());
-    allow_lds(k_shade_train<false, true, true>, lds_shade_train<false>());
-    allow_lds(k_shade_train<true, false, true>, lds_shade_train<true>());
-    allow_lds(k_shade_train<true, true, true>, lds_shade_train<true>());
-    return g_attr_failed ? ARAH_E_LAUNCH : ARAH_OK;
+    bool failed = false;
+    allow_lds(k_nearest_invlbs<SRC_POINTS>, kLdsKnn, failed);
+    allow_lds(k_nearest_invlbs<SRC_RAYS>, kLdsKnn, failed);
+    allow_lds(k_nearest_invlbs<SRC_SAMPLES>, kLdsKnn, failed);
+    allow_lds(k_sdf_eval<false, false>, kLdsSdfFwd, failed);
+    allow_lds(k_sdf_eval<false, true>, kLdsSplitSolo, failed);
+    allow_lds(k_sdf_eval<true, false>, kLdsSdfGrad, failed);
+    allow_lds(k_sdf_eval<true, true>, kLdsSdfGrad, failed);
+    allow_lds(k_sdf_march<false>, kLdsSdfFwd, failed);
+    allow_lds(k_sdf_march<true>, kLdsSplitSolo, failed);
+    allow_lds(k_density<false>, kLdsSdfFwd, failed);
+    allow_lds(k_density<true>, kLdsSplitSolo, failed);
+    allow_lds(k_density<true, 8>, kLdsDensityWide, failed);
+    allow_lds(k_sdf_lattice, kLdsDensityWide, failed);
+    allow_lds(k_skin_eval, kLdsSkin, failed);
+    allow_lds(k_skin_jac, kLdsSkin, failed);
+    allow_lds(k_canon_solve<false>, kLdsCanonSolve, failed);
+    allow_lds(k_canon_solve<true>, kLdsSplitSolo, failed);
+    allow_lds((k_canon_wave<true, false>), kLdsCanonWave, failed);
+    allow_lds((k_canon_wave<true, true>), kLdsCanonWave, failed);
+    allow_lds((k_canon_wave<false, false>), kLdsCanonWave, failed);
+    allow_lds((k_canon_wave<false, true>), kLdsCanonWave, failed);
+    allow_lds(k_joint_iter<true, false>, kLdsJoint, failed);
+    allow_lds(k_joint_iter<true, true>, kLdsSplitSolo, failed);
+    allow_lds(k_joint_iter<false, false>, kLdsJoint, failed);
+    allow_lds(k_joint_iter<false, true>, kLdsSplitSolo, failed);
+    allow_lds(k_trace_finish<true>, kLdsTraceFinish, failed);
+    allow_lds(k_trace_finish<false>, kLdsTraceFinish, failed);
+    allow_lds(k_joint_finish<true>, kLdsJointFinish, failed);
+    allow_lds(k_joint_finish<false>, kLdsJointFinish, failed);
+    allow_lds(k_shade<false, false>, lds_shade<false>(), failed);
+    allow_lds(k_shade<false, true>, lds_shade<false>(), failed);
+    allow_lds(k_shade<true, false>, lds_shade<true>(), failed);
+    allow_lds(k_shade<true, true>, lds_shade<true>(), failed);
+    allow_lds((k_shade<false, true, true>), lds_shade_b3<false>(), failed);
+    allow_lds((k_shade<true, true, true>), lds_shade_b3<true>(), failed);
+    allow_lds(k_color_eval<false>, lds_color<false>(), failed);
+    allow_lds(k_color_eval<true>, lds_color<true>(), failed);
+    allow_lds(k_shade_train<false, false, false>, lds_shade_train<false>(), failed);
+    allow_lds(k_shade_train<false, true, false>, lds_shade_train<false>(), failed);
+    allow_lds(k_shade_train<true, false, false>, lds_shade_train<true>(), failed);
+    allow_lds(k_shade_train<true, true, false>, lds_shade_train<true>(), failed);
+    allow_lds(k_shade_train<false, false, true>, lds_shade_train<false>(), failed);
+    allow_lds(k_shade_train<false, true, true>, lds_shade_train<false>(), failed);
+    allow_lds(k_shade_train<true, false, true>, lds_shade_train<true>(), failed);
+    allow_lds(k_shade_train<true, true, true>, lds_shade_train<true>(), failed);
+    return failed ? ARAH_E_LAUNCH : ARAH_OK;
 }
 
 // optional profiling hook: events recorded around the k_shade launch (bench.py's roofline leg)
@@ -3619,10 +3664,14 @@ int arah_sdf_grid(const ArahFrame* f, int32_t n_side, float* sdf, void* workspac
     const FrameDev fd = to_dev(*f);
     const long long n = (long long)n_side * n_side * n_side;
     if (n > 0x7fffffffLL) return ARAH_E_BADARG;
-    LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(n, kTile)), dim3(kThreads),
-                  kLdsSdfFwd, s, fd, (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, (int)n, sdf,
-                  (float*)nullptr, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr,
-                  (int)n_side);
+    if (fd.split && knobs().density_wide && n >= 128ll * 1024)   // long lattices on the split engine: 128-point tiles, like the density pass
+        hipLaunchKernelGGL(k_sdf_lattice, dim3(min(num_cus(), grid_for(n, 128))), dim3(kThreads), kLdsDensityWide, s, fd, (int)n_side,
+                           (int)n, sdf, &w.ctr->n_sdf_fwd);
+    else
+        LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(n, kTile)), dim3(kThreads),
+                      kLdsSdfFwd, s, fd, (const float*)nullptr, (const int*)nullptr, (const int*)nullptr, (int)n, sdf,
+                      (float*)nullptr, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr,
+                      (int)n_side);
     return check_launch();
 }
 
@@ -3674,6 +3723,44 @@ int arah_skin_lbs(const ArahFrame* f, const float* x_hat, int32_t n, float* wout
     if (int arc = setup_attributes()) return arc;
     hipLaunchKernelGGL(k_skin_eval, dim3(grid_for(n, kTile)), dim3(kThreads), kLdsSkin,
                        reinterpret_cast<hipStream_t>(stream), to_dev(*f), x_hat, n, wout, x_bar, T, &w.ctr->n_skin_fwd);
+    return check_launch();
+}
+
+int arah_skin_lbs_counted(const ArahFrame* f, const float* x_hat, int32_t n_max, const int32_t* n_items, int32_t per_item,
+                          float* x_bar, void* workspace, size_t wbytes, void* stream) {
+    if (!f || !x_hat || !x_bar || !n_items || n_max < 0 || per_item <= 0 || !workspace) return ARAH_E_BADARG;
+    if (n_max == 0) return ARAH_OK;
+    Workspace w = carve(workspace, 1, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipLaunchKernelGGL(k_skin_eval, dim3(grid_for(n_max, kTile)), dim3(kThreads), kLdsSkin,
+                       reinterpret_cast<hipStream_t>(stream), to_dev(*f), x_hat, n_max, (float*)nullptr, x_bar, (float*)nullptr,
+                       &w.ctr->n_skin_fwd, n_items, per_item);
+    return check_launch();
+}
+
+// ---- marching cubes (csrc/mcubes.hpp) ------------------------------------------------------------------
+size_t arah_marching_cubes_scratch_bytes(int32_t n_side) {
+    if (n_side < 2) return 0;
+    return (size_t)(n_side - 1) * (n_side - 1) * 2 * sizeof(int);
+}
+
+int arah_marching_cubes(const float* sdf, int32_t n_side, float level, const int8_t* tri_table, const int32_t* n_tri,
+                        float* tris, int32_t cap, int32_t* n_tris, void* scratch, size_t scratch_bytes, void* stream) {
+    if (!sdf || !tri_table || !n_tri || !tris || !n_tris || !scratch || n_side < 2 || n_side > 1024 || cap <= 0) return ARAH_E_BADARG;
+    if (scratch_bytes < arah_marching_cubes_scratch_bytes(n_side)) return ARAH_E_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int rows = (n_side - 1) * (n_side - 1);
+    int* row_count = reinterpret_cast<int*>(scratch);
+    int* row_base = row_count + rows;
+    const float vs = (float)(2.0 / (n_side - 1));   // sdf_meshing.py:27: voxel_size = 2.0 / (N - 1), rounded to fp32 once
+    const signed char* table = reinterpret_cast<const signed char*>(tri_table);
+    hipLaunchKernelGGL(k_mcubes<false>, dim3(rows), dim3(kMcThreads), 0, s, sdf, (int)n_side, level, vs, table, (const int*)n_tri,
+                       row_count, (const int*)nullptr, (float*)nullptr, 0);
+    hipLaunchKernelGGL(k_mc_scan, dim3(1), dim3(1024), 0, s, (const int*)row_count, rows, row_base, (int*)n_tris);
+    hipLaunchKernelGGL(k_mcubes<true>, dim3(rows), dim3(kMcThreads), 0, s, sdf, (int)n_side, level, vs, table, (const int*)n_tri,
+                       (int*)nullptr, (const int*)row_base, tris, (int)cap);
+    hipLaunchKernelGGL(k_mc_pad, dim3(1024), dim3(256), 0, s, tris, (const int*)n_tris, (int)cap);
     return check_launch();
 }
 

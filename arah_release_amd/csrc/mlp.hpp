@@ -636,7 +636,7 @@ __device__ __forceinline__ void gemm_acc_bsplit(const bf16x8* __restrict__ wp, i
 // register (a VALU or MFMA reading the word next; an in-flight MFMA still reading the registers the word lands in), and the
 // compiler cannot see into an asm statement: with round 4's shorter loop-C epilogue an MFMA came to sit right behind a
 // v_fma_mixhi_f16 often enough for 6 % of the F1 points to miss their root, depending on the schedule
-// (profiles/r04_dstsel_hazard.txt).  Built without packed fp32 (the library always is), instruction selection turns
+// (profiles/r04_hazard_ubench.txt).  Built without packed fp32 (the library always is), instruction selection turns
 // fptrunc(fma(a, k, -fpext(hi))) into exactly the two mixed-precision FMAs, provided it cannot fold the multiplier away:
 // `one` is 1.0 in a scalar register it cannot see through.
 __device__ __forceinline__ float opaque_one() {

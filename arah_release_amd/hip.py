@@ -109,7 +109,8 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel"]
+           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
+           "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes"]
 
 _lib = None
 
@@ -130,6 +131,8 @@ def load_library():
     lib.arah_dominant_kernel.restype = C.c_char_p
     lib.arah_shade_train_slab_bytes.restype = C.c_size_t
     lib.arah_mesh_query_scratch_bytes.restype = C.c_size_t
+    lib.arah_marching_cubes_scratch_bytes.restype = C.c_size_t
+    lib.arah_marching_cubes_scratch_bytes.argtypes = [C.c_int32]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the symbol is missing
     _lib = lib
@@ -443,6 +446,53 @@ def sdf_grid(frame, ws, n_side=256):
     _check(lib.arah_sdf_grid(C.byref(frame.handle), C.c_int32(int(n_side)), _ptr(out), _ptr(buf), C.c_size_t(buf.numel()),
                              _stream()), "arah_sdf_grid")
     return out
+
+
+_mc_tables = {}
+
+
+def marching_cubes(sdf, level=0.0, cap=1 << 20):
+    """Level set of the lattice volume sdf (N,N,N) [ix,iy,iz] as a triangle soup, on the device and WITHOUT a host round
+    trip: -> tris (cap,3,3) coordinates in [-1,1]^3 (rows beyond the count are zero: degenerate triangles), n_tris (1,) int32
+    on the device (the size of the level set; it may exceed cap, then only the first cap triangles were written).  The case
+    table is meshing.case_table(), copied to the device once; the result is meshing.marching_cubes(sdf) triangle for triangle."""
+    require_gpu()
+    lib = load_library()
+    v = _f32(sdf)
+    if v.dim() != 3 or v.shape[0] != v.shape[1] or v.shape[0] != v.shape[2] or v.shape[0] < 2:
+        raise ValueError("sdf must be an (N, N, N) lattice volume")
+    dev, N = v.device, int(v.shape[0])
+    if dev not in _mc_tables:
+        import numpy as np
+        from . import meshing
+        table_np, ntri_np = meshing.case_table()
+        assert table_np.shape[1] <= 16
+        t16 = -np.ones((256, 16), np.int8)
+        t16[:, :table_np.shape[1]] = table_np
+        _mc_tables[dev] = (torch.from_numpy(t16).to(dev), torch.from_numpy(ntri_np.astype(np.int32)).to(dev))
+    table, ntri = _mc_tables[dev]
+    with _on_device(dev):
+        tris = torch.empty(int(cap), 3, 3, device=dev)
+        n_tris = torch.empty(1, dtype=torch.int32, device=dev)
+        scratch = torch.empty(int(lib.arah_marching_cubes_scratch_bytes(N)), dtype=torch.uint8, device=dev)
+        _check(lib.arah_marching_cubes(_ptr(v), C.c_int32(N), C.c_float(float(level)), _ptr(table), _ptr(ntri), _ptr(tris),
+                                       C.c_int32(int(cap)), _ptr(n_tris), _ptr(scratch), C.c_size_t(scratch.numel()), _stream()),
+               "arah_marching_cubes")
+    return tris, n_tris
+
+
+@_guarded
+def skin_lbs_counted(frame, ws, x_hat, n_items, per_item=1):
+    """Forward skinning of the first n_items[0] * per_item rows of x_hat (P,3) -- a count that lives on the device -- ->
+    x_bar (P,3), zero beyond.  (The vertices of a mesh hip.marching_cubes just extracted, per_item = 3.)"""
+    lib = load_library()
+    x = _f32(x_hat)
+    buf = ws.ensure(1, 1)
+    xb = torch.zeros(x.shape[0], 3, device=x.device)
+    _check(lib.arah_skin_lbs_counted(C.byref(frame.handle), _ptr(x), C.c_int32(int(x.shape[0])), _ptr(n_items),
+                                     C.c_int32(int(per_item)), _ptr(xb), _ptr(buf), C.c_size_t(buf.numel()), _stream()),
+           "arah_skin_lbs_counted")
+    return xb
 
 
 def gemv_rows(weight, x, b0=None, b1=None):

@@ -3,7 +3,10 @@
 
   1. SDF on the 256^3 lattice of [-1,1]^3 -- one launch of the SDF kernel (``arah_sdf_grid``), the values never
      leave HBM (the reference: 64 chunks with a ``.cpu()`` copy each, sdf_meshing.py:44-57);
-  2. marching cubes at level 0 as vectorised tensor operations over the ~10^5 surface cells;
+  2. marching cubes at level 0 as three kernels (``arah_marching_cubes``, csrc/mcubes.hpp: count per lattice row, scan,
+     emit) whose triangle COUNT stays on the device -- no host round trip anywhere in the branch, so that the frames of a
+     test sequence keep overlapping (``marching_cubes`` below is the same extraction as tensor operations: the
+     specification the kernel is tested against, and what runs for volumes that live on the host);
   3. forward skinning of the vertices (``arah_skin_lbs``), projection, rasterisation (``arah_rasterize``) and the three
      normal maps ``output_normal`` / ``normal_cano_front`` / ``normal_cano_back`` (1,512,512,3).
 
@@ -149,17 +152,31 @@ def project_opencv(pts, cam_rot, cam_trans, K):
     return torch.stack([u, v, z], dim=-1)
 
 
+_LOOKAT = {}   # (device, azimuth, distance) -> (camera position (3,), view axes as columns (3,3)) on the device
+
+
+def _lookat(device, azim_deg, dist):
+    """look_at_view_transform(dist, 0, azim): the camera position and the matrix whose columns are the view axes.  Built once
+    per device and view: a tensor made from Python numbers is a blocking host -> device copy, which waits for everything the
+    stream has queued -- inside a frame that would be the whole render in front of the mesh branch."""
+    key = (device, float(azim_deg), float(dist))
+    if key not in _LOOKAT:
+        a = math.radians(azim_deg)
+        cam = torch.tensor([dist * math.sin(a), 0.0, dist * math.cos(a)])
+        z_axis = -cam / cam.norm()
+        up = torch.tensor([0.0, 1.0, 0.0])
+        x_axis = torch.cross(up, z_axis, dim=0)
+        x_axis = x_axis / x_axis.norm()
+        y_axis = torch.cross(z_axis, x_axis, dim=0)
+        R = torch.stack([x_axis, y_axis, z_axis], dim=1)          # columns = view axes
+        _LOOKAT[key] = (cam.to(device), R.to(device))
+    return _LOOKAT[key]
+
+
 def project_lookat(pts, azim_deg, size, dist=2.0, fov_deg=60.0):
     """look_at_view_transform(dist, elev 0, azim) + FoVPerspectiveCameras(fov 60): canonical points -> (u, v, depth).
     pytorch3d's view space has +X left, +Y up, +Z into the screen; NDC (1,1) is the top-left pixel corner."""
-    a = math.radians(azim_deg)
-    cam = torch.tensor([dist * math.sin(a), 0.0, dist * math.cos(a)], device=pts.device)
-    z_axis = -cam / cam.norm()
-    up = torch.tensor([0.0, 1.0, 0.0], device=pts.device)
-    x_axis = torch.cross(up, z_axis, dim=0)
-    x_axis = x_axis / x_axis.norm()
-    y_axis = torch.cross(z_axis, x_axis, dim=0)
-    R = torch.stack([x_axis, y_axis, z_axis], dim=1)          # columns = view axes
+    cam, R = _lookat(pts.device, azim_deg, dist)
     xv = (pts - cam) @ R
     f = 1.0 / math.tan(math.radians(fov_deg) / 2.0)
     z = xv[..., 2]
@@ -169,29 +186,83 @@ def project_lookat(pts, azim_deg, size, dist=2.0, fov_deg=60.0):
 
 
 def normal_image(pix_to_face, normals, background):
-    """normals (F,3) gathered per pixel, `background` elsewhere, mapped to [0,1] like models/__init__.py:247,278."""
-    H, W = pix_to_face.shape
-    img = torch.full((H, W, 3), float(background), device=normals.device)
-    fg = pix_to_face >= 0
-    img[fg] = normals[pix_to_face[fg]]
+    """normals (F,3) gathered per pixel, `background` elsewhere, mapped to [0,1] like models/__init__.py:247,278.
+    (A gather and a select: boolean-mask indexing would cost a device -> host round trip for the number of pixels.)"""
+    fg = (pix_to_face >= 0).unsqueeze(-1)
+    img = torch.where(fg, normals[pix_to_face.clamp_min(0)], torch.full((), float(background), device=normals.device))
     return ((img + 1.0) / 2.0).clip(0.0, 1.0).unsqueeze(0)
 
 
-def canonical_mesh_outputs(frame, ws, inputs, rasterize_fn=None, n_side=256, image_size=512, tri=None):
+# Triangle capacity of the device-side extraction per device, and the counts of earlier calls on their way to the host
+# (asynchronous copies into pinned memory: nothing here ever waits for the GPU).  A count that turns out to have exceeded
+# the capacity raises it for the calls that follow and is reported: that call's mesh was truncated.
+_MC_STATE = {}
+MC_DEFAULT_CAP = 1 << 20
+
+
+def _mc_state(dev):
+    st = _MC_STATE.get(dev)
+    if st is None:
+        st = _MC_STATE[dev] = {"cap": MC_DEFAULT_CAP, "pending": [], "free": [], "overflowed": 0, "last_count": None}
+    return st
+
+
+def _mc_poll(st, wait=False):
+    import warnings
+    keep = []
+    for ev, host, cap in st["pending"]:
+        if wait:
+            ev.synchronize()
+        if ev.query():
+            n = int(host[0])
+            st["last_count"] = n
+            st["free"].append((ev, host))
+            if n > cap:
+                st["overflowed"] += 1
+                st["cap"] = max(st["cap"], 1 << int(math.ceil(math.log2(1.5 * n))))
+                warnings.warn("canonical mesh: the level set has %d triangles, the device buffer held %d -- that frame's mesh was "
+                              "truncated; capacity raised to %d for the following frames" % (n, cap, st["cap"]))
+        else:
+            keep.append((ev, host, cap))
+    st["pending"] = keep
+
+
+def mesh_counts(device, wait=True):
+    """(triangles of the last finished extraction on `device`, number of truncated extractions so far); wait=True drains the
+    outstanding count copies first (tests, end of a sequence)."""
+    st = _mc_state(torch.device(device))
+    _mc_poll(st, wait=wait)
+    return st["last_count"], st["overflowed"]
+
+
+def canonical_mesh_outputs(frame, ws, inputs, rasterize_fn=None, n_side=256, image_size=512, tri=None, want_tri=True):
     """The three normal maps of the gen_cano_mesh branch + the canonical triangle soup (normalised coordinates).
     frame: packed hip.Frame of the current pose; inputs: the model's input dict (coord_min/max, center, trans,
     cam_rot, cam_trans, intrinsics).  tri: a triangle soup to use instead of meshing the SDF (fixture F18 injects the mesh
-    the reference's own branch was run on)."""
+    the reference's own branch was run on).  want_tri=False (the model entry): the soup is not returned and the call makes
+    no device -> host round trip at all -- the mesh lives in a fixed-capacity buffer whose tail is degenerate triangles, its
+    size stays on the device (hip.marching_cubes, hip.skin_lbs_counted); want_tri=True trims the soup to its size, which
+    waits for the GPU."""
     from . import hip, training
     rasterize_fn = rasterize_fn or hip.rasterize
     with torch.no_grad():
+        n_dev = None
         if tri is None:
             sdf = hip.sdf_grid(frame, ws, n_side)
-            tri = marching_cubes(sdf)                                                    # (F,3,3) in [-1,1]^3
+            st = _mc_state(sdf.device)
+            _mc_poll(st)
+            tri, n_dev = hip.marching_cubes(sdf, 0.0, st["cap"])                         # (cap,3,3) in [-1,1]^3, zero tail
+            ev, host = st["free"].pop() if st["free"] else (torch.cuda.Event(), torch.empty(1, dtype=torch.int32).pin_memory())
+            host.copy_(n_dev, non_blocking=True)
+            ev.record()
+            st["pending"].append((ev, host, st["cap"]))
         F = tri.shape[0]
         cmin, cmax, center = inputs["coord_min"][:1], inputs["coord_max"][:1], inputs["center"][:1]
         x_hat = training.unnormalize_canonical_points(tri.reshape(1, -1, 3), cmin, cmax, center)[0]
-        _, x_bar, _ = hip.skin_lbs(frame, ws, x_hat)
+        if n_dev is None:
+            _, x_bar, _ = hip.skin_lbs(frame, ws, x_hat)
+        else:
+            x_bar = hip.skin_lbs_counted(frame, ws, x_hat, n_dev, per_item=3)            # zero beyond the mesh: degenerate
         posed = (x_bar + inputs["trans"].reshape(1, 3)).reshape(F, 3, 3)
         cam_rot, cam_trans, K = inputs["cam_rot"][0], inputs["cam_trans"][0], inputs["intrinsics"][0]
         p2f = rasterize_fn(project_opencv(posed, cam_rot, cam_trans, K), image_size, image_size)
@@ -201,4 +272,8 @@ def canonical_mesh_outputs(frame, ws, inputs, rasterize_fn=None, n_side=256, ima
         for key, azim in (("normal_cano_front", 0.0), ("normal_cano_back", 180.0)):
             p2f = rasterize_fn(project_lookat(tri, azim, image_size), image_size, image_size, z_near=1.0)
             out[key] = normal_image(p2f, n_cano, 0.0)
+        if not want_tri:
+            return out, None
+        if n_dev is not None:
+            tri = tri[:min(int(n_dev.item()), F)]
     return out, tri

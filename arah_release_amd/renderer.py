@@ -486,7 +486,7 @@ class MetaAvatarRender(nn.Module):
                 frame = build_frame(inputs["sdf_network"], self.skinning_model, None, None, None, inputs["smpl_verts"],
                                     inputs["skinning_weights"], inputs["bone_transforms"], inputs["trans"],
                                     inputs["coord_min"], inputs["coord_max"], inputs["center"])
-            maps, _ = meshing.canonical_mesh_outputs(frame, self.idhr_network.ray_tracer.workspace(dev), inputs)
+            maps, _ = meshing.canonical_mesh_outputs(frame, self.idhr_network.ray_tracer.workspace(dev), inputs, want_tri=False)
             model_outputs.update(maps)
         return model_outputs
 

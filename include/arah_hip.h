@@ -27,6 +27,7 @@
  *                           (broyden.py:4-78 with g = LBS(x) - target)
  *   arah_joint_root_find    search_iso_surface_depth on caller-supplied starts  root_finding_utils.py:365-484
  *   arah_sdf_grid           create_mesh_vertices_and_faces' lattice evaluation  utils/sdf_meshing.py:13-70
+ *   arah_marching_cubes     skimage.measure.marching_cubes_lewiner as called at utils/sdf_meshing.py:95 (+ :96-101)
  *   arah_rasterize          pytorch3d MeshRasterizer (pix_to_face) as used at metaavatar_render/models/__init__.py:232-276
  *   arah_shade_train_*      get_rbg_value_vol_sdf with self.training: per-sample forward and backward
  *                           renderer/implicit_differentiable_renderer.py:291-361, diff_operators.py:39-50
@@ -233,6 +234,23 @@ int arah_rasterize(const float* tri_uvz, int32_t n_faces, int32_t height, int32_
 /* raw canonical x_hat [P,3] -> optional w [P,24], x_bar [P,3], T [P,16] */
 int arah_skin_lbs(const ArahFrame* h_frame, const float* x_hat, int32_t n_pts, float* w, float* x_bar,
                   float* T, void* workspace, size_t workspace_bytes, void* stream);
+/* arah_skin_lbs for a point list whose length is known on the DEVICE only: the first min(n_max, *n_items * per_item) rows
+ * of x_hat are skinned into x_bar, the other rows of x_bar are left as the caller set them.  (The vertices of the mesh
+ * arah_marching_cubes just extracted: per_item = 3 corners per triangle; no host round trip for the count.) */
+int arah_skin_lbs_counted(const ArahFrame* h_frame, const float* x_hat, int32_t n_max, const int32_t* n_items,
+                          int32_t per_item, float* x_bar, void* workspace, size_t workspace_bytes, void* stream);
+/* Level set of a lattice volume as a triangle soup (the call utils/sdf_meshing.py:95 makes to
+ * skimage.measure.marching_cubes_lewiner, followed by :96-101's vertex = origin + index * voxel_size on the lattice of
+ * [-1,1]^3).  sdf [n][n][n] indexed [ix][iy][iz]; tri_table [256][16] int8 / n_tri [256] int32 (DEVICE): for every
+ * inside-outside pattern of a cell's 8 corners (bit c set = corner c below `level`; corner / edge numbering of
+ * arah_release_amd/meshing.py) the edge ids of its triangles, -1 padded, and their number (<= 5).  -> tris [cap][3][3]
+ * coordinates in [-1,1]^3, right-hand normals towards decreasing values, cells in (ix, iy, iz) order; rows beyond the count
+ * are ZERO (degenerate triangles); *n_tris (device) = the number of triangles of the level set, which may exceed cap (then
+ * only the first cap were written).  Shared vertices of neighbouring cells are bit-equal.  scratch:
+ * arah_marching_cubes_scratch_bytes(n_side) device bytes.  No host synchronisation. */
+size_t arah_marching_cubes_scratch_bytes(int32_t n_side);
+int arah_marching_cubes(const float* sdf, int32_t n_side, float level, const int8_t* tri_table, const int32_t* n_tri,
+                        float* tris, int32_t cap, int32_t* n_tris, void* scratch, size_t scratch_bytes, void* stream);
 /* raw canonical x_hat [P,3] -> d x_bar / d x_hat [P,3,3] */
 int arah_skin_jacobian(const ArahFrame* h_frame, const float* x_hat, int32_t n_pts, float* jac,
                        void* workspace, size_t workspace_bytes, void* stream);

@@ -50,13 +50,13 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_keeps_no_mutable_process_state():
     """Re-entrancy: the shared object's writable data is the kernel stubs of the HIP runtime plus a short list of
-    write-once items (tuning knobs read at first use, per-device attribute setup under call_once, the CU-count cache)."""
+    write-once items (tuning knobs read at first use, per-device attribute setup (a success flag per device under a mutex), the CU-count cache)."""
     import subprocess
     import __graft_entry__ as g
     g.build()
     so = os.path.join(REPO, "arah_release_amd", "libarah_hip.so")
     out = subprocess.run(["nm", "-C", so], capture_output=True, text=True, check=True).stdout
-    allowed = ("knobs()::k", "setup_attributes()::once", "setup_attributes()::rc", "num_cus()::cus", "g_attr_failed",
+    allowed = ("knobs()::k", "setup_attributes()::done", "setup_attributes()::mu", "num_cus()::cus",
                "guard variable for (anonymous namespace)::knobs()::k")
     runtime = ("__hip", "__do_init", "__do_fini", "__init", "__fini", "_GLOBAL_OFFSET_TABLE_", "DW.ref", "__dso_handle",
                "completed", "__TMC_END__", "_DYNAMIC", "__bss_start", "_edata", "_end", "__data_start")

@@ -66,6 +66,67 @@ def test_marching_cubes_two_touching_blobs_has_no_cracks():
     assert 1 not in mult and 3 not in mult                              # no boundary edges: no cracks
 
 
+@gpu
+@pytest.mark.parametrize("case", ["sphere", "noise", "emitted_sdf"])
+def test_marching_cubes_kernel_is_the_tensor_formulation(scene, case):
+    """arah_marching_cubes (csrc/mcubes.hpp) against meshing.marching_cubes, the tensor formulation it replaces, run on the
+    CPU: the same number of triangles, in the same order, every corner bit-equal; the orientation may differ where a
+    triangle is degenerate (its normal is rounding noise), nowhere else.  Rows beyond the count are zero, the count stays
+    on the device, a capacity below the count truncates and reports the full count."""
+    from arah_release_amd import hip, meshing
+    dev = torch.device("cuda:0")
+    if case == "emitted_sdf":
+        model, cfg = get_model("zju377_mono", dev)
+        inputs = scene.make_inputs(512, 512, frame_idx=1, device=dev, max_rays=1024)
+        with torch.no_grad():
+            model(inputs, eval=True)
+        frame, ws = model.idhr_network.last_frame, model.idhr_network.ray_tracer.workspace(dev)
+        sdf = hip.sdf_grid(frame, ws, 256)
+    else:
+        N = 56 if case == "sphere" else 33
+        ax = torch.linspace(-1, 1, N)
+        X, Y, Z = torch.meshgrid(ax, ax, ax, indexing="ij")
+        sdf = torch.sqrt((X - 0.1) ** 2 + (Y + 0.05) ** 2 + (Z - 0.2) ** 2) - 0.55
+        if case == "noise":
+            sdf = sdf + 0.4 * torch.randn(N, N, N, generator=torch.Generator().manual_seed(5))
+        sdf = sdf.to(dev)
+    ref = meshing.marching_cubes(sdf.cpu())
+    F = ref.shape[0]
+    assert F > 1000
+    tris, n_dev = hip.marching_cubes(sdf, 0.0, cap=F + 1000)
+    assert int(n_dev.item()) == F
+    got = tris.cpu()
+    assert bool((got[F:] == 0).all())
+    got = got[:F]
+    same = (got == ref).all(-1).all(-1)
+    flipped = (got[:, [0, 2, 1]] == ref).all(-1).all(-1)
+    assert bool((same | flipped).all())                                 # corners bit-equal, triangle for triangle
+    area = torch.cross(ref[:, 1] - ref[:, 0], ref[:, 2] - ref[:, 0], dim=1).norm(dim=1)
+    assert bool((area[~same] < 1e-9).all()), int((~same).sum())          # orientation differs on degenerate triangles only
+    small, n2 = hip.marching_cubes(sdf, 0.0, cap=F // 2)
+    assert int(n2.item()) == F and torch.equal(small.cpu()[:F // 2][same[:F // 2]], ref[:F // 2][same[:F // 2]])
+
+
+@gpu
+def test_mesh_branch_keeps_its_triangle_count_on_the_device(scene):
+    """The model entry's gen_cano_mesh branch must not wait for the GPU (frames of a test sequence overlap): the triangle
+    count travels to the host asynchronously, and the maps of the fixed-capacity path equal those of the trimmed mesh."""
+    from arah_release_amd import meshing
+    dev = torch.device("cuda:0")
+    model, cfg = get_model("zju377_mono", dev)
+    inputs = scene.make_inputs(512, 512, frame_idx=2, device=dev, max_rays=2048)
+    with torch.no_grad():
+        out = model(inputs, gen_cano_mesh=True, eval=True)
+    n, overflowed = meshing.mesh_counts(dev)
+    assert n is not None and 20000 < n < meshing.MC_DEFAULT_CAP and overflowed == 0
+    frame, ws = model.idhr_network.last_frame, model.idhr_network.ray_tracer.workspace(dev)
+    maps, tri = meshing.canonical_mesh_outputs(frame, ws, inputs)
+    assert tri.shape[0] == n
+    maps2, _ = meshing.canonical_mesh_outputs(frame, ws, inputs, tri=tri)   # exact-size mesh through arah_skin_lbs
+    for k in ("output_normal", "normal_cano_front", "normal_cano_back"):
+        assert torch.equal(maps[k], out[k]) and torch.equal(maps[k], maps2[k]), k
+
+
 def test_lookat_projection_matches_the_documented_camera():
     """look_at_view_transform(2, 0, azim) + FoVPerspectiveCameras(fov 60): +x is right / +y is up seen from the front,
     mirrored in x seen from the back; the optical axis hits the image centre."""
@@ -261,7 +322,9 @@ def test_normal_maps_of_the_reference_branch_cpu():
     n_cano = meshing.face_normals(tri)
     np.testing.assert_allclose(meshing.normal_image(p2f["p2f_front"], n_cano, 0.0).numpy(), g["normal_cano_front"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(meshing.normal_image(p2f["p2f_back"], n_cano, 0.0).numpy(), g["normal_cano_back"], rtol=0, atol=2e-6)
-    # projections: a 64 x 64 corner of each view through the oracle rasteriser (the full images are the generator's own)
+    # REGRESSION check only, not a pin to the reference: the recorded pix_to_face came from these same two functions
+    # (meshing.project_opencv + oracle rasterize_np stand in for pytorch3d, which is absent here and from the reference tree);
+    # what F18 pins to the reference is above -- posed vertices, camera arguments, normal selection / sign / frame / colouring
     uvz = meshing.project_opencv(posed, cam_rot, cam_trans, K).numpy()
     sub = mesh_oracle.rasterize_np(uvz, 512, 512)
     assert (sub == g["p2f_posed"]).all()
