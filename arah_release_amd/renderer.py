@@ -127,12 +127,12 @@ class BodyRayTracing(nn.Module):
     def workspaces(self):
         return list(self._ws.values())
 
-    def sampling(self, device, cano_view_dirs=True, render_last_pt=False):
-        key = (str(device), bool(cano_view_dirs), bool(render_last_pt), bool(self.full_shading), self.shade_engine,
-               self.canon_kernel)
+    def sampling(self, device, cano_view_dirs=True, render_last_pt=False, full_shading=None):
+        full = bool(self.full_shading if full_shading is None else full_shading)
+        key = (str(device), bool(cano_view_dirs), bool(render_last_pt), full, self.shade_engine, self.canon_kernel)
         if key not in self._sampling:
             sm = hip.Sampling(device, self.n_steps, self.near_surface_vol_samples, self.far_surface_vol_samples,
-                              cano_view_dirs, render_last_pt, self.full_shading, self.shade_engine, self.canon_kernel)
+                              cano_view_dirs, render_last_pt, full, self.shade_engine, self.canon_kernel)
             for which, (a, b) in self._events.items():
                 sm.set_events(which, a, b)
             self._sampling[key] = sm
@@ -201,6 +201,18 @@ class IDHRNetwork(nn.Module):
         # (one synchronisation per frame) and a frame that tripped it is rendered AGAIN on the exact fp32 engine before it
         # is returned.
         self.guard_mode = os.environ.get("ARAH_SPLIT_GUARD", "lazy")
+        # Lazy or full shading, decided per frame from what earlier frames needed (both give the same image bit for bit,
+        # DESIGN.md section 4).  The density pre-pass of lazy shading costs D = one SDF trunk per valid sample and saves the
+        # normal sweep + colour MLP of the samples whose density is exactly 0; once the share r of samples with density > 0
+        # exceeds 1 - D / S (S = shading every sample: ~0.7 on the MI355X) the pre-pass is pure overhead -- that happens when
+        # the LEARNED VolSDF beta is large (r = 0.04 at the reference's initial 1e-3, 0.95 at 3e-2).  r of frame k travels to
+        # the host with the range guard's counters (no stream drain) and picks the mode of the frames that follow; while in
+        # full mode every 16th frame runs lazily again to keep r current.  ARAH_ADAPTIVE_SHADING=0 / tracer.full_shading
+        # pin the mode.
+        self.adaptive_shading = os.environ.get("ARAH_ADAPTIVE_SHADING", "1") != "0"
+        self.shade_ratio = None          # last measured r
+        self._shade_full = False
+        self._shade_since_probe = 0
         self.precision = None    # GEMM engine frames are prepared for: None = the process default (ARAH_PRECISION, split),
                                  # hip.PRECISION_FP32 / PRECISION_SPLIT_F16 = this renderer's own choice (bench.py's passes)
         self._precision = None   # becomes hip.PRECISION_FP32 once the range guard has fired: overrides `precision`
@@ -289,9 +301,16 @@ class IDHRNetwork(nn.Module):
         key = (dev, id(ws))   # one record per scratch = per stream with a frame in flight: each has its own counter
         g = self._guard.get(key)
         if g is not None and self.guard_mode != "strict" and g["event"].query():   # (strict: read behind the frame itself)
-            now = int(g["host"].item())
+            ctr = g["host"].tolist()                                 # the nine counters of ArahCounters behind an earlier frame
+            now = int(ctr[8])
             grew = now - g["seen"] if now >= g["seen"] else now      # the counters may have been reset in between
             g["seen"] = now
+            d_col, d_den = ctr[4] - g["col"], ctr[6] - g["den"]      # n_col, n_density since the last look
+            g["col"], g["den"] = ctr[4], ctr[6]
+            win_full, g["win_full"] = g["win_full"], False
+            if d_den > 0 and d_col >= 0 and not win_full:            # lazily shaded frame(s) went by: their share of sigma > 0 samples
+                self.shade_ratio = d_col / d_den
+                self._shade_full = self.shade_ratio > 0.7
             if grew > 0:
                 self.split_nonfinite += grew
                 if self._precision != hip.PRECISION_FP32:
@@ -302,12 +321,14 @@ class IDHRNetwork(nn.Module):
         if g is None:
             if len(self._guard) >= 8:
                 self._guard.pop(next(iter(self._guard)))
-            g = self._guard[key] = {"host": torch.zeros(1, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(), "seen": 0}
+            g = self._guard[key] = {"host": torch.zeros(9, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(), "seen": 0,
+                                    "col": 0, "den": 0, "win_full": False}
         return g
 
-    def _split_guard_arm(self, g, ws):
+    def _split_guard_arm(self, g, ws, full=False):
+        g["win_full"] = g["win_full"] or bool(full)   # a frame that shaded everything says nothing about the share
         # n_split_nonfinite is the ninth 64-bit counter at the head of the workspace (include/arah_hip.h: ArahCounters)
-        g["host"].copy_(ws.buf[64:72].view(torch.int64), non_blocking=True)
+        g["host"].copy_(ws.buf[0:72].view(torch.int64), non_blocking=True)
         g["event"].record()
 
     def forward(self, input):
@@ -330,7 +351,11 @@ class IDHRNetwork(nn.Module):
                             precision=self._precision if self._precision is not None else self.precision,
                             body_tables=input.get("_body_tables"))
         self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
-        samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt)
+        full = self.ray_tracer.full_shading
+        if not full and self.adaptive_shading and self._shade_full and guard is not None and self.guard_mode != "strict":
+            self._shade_since_probe += 1
+            full = self._shade_since_probe % 16 != 0       # every 16th frame lazily: refreshes the measured share
+        samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt, full_shading=full)
         pose34 = pose[0, :3, :4].detach().float().contiguous()
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                       ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
@@ -353,7 +378,7 @@ class IDHRNetwork(nn.Module):
                 rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                               ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
         elif guard is not None and self.guard_mode != "strict":
-            self._split_guard_arm(guard, ws)
+            self._split_guard_arm(guard, ws, full)
         pcam = pcam.reshape(B, N, 3)
         if B > 1:   # per-view camera pose for the remaining batch elements (IDR:114-115)
             pw = cam_loc.reshape(B, 1, 3) + dists.reshape(B, N, 1) * ray_dirs

@@ -256,6 +256,10 @@ class GpuRuntime:
         self.tracer.set_events(which, self.ev0 if on else None, self.ev1 if on else None)
         self.tracer.set_events("canon", self.cv0 if on else None, self.cv1 if on else None)
 
+    def set_adaptive(self, on):
+        """Lazy / full shading chosen per frame from the measured share of sigma > 0 samples (renderer.IDHRNetwork) or pinned."""
+        self.model.idhr_network.adaptive_shading = bool(on) and os.environ.get("ARAH_ADAPTIVE_SHADING", "1") != "0"
+
     def set_precision(self, name):
         """GEMM engine the following frames are prepared for: an attribute of this renderer, not the process environment."""
         self.model.idhr_network.precision = {"split": self.hip.PRECISION_SPLIT_F16, "fp32": self.hip.PRECISION_FP32}[name]
@@ -278,28 +282,43 @@ class GpuRuntime:
         keep = var.detach().clone()
         rays = sum(int(i["ray_dirs"].shape[1]) for i in timed_inputs)
         rows = []
+        idhr = self.model.idhr_network
+
+        def one_pass():
+            self.render_many(warm_inputs[:1] + timed_inputs[:n_streams], n_streams)   # also lets the adaptive choice settle
+            self.device_sync()
+            self.reset_counters()
+            self.device_sync()
+            t0 = time.perf_counter()
+            self.render_many(timed_inputs, n_streams)
+            self.device_sync()
+            dt = time.perf_counter() - t0
+            c = self.counters()
+            return {"value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / max(len(timed_inputs), 1),
+                    "shaded_samples_per_ray": c["n_col"] / max(rays, 1),
+                    "samples_through_the_density_pre_pass_per_ray": c["n_density"] / max(rays, 1)}
         try:
             for b in betas:
                 with torch.no_grad():
                     var.fill_(b)
-                    self.render_many(warm_inputs[:1] + timed_inputs[:n_streams], n_streams)
-                    self.device_sync()
-                    self.reset_counters()
-                    self.device_sync()
-                    t0 = time.perf_counter()
-                    self.render_many(timed_inputs, n_streams)
-                    self.device_sync()
-                    dt = time.perf_counter() - t0
-                c = self.counters()
-                rows.append({"beta": b, "value": rays / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / max(len(timed_inputs), 1),
-                             "shaded_samples_per_ray": c["n_col"] / max(rays, 1),
-                             "valid_samples_per_ray": c["n_density"] / max(rays, 1)})
+                    self.set_adaptive(False)
+                    row = {"beta": b, "lazy_shading_pinned": one_pass()}
+                    self.set_adaptive(True)
+                    idhr._shade_full, idhr.shade_ratio = False, None
+                    row["product_default"] = one_pass()       # lazy or full per frame, from the measured share
+                    row["product_default"]["measured_share_of_shaded_samples"] = idhr.shade_ratio
+                rows.append(row)
         finally:
             with torch.no_grad():
                 var.copy_(keep)
-        return {"note": "the default path (exact lazy shading, %d frames in flight) on the same %d frames with the VolSDF beta "
-                        "overridden; beta = 1e-3 is the subject's own value (the reference's initial value).  With every valid "
-                        "sample shaded (value_full_shading) the figure does not depend on beta" % (n_streams, len(timed_inputs)),
+            self.set_adaptive(True)
+            idhr._shade_full, idhr.shade_ratio = False, None
+        return {"note": "the same %d frames (%d in flight) with the VolSDF beta overridden; beta = 1e-3 is the subject's own value "
+                        "(the reference's initial value).  lazy_shading_pinned: the density pre-pass + normal / colour for the "
+                        "sigma > 0 samples only (what `value` measures); product_default: the renderer picks lazy or full "
+                        "shading per frame from the share of sigma > 0 samples earlier frames reported (same image either way, "
+                        "bit for bit).  With every valid sample shaded (value_full_shading) the figure does not depend on beta"
+                        % (len(timed_inputs), n_streams),
                 "sweep": rows}
 
     def cpu_baseline(self, args, near, far):
@@ -433,6 +452,7 @@ def run(args, rt):
         around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
         # ARAH_FULL_SHADING=1 forces the shade-everything path in every pass (the profiler's full-shading PMC passes)
         tracer.full_shading = full_shading or os.environ.get("ARAH_FULL_SHADING") == "1"
+        rt.set_adaptive(False)   # the passes measure the path they name; the product's own choice is reported by beta_sweep
         rt.set_precision(precision)
         n_streams = args.streams if n_streams is None else n_streams
         rt.render_many(warm_inputs, n_streams)
@@ -453,6 +473,7 @@ def run(args, rt):
             ms.append(rt.event_ms())
             cms.append(rt.canon_ms())
         rt.set_events(full_shading, False)
+        rt.set_adaptive(True)
         rt.set_precision(default_engine)
         canon_ms[(full_shading, precision)] = cms
         return dt, ctr, ms

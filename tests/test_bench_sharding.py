@@ -118,6 +118,9 @@ class _StubRuntime:
     def set_events(self, full_shading, on):
         pass
 
+    def set_adaptive(self, on):
+        pass
+
     def set_precision(self, name):
         pass
 

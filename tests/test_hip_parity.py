@@ -722,6 +722,37 @@ def test_lazy_shading_is_exact(scene, name):
 
 
 @gpu
+def test_shading_mode_follows_the_measured_share(scene):
+    """The renderer picks lazy or full shading per frame from the share of sigma > 0 samples earlier frames reported (the
+    counters travel to the host without a stream drain).  A subject with a large VolSDF beta (3e-2: nearly every sample has
+    density > 0) must end up shading everything -- no density pre-pass -- a subject at the reference's initial 1e-3 must stay
+    lazy, and the images must be those of the pinned modes bit for bit."""
+    from arah_release_amd import config
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model("zju377_mono", device=dev)
+    idhr, tracer = model.idhr_network, model.idhr_network.ray_tracer
+    inputs = scene.make_inputs(96, 96, frame_idx=3, device=dev)
+    for beta, want_full in ((3e-2, True), (1e-3, False)):
+        with torch.no_grad():
+            model.deviation_decoder.variance.fill_(beta)
+            idhr.adaptive_shading, idhr._shade_full, idhr.shade_ratio = False, False, None
+            pinned = model(dict(inputs), eval=True)["rgb_values"].clone()
+            idhr.adaptive_shading = True
+            ws = tracer.workspace(dev)
+            for _ in range(3):                       # frame k's counters are looked at when frame k + 1 starts
+                torch.cuda.synchronize()
+                before = ws.counters()
+                out = model(dict(inputs), eval=True)
+                torch.cuda.synchronize()
+                after = ws.counters()
+        assert idhr.shade_ratio is not None and (idhr.shade_ratio > 0.7) == want_full, idhr.shade_ratio
+        assert idhr._shade_full == want_full
+        assert (after["n_density"] == before["n_density"]) == want_full     # the last frame ran without / with the pre-pass
+        assert torch.equal(out["rgb_values"], pinned)
+    idhr._shade_full, idhr.shade_ratio = False, None
+
+
+@gpu
 def test_training_step_against_reference(scene):
     """One training step (ZJUMOCAP-313 shapes: idr colour net, train_skinning_net, view-rotation augmentation):
     forward dict, every loss term and the per-parameter gradient norms vs the reference's (fixture f8), with the
