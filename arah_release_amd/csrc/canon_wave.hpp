@@ -20,10 +20,12 @@
 //     HBM;
 //   * the per-point tail runs on the FOUR LANES (j, g) of a point, with no LDS round trip between them (round 4; round 3
 //     exchanged logits, gates and T rows through LDS rows behind wave barriers and ran the Broyden step on 32 of the 64
-//     lanes: 38-41 % of the kernel's time in its phase clocks).  What one lane has and the other three need crosses on the
-//     MATRIX pipe: v_mfma_f32_16x16x4_f32 with A[i][k] = (i mod 4 == k) hands every lane of point n the four values
-//     B[0..3][n] its lane groups supplied (an exact copy: products with 1 and sums with 0), with A[i][k] = (k < 3) their
-//     sum over the three rows of a 3-vector (an fmaf chain in row order).  Lane g keeps row g of everything: the gate
+//     lanes: 38-41 % of the kernel's time in its phase clocks).  What one lane has and the other three need crosses
+//     lanes without touching LDS memory -- round 4: on the MATRIX pipe (v_mfma_f32_16x16x4_f32 with A[i][k] = (i mod 4 == k)
+//     hands every lane of point n the four values B[0..3][n] its lane groups supplied, an exact copy: products with 1 and
+//     sums with 0; with A[i][k] = (k < 3) their sum over the three rows of a 3-vector, an fmaf chain in row order); round 5:
+//     on the LDS crossbar (ds_bpermute_b32: the same copies, the same sums in the same order, and the matrix pipe stays
+//     with the MLP: -3 % per launch).  Lane g keeps row g of everything: the gate
 //     sigmoids of its own eight logits (gathered: 8 MFMAs), row g of T (six MFMA steps as before), component g of x, step,
 //     residual and best x, row g of J^-1 -- the Broyden update needs one gather of the new residual, one of the old, and
 //     three row sums (v^T = dx^T J^-1).  The two N-tiles of a wave are independent instruction streams the compiler
@@ -508,8 +510,29 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves >= 8 ? kCwWaves / 4 : 2) void 
         request(cl);     // this pass's claims: a whole pass to land in
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         const float selA = ((j & 3) == g) ? 1.0f : 0.0f, sumA = g < 3 ? 1.0f : 0.0f;
+        // What one lane of a point has and the other three need.  Round 4 moved these copies from LDS rows (write, wave barrier,
+        // read) to the matrix pipe: v_mfma_f32_16x16x4_f32 with A[i][k] = (i mod 4 == k) hands every lane of point n the four
+        // values B[0..3][n] its lane groups supplied, with A[i][k] = (k < 3) their sum over three rows.  Exact, no LDS traffic --
+        // but 40 fp32 MFMAs per pass, 32 cycles each, on the pipe the OTHER wave of the SIMD needs for its MLP, and matrix time
+        // is what a pass is made of (vector work hides to 45 % behind MFMAs, matrix work does not hide at
+        // all).  Round 5: ds_bpermute_b32 -- the LDS crossbar, no LDS memory, no barrier: lane (j, g) reads the value of lane
+        // (j, r) for r = 0..3.  Same bits (a copy is a copy; the three-row sum adds in the MFMA's row order).  Alternating
+        // passes on one box: 14.66 -> 14.24 ms per launch, 38.55 -> 38.2 ms per frame (gpurun_out/r5l).  -DCW_GATHER_MFMA
+        // restores the matrix-pipe form.
+#ifndef CW_GATHER_MFMA
+        const int sh0 = (j) << 2, sh1 = (j + 16) << 2, sh2 = (j + 32) << 2, sh3 = (j + 48) << 2;
+        auto bperm = [&](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+        auto gather = [&](float v) { return f32x4{bperm(sh0, v), bperm(sh1, v), bperm(sh2, v), bperm(sh3, v)}; };
+        auto sum3 = [&](float v) {
+            const float t = (bperm(sh0, v) + bperm(sh1, v)) + bperm(sh2, v);
+            return f32x4{t, t, t, t};
+        };
+        (void)selA;
+        (void)sumA;
+#else
         auto gather = [&](float v) { return __builtin_amdgcn_mfma_f32_16x16x4f32(selA, v, zero4, 0, 0, 0); };
         auto sum3 = [&](float v) { return __builtin_amdgcn_mfma_f32_16x16x4f32(sumA, v, zero4, 0, 0, 0); };
+#endif
         f32x4 p0[NT], p1[NT], s0[NT];
         float tgt[NT];
 #pragma unroll
