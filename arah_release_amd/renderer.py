@@ -43,11 +43,99 @@ def _emitted_sdf_layers(sdf_network):
 
 
 def _mlp_layers(module):
+    """Row-major (W, b) of a weight-normed MLP, W = g v / |v| folded.  Without gradients (inference) the folded weights are
+    kept on the module until a parameter changes (data pointer or in-place version): a test sequence folds the skinning and
+    colour networks once instead of eleven launches per frame.  An event orders other streams behind the fold."""
+    cache = not torch.is_grad_enabled()
+    if cache:
+        key = tuple((p.data_ptr(), p._version) for p in module.parameters())
+        hit = module.__dict__.get("_arah_folded")
+        if hit is not None and hit[0] == key:
+            if hit[2] is not None and torch.cuda.current_stream(hit[3]).cuda_stream != hit[4]:
+                torch.cuda.current_stream(hit[3]).wait_event(hit[2])
+            return hit[1]
     out = []
     for l in range(module.num_layers - 1):
         lin = getattr(module, "lin%d" % l)
         out.append((folded_weight(lin), lin.bias))
+    if cache:
+        out = [(w.detach().float().contiguous(), b.detach().float().contiguous()) for w, b in out]
+        dev = out[0][0].device
+        ev = sid = None
+        if dev.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(dev))
+            sid = torch.cuda.current_stream(dev).cuda_stream
+        module.__dict__["_arah_folded"] = (key, out, ev, dev, sid)
     return out
+
+
+class _GraphedDecoder:
+    """The pose encoder + hypernetwork of one frame (sdf_decoder: ~110 small launches, 2.5 ms of a launch-bound GPU in front of
+    every frame) captured once per device as a graph and replayed: inference only (no gradients, no input noise).  The
+    graph's inputs are copied into its static tensors, its outputs -- the emitted layers -- are copied out into fresh
+    tensors in one multi-tensor launch, so that what the caller sees (inputs['sdf_network'], the returned sdf_params) is its
+    own, as with the eager call; the kernels and their order are the eager call's: same bits.  Parameters are read in place,
+    an update is seen by the next replay; a re-allocated parameter re-captures.  ARAH_HYPERNET_GRAPH=0 switches it off."""
+
+    def __init__(self, decoder):
+        self.decoder = decoder
+        self.entries = {}
+
+    def _key(self, dev):
+        ptrs = 0
+        for p in self.decoder.parameters():
+            ptrs = (ptrs * 1000003 + p.data_ptr()) & 0xFFFFFFFFFFFF
+        return (dev, ptrs)   # ONE graph per device: a replay runs on whatever stream the frame is on, an event hands the
+                             # static tensors from one frame to the next (the decoders of frames in flight take turns, ~0.5 ms each)
+
+    def __call__(self, decoder_input):
+        dev = decoder_input["rots"].device
+        key = self._key(dev)
+        e = self.entries.get(key)
+        if e is None:
+            if len(self.entries) >= 8:
+                self.entries.pop(next(iter(self.entries)))
+            static_in = {k: v.detach().clone() for k, v in decoder_input.items()}
+            cur = torch.cuda.current_stream(dev)
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                for _ in range(2):                       # warm-up outside the capture (library handles, workspaces, attribute setup)
+                    self.decoder(dict(static_in))
+            cur.wait_stream(side)
+            torch.cuda.current_stream(dev).synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.decoder(dict(static_in))
+            srcs = []
+            for i in range(len(out["decoder"])):
+                lin = out["decoder"][i][0] if i < len(out["decoder"]) - 1 else out["decoder"][i]
+                srcs += [lin.weights, lin.biases] + ([lin.freq, lin.phase_shift] if hasattr(lin, "freq") else [])
+            e = self.entries[key] = {"graph": graph, "in": static_in, "out": out, "srcs": srcs, "done": None}
+        cur = torch.cuda.current_stream(dev)
+        if e["done"] is not None:
+            cur.wait_event(e["done"])
+        for k, v in decoder_input.items():
+            e["in"][k].copy_(v, non_blocking=True)
+        e["graph"].replay()
+        from .nets import EmittedFiLMLinear, EmittedLinear, Sine
+        fresh = [torch.empty_like(t) for t in e["srcs"]]
+        torch._foreach_copy_(fresh, e["srcs"])
+        model_out = e["out"]["model_out"].clone()
+        e["done"] = torch.cuda.Event()
+        e["done"].record(cur)
+        mods, it = [], iter(fresh)
+        n = len(e["out"]["decoder"])
+        for i in range(n - 1):
+            w, b, f, ph = next(it), next(it), next(it), next(it)
+            mods.append(nn.Sequential(EmittedFiLMLinear(w, b, f, ph), Sine()))
+        w, b = next(it), next(it)
+        mods.append(EmittedLinear(w, b))
+        decoder = nn.Sequential(*mods)
+        B = e["in"]["coords"].shape[0]
+        params = [decoder[i][0].weights.reshape(B, -1) for i in range(n - 1)] + [decoder[-1].weights.reshape(B, -1)]
+        return {"model_in": e["out"]["model_in"], "model_out": model_out, "params": params, "decoder": decoder}
 
 
 def build_frame(sdf_network, skinning_model, rendering_network, deviation_network, pose_cond, smpl_verts,
@@ -494,7 +582,14 @@ class MetaAvatarRender(nn.Module):
                     else:
                         raise ValueError("wrong nv_noise_type, expected either gaussian or rotation, got %s"
                                          % self.nv_noise_type)
-        out = self.sdf_decoder(decoder_input)
+        if (eval and dev.type == "cuda" and not torch.is_grad_enabled() and "rots_noise" not in decoder_input
+                and "latent" in decoder_input and os.environ.get("ARAH_HYPERNET_GRAPH", "1") != "0"):
+            graphed = self.__dict__.get("_graphed_decoder")
+            if graphed is None or graphed.decoder is not self.sdf_decoder:
+                graphed = self.__dict__["_graphed_decoder"] = _GraphedDecoder(self.sdf_decoder)
+            out = graphed(decoder_input)
+        else:
+            out = self.sdf_decoder(decoder_input)
         inputs.update({"loc": torch.zeros(B, 1, 3, device=dev), "sc_factor": torch.ones(B, 1, 1, device=dev),
                        "vol_feat": torch.empty(B, 0, device=dev), "sdf_network": out["decoder"]})
         if "latent_code_idx" in inputs["pose_cond"]:
