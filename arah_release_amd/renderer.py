@@ -81,6 +81,7 @@ class _GraphedDecoder:
     def __init__(self, decoder):
         self.decoder = decoder
         self.entries = {}
+        self.broken = False
 
     def _key(self, dev):
         ptrs = 0
@@ -587,7 +588,13 @@ class MetaAvatarRender(nn.Module):
             graphed = self.__dict__.get("_graphed_decoder")
             if graphed is None or graphed.decoder is not self.sdf_decoder:
                 graphed = self.__dict__["_graphed_decoder"] = _GraphedDecoder(self.sdf_decoder)
-            out = graphed(decoder_input)
+            try:
+                out = graphed(decoder_input) if not graphed.broken else self.sdf_decoder(decoder_input)
+            except RuntimeError as err:   # a capture the runtime refuses: the same launches, eagerly, from here on
+                import warnings
+                warnings.warn("hypernetwork graph capture failed (%s); this model runs the eager call from now on" % err)
+                graphed.broken = True
+                out = self.sdf_decoder(decoder_input)
         else:
             out = self.sdf_decoder(decoder_input)
         inputs.update({"loc": torch.zeros(B, 1, 3, device=dev), "sc_factor": torch.ones(B, 1, 1, device=dev),

@@ -42,6 +42,10 @@ F_SKIN = 105472         # 2*(3*128 + 3*128^2 + 128*25), one skinnin
 PEAK_F32_MFMA_TFLOPS = 157.3
 PEAK_F16_MFMA_TFLOPS = 2500.0
 PEAK_SPLIT_TFLOPS = PEAK_F16_MFMA_TFLOPS / 3.0   # three f16 MFMAs per fp32 product
+# what a loop of nothing but v_mfma_f32_16x16x32_f16 on random data sustains on an MI355X under its power budget, two waves per SIMD
+# (tools/ubench/mfma_shape.hip, profiles/r05_mfma_shape.txt: 1968 TFLOP/s at 2.0 GHz; one wave per SIMD 1693) -- context for
+# `frac`, which stays priced against the nominal peak
+MEASURED_F16_MFMA_TFLOPS = 1968.0
 
 
 def mixed_peak(parts):
@@ -567,12 +571,18 @@ def run(args, rt):
                          "avg_launch_ms": canon_avg_ms, "evaluations_per_launch": canon_evals,
                          "flops_per_evaluation": F_SKIN,
                          "peak_note": ("dense f16 MFMA peak / 3: three v_mfma_f32_16x16x32_f16 per fp32 product "
-                                       "(MI355X_MICROARCH.md)" if split else "dense fp32 MFMA peak")},
+                                       "(MI355X_MICROARCH.md)" if split else "dense fp32 MFMA peak"),
+                         "frac_of_measured_mfma_ceiling": (canon_achieved / (MEASURED_F16_MFMA_TFLOPS / 3.0)) if split else None,
+                         "measured_mfma_ceiling_note": "a loop of nothing but v_mfma_f32_16x16x32_f16 on random data sustains "
+                                                       "1968 TFLOP/s on this part (power-limited clock; tools/ubench/mfma_shape.hip, "
+                                                       "profiles/r05_mfma_shape.txt) = 656 TFLOP/s in this engine's algorithmic "
+                                                       "flops; context only, `frac` is against the nominal peak"},
             "roofline_k_density": {"bound": "mfma", "kernel": "k_density", "achieved": achieved, "peak": peak_fwd,
                                    "unit": "TFLOP/s", "frac": achieved / peak_fwd, "traffic": dens_traffic,
                                    "traffic_unit": "bytes/launch", "traffic_source": traffic_src, "traffic_live": False,
                                    "avg_launch_ms": dens_avg_ms, "samples_per_launch": dens_samples,
                                    "flops_per_sample": F_SDF,
+                                   "frac_of_measured_mfma_ceiling": (achieved / (MEASURED_F16_MFMA_TFLOPS / 3.0)) if split else None,
                                    "note": "second largest launch (the dominant one of round 1): SDF MLP forward on every "
                                            "valid sample"},
             "work": {"per_ray": {k: v / max(n_rays_local, 1) for k, v in counters.items()},
