@@ -20,6 +20,9 @@ Extra objects on the JSON line:
   roofline_k_density  the same for the second largest launch (round 1's dominant kernel): the SDF MLP forward on
                 every valid sample.
   exact_fp32_engine  the same frames with v_mfma_f32_16x16x4_f32 everywhere.
+  parity_vs_reference_frame  frame 0 of the workload, every ray, against the reference's OWN render of it (a committed fixture:
+                tests/golden/make_golden.py f7full ran taconite/arah-release on the CPU in the build container).
+  beta_sweep    the same frames with the VolSDF beta overridden (what exact lazy shading saves depends on it).
   cpu_baseline  the oracle (a torch-CPU restatement of the reference, pinned against it) on a bounded
                 sample of the same frame's rays, on the host cores of this box; rank 0, N == 1 only.
 """
@@ -324,6 +327,35 @@ class GpuRuntime:
                         "bit for bit).  With every valid sample shaded (value_full_shading) the figure does not depend on beta"
                         % (len(timed_inputs), n_streams),
                 "sweep": rows}
+
+    def reference_frame_parity(self, args):
+        """Frame 0 of the benchmark workload against the REFERENCE's own render of it (tests/golden/
+        f7_forward_zju377_mono_512x512_s64.npz: taconite/arah-release on the CPU, all 155 572 rays, written by
+        tests/golden/make_golden.py f7full in the build container; data, not code).  BASELINE.json's "+ PSNR vs ref"."""
+        import numpy as np
+        path = os.path.join(ROOT, "tests", "golden", "f7_forward_%s_%dx%d_s%d.npz" % (args.config, args.size, args.size, args.n_steps))
+        if not os.path.exists(path):
+            return None
+        g = np.load(path)
+        with torch.no_grad():
+            out = self.model(self.make_inputs(args.size, int(g["frame_idx"])), eval=True)
+        rgb = out["rgb_values"][0].double().cpu().numpy()
+        mask = out["network_body_mask"][0].cpu().numpy()
+        if rgb.shape != g["rgb_values"].shape:
+            return None
+        mse = float(np.mean((rgb - g["rgb_values"].astype(np.float64)) ** 2))
+        pc = out["points_cam"][0].cpu().numpy()
+        hit, hit_ref = np.abs(pc).sum(-1) > 0, np.abs(g["points_cam"]).sum(-1) > 0
+        both = hit & hit_ref
+        return {"note": "frame %d of this workload, every ray, against the reference's own render of it (fixture written by "
+                        "tests/golden/make_golden.py f7full: the reference on %d CPU threads, %.0f s)"
+                        % (int(g["frame_idx"]), int(g["reference_threads"]), float(g["reference_seconds"])),
+                "rays": int(rgb.shape[0]), "psnr_db": None if mse == 0 else -10.0 * float(np.log10(mse)),
+                "mask_agreement": float((mask == g["network_body_mask"]).mean()),
+                "surface_hit_agreement": float((hit == hit_ref).mean()),
+                "surface_points_within_2e-4": float((np.abs(pc[both] - g["points_cam"][both]).max(-1) <= 2e-4).mean()),
+                "reference_cpu_rays_per_s": float(rgb.shape[0] / float(g["reference_seconds"])),
+                "reference_cpu_threads": int(g["reference_threads"])}
 
     def cpu_baseline(self, args, near, far):
         return cpu_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.cpu_sample_rays,
@@ -637,6 +669,8 @@ def run(args, rt):
         if world == 1 and not args.no_train:
             line["training"] = rt.training_line()
             line["test_py_frame"] = rt.test_py_frame(args.size)
+        if world == 1 and hasattr(rt, "reference_frame_parity"):
+            line["parity_vs_reference_frame"] = rt.reference_frame_parity(args)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = rt.cpu_baseline(args, near, far)
             line["psnr_vs_oracle_db"] = line["cpu_baseline"].get("psnr_vs_oracle_db")

@@ -477,20 +477,29 @@ def make_f14():
     print("psnr", res["psnr"], "nan->-1 pixels", int((res["normal_pred"] == 0).all(0).sum()))
 
 
-def make_f7(which):
+def make_f7(which, full_frames=False):
     """F7: the reference's whole MetaAvatarRender.forward(eval=True) on small synthetic frames.  The last entry is BASELINE
-    config 5's sampling (128 samples per ray, 32 near / 32 far, H36M shapes) on a small frame."""
+    config 5's sampling (128 samples per ray, 32 near / 32 far, H36M shapes) on a small frame.
+    full_frames (round 5, `f7full`): BASELINE configs 1 and 2 at their FULL sizes -- 256 x 256 x 32 and the benchmark frame
+    itself, 512 x 512 x 64 -- rendered by the reference on the CPU (one and nine minutes on eight cores); the rays are what
+    synthetic.SyntheticScene makes for the frame and are not stored again."""
+    import time
     torch.set_num_threads(os.cpu_count())
     scene = synthetic.SyntheticScene(seed=0)
     for name, (H, W), (S, near, far), fidx in which:
         model, cfg = build_reference_model(name, S, near, far)
         inputs = scene.make_inputs(H, W, frame_idx=fidx)
+        t0 = time.time()
         with torch.no_grad():
             out = model(inputs, gen_cano_mesh=False, eval=True)
+        extra = {} if full_frames else dict(ray_dirs=inputs["ray_dirs"][0],
+                                            body_bounds_intersections=inputs["body_bounds_intersections"][0])
+        if full_frames:
+            extra["reference_seconds"] = np.float64(time.time() - t0)
+            extra["reference_threads"] = np.int64(torch.get_num_threads())
         save("f7_forward_%s_%dx%d_s%d.npz" % (name, H, W, S), frame_idx=fidx, H=H, W=W, n_steps=S, n_near=near,
              n_far=far, rgb_values=out["rgb_values"][0], points_cam=out["points_cam"][0],
-             network_body_mask=out["network_body_mask"][0], sdf_param0=out["sdf_params"][0][0, :16],
-             ray_dirs=inputs["ray_dirs"][0], body_bounds_intersections=inputs["body_bounds_intersections"][0])
+             network_body_mask=out["network_body_mask"][0], sdf_param0=out["sdf_params"][0][0, :16], **extra)
 
 
 def make_f15():
@@ -682,6 +691,7 @@ def make_f17():
     print("hidden |activation| max per layer:", amax, "converged", int(r3["valid_ids"].sum()), "of", Pb)
 
 
+F7_FULL = (("zju377_mono", (256, 256), (32, 8, 8), 1), ("zju377_mono", (512, 512), (64, 16, 16), 0))   # BASELINE configs 1 and 2
 F7_SET = (("zju377_mono", (64, 64), (64, 16, 16), 0), ("zju313", (64, 64), (64, 16, 16), 1), ("h36m", (48, 48), (32, 8, 8), 2),
           ("zju377_mono", (128, 128), (32, 8, 8), 5), ("h36m", (40, 40), (128, 32, 32), 3))
 
@@ -825,6 +835,8 @@ def make_f18():
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "f18":
         return make_f18()
+    if len(sys.argv) > 1 and sys.argv[1] == "f7full":
+        return make_f7(F7_FULL[int(sys.argv[2]):int(sys.argv[2]) + 1] if len(sys.argv) > 2 else F7_FULL, full_frames=True)
     if len(sys.argv) > 1 and sys.argv[1] == "f7c5":
         return make_f7(F7_SET[-1:])
     if len(sys.argv) > 1 and sys.argv[1] == "f17":

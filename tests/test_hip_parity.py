@@ -581,7 +581,9 @@ def test_shade_composite_against_reference(scene, name, tag, eng):
                                         ("f7_forward_zju313_64x64_s64.npz", "zju313"),
                                         ("f7_forward_h36m_48x48_s32.npz", "h36m"),
                                         ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono"),
-                                        ("f7_forward_h36m_40x40_s128.npz", "h36m")])   # BASELINE config 5's sampling (128, 32, 32)
+                                        ("f7_forward_h36m_40x40_s128.npz", "h36m"),   # BASELINE config 5's sampling (128, 32, 32)
+                                        ("f7_forward_zju377_mono_256x256_s32.npz", "zju377_mono"),   # BASELINE config 1, full size
+                                        ("f7_forward_zju377_mono_512x512_s64.npz", "zju377_mono")])  # BASELINE config 2: the benchmark frame, rendered by the reference
 @pytest.mark.parametrize("eng", ENGINES)
 def test_forward_against_reference(scene, fname, name, eng):
     """MetaAvatarRender.forward(inputs, eval=True): dict in / dict out vs the reference's dict (f7)."""
@@ -979,7 +981,7 @@ def test_batch_of_views_equals_single_views(scene):
 @gpu
 def test_config5_stress_1024_128(scene):
     """BASELINE config 5: 1024x1024, 128 samples/ray (near 32 / far 32), H36M shapes (idr colour net, canonical view
-    directions): one frame = ~6e5 rays, ~4e7 samples, ~29 GB of workspace.  Size-independent properties only."""
+    directions): one frame = ~4.9e5 rays, ~6.3e7 sample slots, 7.4 GB of workspace (122 bytes per sample slot).  Size-independent properties only."""
     from arah_release_amd import hip
     dev = torch.device("cuda:0")
     from arah_release_amd import config, renderer

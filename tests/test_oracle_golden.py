@@ -178,3 +178,26 @@ def test_f7_forward(scene, fname, name):
     assert (hit == hit_ref).mean() >= 0.995
     both = hit & hit_ref
     np.testing.assert_allclose(out["points_cam"].numpy()[both], g["points_cam"][both], rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("fname,n_sub", [("f7_forward_zju377_mono_256x256_s32.npz", 2048),    # BASELINE config 1 at its full size
+                                         ("f7_forward_zju377_mono_512x512_s64.npz", 1024)])   # BASELINE config 2: the benchmark frame
+def test_f7_full_frames_on_a_ray_subset(scene, fname, n_sub):
+    """The reference's own render of BASELINE configs 1 and 2 at FULL size (tests/golden/make_golden.py f7full: 256 x 256 x 32 and
+    the 512 x 512 x 64 benchmark frame, one and nine minutes of the reference on eight cores).  The oracle renders an evenly
+    spread subset of the frame's rays -- rays are independent, the subset is what make_inputs(max_rays=...) picks -- and must
+    agree with the reference's rows for those rays; the GPU test holds the HIP path to the whole frame."""
+    g = golden(fname)
+    model, cfg = get_model("zju377_mono")
+    H, W, fidx = int(g["H"]), int(g["W"]), int(g["frame_idx"])
+    n_full = int(g["rgb_values"].shape[0])
+    inputs = scene.make_inputs(H, W, frame_idx=fidx, max_rays=n_sub)
+    sel = np.linspace(0, n_full - 1, n_sub).round().astype(int)     # synthetic.make_inputs' own subsampling rule
+    out = O.render_inputs(model, inputs, cfg["model"]["cano_view_dirs"], int(g["n_steps"]), int(g["n_near"]), int(g["n_far"]))
+    assert (out["network_body_mask"].numpy() == g["network_body_mask"][sel]).mean() >= 0.995
+    assert psnr(out["rgb_values"].numpy(), g["rgb_values"][sel]) >= 45.0
+    hit_ref = np.abs(g["points_cam"][sel]).sum(-1) > 0
+    hit = np.abs(out["points_cam"].numpy()).sum(-1) > 0
+    assert (hit == hit_ref).mean() >= 0.995
+    both = hit & hit_ref
+    assert (np.abs(out["points_cam"].numpy()[both] - g["points_cam"][sel][both]).max(-1) <= 2e-4).mean() >= 0.999
