@@ -2367,6 +2367,10 @@ __global__ __launch_bounds__(kThreads, 2) void k_sdf_lattice(FrameDev fr, int gr
     }
 }
 
+#ifdef ARAH_REG_TRUNK   // round 5 experiment, not in the shipped library: the density pass on point-owning waves
+#include "regtrunk.hpp"
+#endif
+
 // ------------------------------------------------------------------------------------------
 // loop D: SDF value + normal (reverse sweep) + colour MLP + VolSDF density per valid sample
 // (IDR:291-368), then per-ray compositing (IDR:370-394)
@@ -2765,6 +2769,7 @@ struct Knobs {
     int trace_bulk;      // ARAH_TRACE_BULK_STEPS  loop A steps launched wide before the finisher
     int trace_small;     // ARAH_TRACE_SMALL       ray lists up to this length go to the finisher at once
     bool density_wide;   // ARAH_DENSITY_TILE=128  128-point tiles in the density pass
+    bool density_reg;    // ARAH_DENSITY_REG=1     the density pass on the point-owning trunk (regtrunk.hpp)
     int canon_lds_min;   // ARAH_CANON_LDS_MIN     loop C's point-owning-wave kernel asks for at least this much LDS (bytes): with
                          //                        more than half of the CU's 160 KB a half-size build (-DCW_WAVES=4) owns one slot per CU
     int canon_wg_per_cu; // ARAH_CANON_WG_PER_CU   resident workgroups of that kernel per CU (grid = this x CUs; 1)
@@ -2788,6 +2793,7 @@ inline const Knobs& knobs() {
         v.trace_bulk = max(0, min(kSphereIters, env_int("ARAH_TRACE_BULK_STEPS", 24)));
         v.trace_small = env_int("ARAH_TRACE_SMALL", 4096);
         v.density_wide = env_int("ARAH_DENSITY_TILE", 128) == 128;
+        v.density_reg = env_int("ARAH_DENSITY_REG", 0) == 1;
         v.canon_lds_min = max(0, min((int)kLdsCanonWave, env_int("ARAH_CANON_LDS_MIN", 0)));
         v.canon_wg_per_cu = max(1, min(4, env_int("ARAH_CANON_WG_PER_CU", 1)));
         const char* e = getenv("ARAH_TRAIN_ENGINE");
@@ -2897,6 +2903,9 @@ int setup_attributes_once() {
     allow_lds(k_density<false>, kLdsSdfFwd, failed);
     allow_lds(k_density<true>, kLdsSplitSolo, failed);
     allow_lds(k_density<true, 8>, kLdsDensityWide, failed);
+#ifdef ARAH_REG_TRUNK
+    allow_lds(k_density_reg, kLdsRegTrunk, failed);
+#endif
     allow_lds(k_sdf_lattice, kLdsDensityWide, failed);
     allow_lds(k_skin_eval, kLdsSkin, failed);
     allow_lds(k_skin_jac, kLdsSkin, failed);
@@ -3610,7 +3619,7 @@ int arah_counters_reset(void* workspace, void* stream) {
                                                                                                            : ARAH_E_LAUNCH;
 }
 
-#ifdef ARAH_CLOCKS
+#if defined(ARAH_CLOCKS) || defined(RT_CLOCKS)
 // instrumented builds only (tools/phase_clocks.py): the 2 x 8 x 16 phase clocks (loop C, k_shade) behind the counters;
 // syncs the stream
 int arah_debug_clocks(const void* workspace, unsigned long long* h_out, void* stream) {
@@ -4052,6 +4061,18 @@ int arah_sample_canonicalize(const ArahFrame* f, const ArahSampling* cfg, const 
                        rand_far, z, pts, T, mask, reinterpret_cast<hipStream_t>(stream));
 }
 
+#ifdef ARAH_REG_TRUNK
+// phase clocks of the point-owning trunk (instrumented builds, -DRT_CLOCKS: tools/probes/density_probe.py clocks)
+static unsigned long long* rt_clk_of(const Workspace& w) {
+#ifdef RT_CLOCKS
+    return w.ctr->clk;
+#else
+    (void)w;
+    return nullptr;
+#endif
+}
+#endif
+
 // ---- loop D -----------------------------------------------------------------------------------
 static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w, const float* dirs, const float* z,
                       const float* pts, const float* T, const uint8_t* mask, int32_t n, float* rgb, float* acc,
@@ -4067,6 +4088,13 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
         if (cfg->ev_density[0] && cfg->ev_density[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[0]), s);
         // long lists on the split engine: 128-point tiles, one workgroup per CU (ARAH_DENSITY_TILE=64 keeps the 64-point kernel)
+#ifdef ARAH_REG_TRUNK
+        if (fd.split && knobs().density_reg && Q >= 128ll * 1024)
+            hipLaunchKernelGGL(k_density_reg, dim3(min(num_cus(), grid_for(Q, kRtTile))), dim3(kRtThreads), kLdsRegTrunk, s, fd,
+                               pts, (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1],
+                               &w.ctr->n_sdf_fwd, &w.ctr->n_density, rt_clk_of(w));
+        else
+#endif
         if (fd.split && knobs().density_wide && Q >= 128ll * 1024)
             hipLaunchKernelGGL((k_density<true, 8>), dim3(min(num_cus(), grid_for(Q, 128))), dim3(kThreads), kLdsDensityWide, s, fd,
                                pts, (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1],

@@ -1193,6 +1193,35 @@ template <bool SPLIT = false>
 __device__ __forceinline__ void sdf_head(const SdfNet& net, const float* act, int ld, float* out, int ostride,
                                          int tid, int n_pts = kTile) {
     const int part = tid & 7;
+#ifdef ARAH_REG_TRUNK   // experiment builds only (regtrunk.hpp, profiles/r05_reg_trunk.txt): the shipped head is the loop below
+    if constexpr (SPLIT) {
+        // The split engine's head sums in the order a POINT-OWNING wave can follow without leaving its registers
+        // (regtrunk.hpp: lane group g of a point holds the units 32 q + 8 g + e): 32 chains (g, e) per point, each over
+        // q = 0 .. 7 with two fmas per unit -- the hi half, then the lo half, against w6 / 1024 (exact) -- then the tree over e
+        // and (t0 + t1) + (t2 + t3) over g.  Every kernel of the engine comes through here, so they all agree bit for bit.
+        for (int pt = tid >> 3; pt < n_pts; pt += kThreads / 8) {   // whole waves drop out: n_pts is a multiple of 8
+            float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = 32 * q + 8 * g + part;
+                    const float w = net.w6[ch] * kInvActScale;
+                    const char* row = reinterpret_cast<const char*>(act) + pt * ld * 4 + split_byte(pt, ch);
+                    s[g] = fmaf(w, (float)*reinterpret_cast<const _Float16*>(row), s[g]);
+                    s[g] = fmaf(w, (float)*reinterpret_cast<const _Float16*>(row + 512), s[g]);
+                }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                s[g] += __shfl_xor(s[g], 1);
+                s[g] += __shfl_xor(s[g], 2);
+                s[g] += __shfl_xor(s[g], 4);
+            }
+            if (part == 0) out[pt * ostride] = ((s[0] + s[1]) + (s[2] + s[3])) + net.b6[0];
+        }
+        return;
+    }
+#endif
     for (int pt = tid >> 3; pt < n_pts; pt += kThreads / 8) {   // whole waves drop out: n_pts is a multiple of 8
         float s = 0.f;
 #pragma unroll 8
