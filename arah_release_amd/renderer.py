@@ -139,6 +139,77 @@ class _GraphedDecoder:
         return {"model_in": e["out"]["model_in"], "model_out": model_out, "params": params, "decoder": decoder}
 
 
+class _FlatDecoder(nn.Module):
+    """sdf_decoder as a function of tensors to a tuple of tensors (what torch.cuda.make_graphed_callables captures)."""
+
+    def __init__(self, decoder):
+        super().__init__()
+        self.decoder = decoder
+
+    def forward(self, rots, Jtrs, latent):
+        out = self.decoder({"coords": torch.zeros(1, 1, 3, dtype=torch.float32, device=rots.device), "rots": rots, "Jtrs": Jtrs,
+                            "latent": latent})
+        d = out["decoder"]
+        flat = []
+        for i in range(len(d) - 1):
+            lin = d[i][0]
+            flat += [lin.weights, lin.biases, lin.freq, lin.phase_shift]
+        flat += [d[len(d) - 1].weights, d[len(d) - 1].biases, out["model_out"]]
+        return tuple(flat)
+
+
+class _TrainGraphedDecoder:
+    """The pose encoder + hypernetwork of a TRAINING step -- ~95 launches forward, ~300 in backward, a third of the step's
+    1100 and of the ~28 ms of host time they cost (profiles/r05_train_regions.txt; on a box with a slower host the step is
+    host-bound: 60-65 ms instead of 25) -- captured once as a forward and a backward graph (torch.cuda.make_graphed_callables)
+    and replayed inside autograd: same kernels, same order, same bits; the gradients of the 85.6 M hypernetwork parameters
+    arrive in the graph's static buffers.  Used when only the latent code of the call's inputs requires gradients (the
+    reference's training configuration without train_smpl); a re-allocated parameter re-captures.
+    OFF by default (ARAH_TRAIN_HYPERNET_GRAPH=1 switches it on): measured on the MI355X box it does not pay -- 26.2 ms per
+    step against 24.7 eager, and the process spends MORE host time per step (37 against 27 ms: replaying a 300-node graph is not
+    cheaper for this runtime than enqueueing its kernels); beside a busy loop on the same core (a host half as fast) 41.6
+    against 41.0 ms (tools/probes/train_host.py, profiles/r05_train_host.txt).  Gradients are the eager step's
+    (tests/test_hip_parity.py::test_graphed_training_hypernetwork_is_the_eager_one)."""
+
+    def __init__(self, decoder):
+        self.decoder = decoder
+        self.key = None
+        self.fn = None
+        self.broken = False
+
+    def _key(self, dev):
+        ptrs = 0
+        for p in self.decoder.parameters():
+            ptrs = (ptrs * 1000003 + p.data_ptr() + (7 if p.requires_grad else 0)) & 0xFFFFFFFFFFFF
+        return (dev, ptrs)
+
+    def __call__(self, decoder_input):
+        rots, Jtrs, latent = decoder_input["rots"], decoder_input["Jtrs"], decoder_input["latent"]
+        if "rots_noise" in decoder_input:   # siren_modules.py:288-289: outside the graph, one launch
+            rots = rots + decoder_input["rots_noise"]
+        dev = rots.device
+        key = self._key(dev)
+        if self.fn is None or self.key != key:
+            flat = _FlatDecoder(self.decoder)
+            sample = (rots.detach().clone(), Jtrs.detach().clone(), latent.detach().clone().requires_grad_(True))
+            torch.cuda.current_stream(dev).synchronize()
+            self.fn = torch.cuda.make_graphed_callables(flat, sample, allow_unused_input=True)
+            self.key = key
+        out = self.fn(rots.detach(), Jtrs.detach(), latent)
+        from .nets import EmittedFiLMLinear, EmittedLinear, Sine
+        mods, it = [], iter(out[:-1])
+        n = (len(out) - 3) // 4 + 1
+        for _ in range(n - 1):
+            w, b, f, ph = next(it), next(it), next(it), next(it)
+            mods.append(nn.Sequential(EmittedFiLMLinear(w, b, f, ph), Sine()))
+        w, b = next(it), next(it)
+        mods.append(EmittedLinear(w, b))
+        decoder = nn.Sequential(*mods)
+        B = 1
+        params = [decoder[i][0].weights.reshape(B, -1) for i in range(n - 1)] + [decoder[-1].weights.reshape(B, -1)]
+        return {"model_in": decoder_input["coords"], "model_out": out[-1], "params": params, "decoder": decoder}
+
+
 def build_frame(sdf_network, skinning_model, rendering_network, deviation_network, pose_cond, smpl_verts,
                 skinning_weights, bone_transforms, trans, coord_min, coord_max, center, precision=None, body_tables=None):
     """Pack one temporal frame for the kernels (weights emitted by the hypernetwork + body).
@@ -594,6 +665,19 @@ class MetaAvatarRender(nn.Module):
                 import warnings
                 warnings.warn("hypernetwork graph capture failed (%s); this model runs the eager call from now on" % err)
                 graphed.broken = True
+                out = self.sdf_decoder(decoder_input)
+        elif (not eval and dev.type == "cuda" and torch.is_grad_enabled() and "latent" in decoder_input
+              and not rots.requires_grad and not Jtrs.requires_grad and decoder_input["latent"].requires_grad
+              and os.environ.get("ARAH_TRAIN_HYPERNET_GRAPH", "0") == "1"):
+            tg = self.__dict__.get("_train_graphed_decoder")
+            if tg is None or tg.decoder is not self.sdf_decoder:
+                tg = self.__dict__["_train_graphed_decoder"] = _TrainGraphedDecoder(self.sdf_decoder)
+            try:
+                out = tg(decoder_input) if not tg.broken else self.sdf_decoder(decoder_input)
+            except RuntimeError as err:   # a capture the runtime refuses: the eager call from here on
+                import warnings
+                warnings.warn("training hypernetwork graph capture failed (%s); this model runs the eager call from now on" % err)
+                tg.broken = True
                 out = self.sdf_decoder(decoder_input)
         else:
             out = self.sdf_decoder(decoder_input)

@@ -93,6 +93,50 @@ def pmc_traffic(kernel, full_shading=False):
         return None, None
 
 
+def live_traffic(args, kernels, limit_s=150.0):
+    """HBM bytes per launch of `kernels` (name prefixes) measured on THIS box: two child runs of this file under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE, then WRITE_SIZE: separate passes, no other tracing domain), one
+    warm-up + one timed + one event-timed frame of the default path each, reduced as tools/rocpd_pmc.py does it
+    (MI355X_MICROARCH.md, HBM section: both counters in KiB; FETCH_SIZE doubled on gfx950, WRITE_SIZE as is).  Returns
+    ({prefix: bytes}, note) or (None, why)."""
+    import glob, re, shutil, sqlite3, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="arah_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
+             "--no-train", "--passes", "default", "--no-live-traffic", "--size", str(args.size), "--n-steps", str(args.n_steps),
+             "--config", args.config]
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([exe, "--kernel-trace", "--pmc", counter, "-d", d, "-o", "pmc", "--"] + child, cwd="/tmp",
+                               env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=limit_s)
+            dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True), key=os.path.getsize)
+            if r.returncode != 0 or not dbs:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
+            db = sqlite3.connect(dbs[-1])
+            rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? "
+                              "group by kernel_name", (counter,)).fetchall()
+            db.close()
+            for name, n, avg in rows:
+                short = re.sub(r"\(anonymous namespace\)::", "", name)
+                short = re.sub(r"\(.*", "", short).replace("void ", "")
+                per.setdefault(short, {})[counter] = (avg * 1024.0, n)
+    except Exception as e:   # a profiler that hangs or a database that is not there: the committed figure stays
+        return None, "live PMC passes failed: %s" % e
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for prefix in kernels:
+        k = next((v for n, v in sorted(per.items()) if n.startswith(prefix)), None)
+        if k and "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+            out[prefix] = 2.0 * k["FETCH_SIZE"][0] + k["WRITE_SIZE"][0]
+    return out, ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, two child runs of bench.py (--steps 1 --warmup 1 --streams 1 "
+                 "--passes default) spawned by this run on this box; FETCH_SIZE x 2 (gfx950), KiB -> bytes")
+
+
 def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu=None, dev=None):
     """Oracle on `sample_rays` rays spread evenly over frame 0 of the benchmark workload, timed on the host cores;
     the same rays are rendered by the HIP path and compared (BASELINE.json's "+ PSNR vs ref": the oracle is the
@@ -138,6 +182,9 @@ def main():
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not spawn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic on "
+                         "THIS box; the figure then comes from the newest committed profiles/*_pmc_traffic.json")
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight in the timed region of every pass (renderer.render_sequence: frame k on HIP stream "
                          "k mod N, own scratch each); 0 = the product's default for a sequence of --steps frames "
@@ -202,6 +249,15 @@ def main():
         global_dog.join()   # the timer thread holds the runtime (model, tensors): it must be gone before the interpreter winds down
     if rank == 0 and world == 1 and args.pipelined_streams > 1 and args.streams == 1:
         line = pipelined_extra(args, rt, line)
+    if rank == 0 and world == 1 and args.passes == "all" and not args.no_live_traffic and "roofline" in line:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got, note = live_traffic(args, [line["roofline"]["kernel"] + "<", "k_density<"])
+        for key, prefix in (("roofline", line["roofline"]["kernel"] + "<"), ("roofline_k_density", "k_density<")):
+            if got and prefix in got and key in line:
+                line[key].update({"traffic": got[prefix], "traffic_live": True, "traffic_source": note,
+                                  "traffic_committed_profile": line[key].get("traffic")})
+        line["live_traffic"] = {"ok": bool(got), "note": note, "seconds": time.perf_counter() - t0}
     if rank == 0:
         print(json.dumps(line))
     if world > 1:
@@ -415,15 +471,21 @@ class GpuRuntime:
             for k in range(warmup):
                 step(batches[k])
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             for k in range(warmup, warmup + steps):
                 step(batches[k])
+            c1 = time.process_time()
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         return {"note": "ZJUMOCAP-313 training step, 1 view x 2048 rays on one GPU: HIP ray tracer (no_grad) + hand-written "
                         "loop-D forward/backward and regulariser queries (k_shade_train) + compositing / loss / hypernetwork on "
                         "autograd + fused Adam",
-                "value": 2048 * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps}
+                "value": 2048 * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                "host_cpu_ms_per_step": 1e3 * (c1 - c0) / steps,
+                "host_note": "CPU time of this process until the last step was enqueued: the step is ~1100 launches, 24.9 ms of kernels "
+                             "and ~27 ms of host time on the round's usual boxes (24.7-26.4 ms per step); on a box whose host is "
+                             "slower it is host-bound (60-65 ms seen twice; 41 ms beside a busy loop on the same core, "
+                             "profiles/r05_train_host.txt)"}
 
 
 def pipelined_extra(args, rt, line, limit_s=90.0):

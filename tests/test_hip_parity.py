@@ -753,6 +753,57 @@ def test_graphed_hypernetwork_is_the_eager_one(scene, monkeypatch):
 
 
 @gpu
+def test_graphed_training_hypernetwork_is_the_eager_one(scene, monkeypatch):
+    """A training step replays the pose encoder + hypernetwork as captured forward / backward graphs
+    (renderer._TrainGraphedDecoder, torch.cuda.make_graphed_callables): losses and every one of the 211 gradients must be the
+    eager step's (to the run-to-run noise of the step's atomics), on the capture call and on a replay with another frame."""
+    from arah_release_amd import config, renderer, training
+    dev = torch.device("cuda:0")
+    frames = [3, 5]
+    draws = {}
+
+    def run(graph):
+        monkeypatch.setenv("ARAH_TRAIN_HYPERNET_GRAPH", "1" if graph else "0")
+        torch.manual_seed(0)
+        model, cfg = config.build_synthetic_model("zju313", device=dev, training=dict(pose_input_noise=False, view_input_noise=False))
+        model.train()
+        crit = training.build_loss(cfg)
+        res = []
+        for k in frames:
+            inp = scene.make_inputs(128, 128, frame_idx=k, max_rays=512, eval_mode=False, device=dev)
+            old = renderer.draw_uniform
+
+            def replay(shape, device, tag, k=k):   # the same jitter for both runs
+                key = (k, tag, tuple(shape))
+                if key not in draws:
+                    draws[key] = torch.rand(shape, device=device)
+                return draws[key]
+            renderer.draw_uniform = replay
+            try:
+                model.zero_grad(set_to_none=True)
+                losses = training.training_step(model, crit, inp)
+                losses["loss"].backward()
+            finally:
+                renderer.draw_uniform = old
+            res.append(({n: v.detach().clone() for n, v in losses.items()},
+                        {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        return res, model
+
+    eager, _ = run(False)
+    graphed, model = run(True)
+    tg = model.__dict__.get("_train_graphed_decoder")
+    assert tg is not None and tg.fn is not None and not tg.broken
+    for (le, ge), (lg, gg) in zip(eager, graphed):
+        # (the graphs replay the eager kernels; what is left between two runs of ANY step are the atomics of the loop-D kernels'
+        # reductions and list orders -- a few ulps)
+        for n in le:
+            assert abs(float(le[n]) - float(lg[n])) <= 1e-6 * abs(float(le[n])) + 1e-12, n
+        assert set(ge) == set(gg) and len(gg) == 211
+        for n in ge:
+            assert float((ge[n] - gg[n]).abs().max()) <= 1e-5 * float(ge[n].abs().max()) + 1e-12, n
+
+
+@gpu
 def test_shading_mode_follows_the_measured_share(scene):
     """The renderer picks lazy or full shading per frame from the share of sigma > 0 samples earlier frames reported (the
     counters travel to the host without a stream drain).  A subject with a large VolSDF beta (3e-2: nearly every sample has

@@ -48,6 +48,7 @@ def wrap(obj, attr, name):
 
 
 def main():
+    os.environ.setdefault("ARAH_TRAIN_HYPERNET_GRAPH", "0")   # the regions wrap the decoder with synchronising calls: no capture
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
