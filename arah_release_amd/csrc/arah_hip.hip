@@ -2285,6 +2285,9 @@ __global__ __launch_bounds__(kThreads, NT > 4 ? 2 : 4) void k_density(FrameDev f
     int* ids = reinterpret_cast<int*>(outv + TW * 4);    // [TW]
     float* actA = reinterpret_cast<float*>(ids + TW);    // [TW][kSdfLd]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef ARAH_PRIO_WAVES   // A/B (profiles/r05_ab_setprio.txt): static issue priority for one half of the workgroup's waves
+    if ((wave >= kWaves / 2) == (ARAH_PRIO_WAVES == 1)) __builtin_amdgcn_s_setprio(1);
+#endif
     const int n = *count;
     const float scale = sdf_scale(bc);
     const float inv_beta = 1.0f / fminf(fmaxf(fabsf(load_beta(fr)), 1e-6f), 1e6f);

@@ -117,6 +117,9 @@ __global__ __launch_bounds__(kCwThreads, kCwWaves >= 8 ? kCwWaves / 4 : 2) void 
 #endif
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
+#ifdef ARAH_PRIO_WAVES   // A/B (profiles/r05_ab_setprio.txt): static issue priority for one half of the workgroup's waves
+    if ((wave >= kCwWaves / 2) == (ARAH_PRIO_WAVES == 1)) __builtin_amdgcn_s_setprio(1);
+#endif
     // small operands first: their absolute LDS offsets stay below 64 KB, i.e. inside the offset field of the DS
     // instructions (one address register per lane pattern, not one per constant for the compiler to hoist and spill)
     float* w0c = smem;                   // kCwW0T: the input layer's A operands by row (32 bytes each)
