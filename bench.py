@@ -93,13 +93,31 @@ def pmc_traffic(kernel, full_shading=False):
         return None, None
 
 
+def pmc_db_per_kernel(path, counter):
+    """{kernel name without namespace and arguments: (average bytes per launch, launches)} of one counter (FETCH_SIZE or
+    WRITE_SIZE, both in KiB) in a rocprofv3 rocpd database -- the reduction of tools/rocpd_pmc.py."""
+    import re, sqlite3
+    db = sqlite3.connect(path)
+    try:
+        rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? "
+                          "group by kernel_name", (counter,)).fetchall()
+    finally:
+        db.close()
+    out = {}
+    for name, n, avg in rows:
+        short = re.sub(r"\(anonymous namespace\)::", "", name)
+        short = re.sub(r"\(.*", "", short).replace("void ", "")
+        out[short] = (avg * 1024.0, n)
+    return out
+
+
 def live_traffic(args, kernels, limit_s=150.0):
     """HBM bytes per launch of `kernels` (name prefixes) measured on THIS box: two child runs of this file under
     `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE, then WRITE_SIZE: separate passes, no other tracing domain), one
     warm-up + one timed + one event-timed frame of the default path each, reduced as tools/rocpd_pmc.py does it
     (MI355X_MICROARCH.md, HBM section: both counters in KiB; FETCH_SIZE doubled on gfx950, WRITE_SIZE as is).  Returns
     ({prefix: bytes}, note) or (None, why)."""
-    import glob, re, shutil, sqlite3, subprocess, tempfile
+    import glob, shutil, subprocess, tempfile
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
@@ -116,14 +134,8 @@ def live_traffic(args, kernels, limit_s=150.0):
             dbs = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True), key=os.path.getsize)
             if r.returncode != 0 or not dbs:
                 return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (counter, r.returncode)
-            db = sqlite3.connect(dbs[-1])
-            rows = db.execute("select kernel_name, count(*), avg(value) from counters_collection where counter_name=? "
-                              "group by kernel_name", (counter,)).fetchall()
-            db.close()
-            for name, n, avg in rows:
-                short = re.sub(r"\(anonymous namespace\)::", "", name)
-                short = re.sub(r"\(.*", "", short).replace("void ", "")
-                per.setdefault(short, {})[counter] = (avg * 1024.0, n)
+            for short, v in pmc_db_per_kernel(dbs[-1], counter).items():
+                per.setdefault(short, {})[counter] = v
     except Exception as e:   # a profiler that hangs or a database that is not there: the committed figure stays
         return None, "live PMC passes failed: %s" % e
     finally:

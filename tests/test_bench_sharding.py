@@ -212,3 +212,24 @@ def test_frames_in_flight_default():
     assert [renderer.frames_in_flight(n) for n in (0, 1, 3, 4, 8, 14, 15, 20, 400)] == [1, 1, 3, 4, 4, 4, 5, 5, 5]
     assert renderer.map_in_flight(lambda x: x + 1, []) == []
     assert renderer.map_in_flight(lambda x: x + 1, [1, 2, 3]) == [2, 3, 4]      # host-resident items: plain map
+
+
+def test_pmc_database_reduction(tmp_path):
+    """bench.live_traffic reduces the rocprofv3 --pmc databases of its child runs as tools/rocpd_pmc.py does: KiB -> bytes,
+    average per launch, kernel names without namespace and argument list."""
+    import sqlite3
+    import bench
+    path = str(tmp_path / "pmc_results.db")
+    db = sqlite3.connect(path)
+    db.execute("create table counters_collection (kernel_name text, counter_name text, value real)")
+    rows = [("void (anonymous namespace)::k_canon_wave<true, false>(FrameDev, int const*)", "FETCH_SIZE", 1000.0),
+            ("void (anonymous namespace)::k_canon_wave<true, false>(FrameDev, int const*)", "FETCH_SIZE", 3000.0),
+            ("void (anonymous namespace)::k_density<true, 8>(FrameDev, float const*)", "FETCH_SIZE", 10.0),
+            ("void (anonymous namespace)::k_density<true, 8>(FrameDev, float const*)", "WRITE_SIZE", 7.0)]
+    db.executemany("insert into counters_collection values (?, ?, ?)", rows)
+    db.commit()
+    db.close()
+    f = bench.pmc_db_per_kernel(path, "FETCH_SIZE")
+    assert f["k_canon_wave<true, false>"] == (2000.0 * 1024.0, 2)
+    assert f["k_density<true, 8>"] == (10.0 * 1024.0, 1)
+    assert bench.pmc_db_per_kernel(path, "WRITE_SIZE") == {"k_density<true, 8>": (7.0 * 1024.0, 1)}
