@@ -121,6 +121,8 @@ def live_traffic(args, kernels, limit_s=150.0):
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         return None, "rocprofv3 not found"
+    if any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in os.environ):
+        return None, "this run is itself under a profiler: no nested rocprofv3 passes"
     tmp = tempfile.mkdtemp(prefix="arah_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
              "--no-train", "--passes", "default", "--no-live-traffic", "--size", str(args.size), "--n-steps", str(args.n_steps),
