@@ -4227,8 +4227,8 @@ int arah_shade_train_forward(const ArahFrame* f, const ArahTrainIn* in, float* s
     const int g = min(grid_for(in->n, kTile), kMaxGrid / 2);   // one workgroup per CU (140 KB of LDS)
     const bool idr = f->col_mode == ARAH_COLOR_IDR;
 #define ARAH_LAUNCH_TRAIN(IDR_, BWD_, B3_, SLAB_)                                                                        \
-    hipLaunchKernelGGL((k_shade_train<IDR_, BWD_, B3_>), dim3(g), dim3(kThreads), lds_shade_train<IDR_>(), s, fd,        \
-                       colT_of(*f), b3_of(*f), ti, to, w.spill, SLAB_)
+    hipLaunchKernelGGL((k_shade_train<IDR_, BWD_, B3_>), dim3(g), dim3(kThreads), lds_shade_train<IDR_>(), s,            \
+                       TrainArgs{fd, colT_of(*f), b3_of(*f), ti, to, w.spill, SLAB_})
     if (train_b3(*f)) {
         if (idr) ARAH_LAUNCH_TRAIN(true, false, true, (f32x4*)nullptr);
         else ARAH_LAUNCH_TRAIN(false, false, true, (f32x4*)nullptr);

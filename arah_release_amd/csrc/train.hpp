@@ -105,9 +105,36 @@ __device__ __forceinline__ void reduce_channels(const float (&p)[kSdfMT][4], flo
 
 // B3: the backward-direction products (colour reverse sweep, tangent pass, both adjoint sweeps: 21 of the 34 layer products
 // of the backward kernel) run on the bf16 x 3 engine (mlp.hpp: gemm_acc_b3); false: everything on the fp32 MFMA
+// The call's two pointer tables (TrainIn: 20 words, TrainOut: 37 pointers) are NOT kernel-argument registers: every use
+// reads its word from the kernarg segment where it stands (a scalar load behind an address the compiler cannot see through, so it
+// neither hoists nor keeps them).  As by-value arguments they sat in ~110 scalar registers for the whole kernel, spilled into
+// vector lanes and pushed 200 vector registers to scratch (331 scratch instructions in the idr backward instance).
+struct TrainArgs {
+    FrameDev fr;
+    ColNetT ct;
+    B3Nets b3;
+    TrainIn in;
+    TrainOut out;
+    f32x4* spill_all;
+    f32x4* slab_all;
+};
+template <typename Tp>
+__device__ __forceinline__ const __attribute__((address_space(4))) Tp& karg_at(unsigned off) {
+    typedef const __attribute__((address_space(4))) char c4;
+    c4* p = (c4*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return *reinterpret_cast<const __attribute__((address_space(4))) Tp*>(p + off);
+}
+#define TI karg_at<TrainIn>(offsetof(TrainArgs, in))
+#define TO karg_at<TrainOut>(offsetof(TrainArgs, out))
+
 template <bool IDR, bool BWD, bool B3>
-__global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT ct, B3Nets b3, TrainIn in, TrainOut out,
-                                                          f32x4* spill_all, f32x4* slab_all) {
+__global__ __launch_bounds__(kThreads) void k_shade_train(TrainArgs ka) {
+    const FrameDev& fr = ka.fr;
+    const ColNetT& ct = ka.ct;
+    const B3Nets& b3 = ka.b3;
+    f32x4* const spill_all = ka.spill_all;
+    f32x4* const slab_all = ka.slab_all;
     typedef ColDims<IDR> D;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* xin = smem;                        // [64][4]
@@ -122,7 +149,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int j = lane & 15, g = lane >> 4;
     const int mt0 = wave * kSdfMT;
-    const int n = in.n;
+    const int n = TI.n;
     f32x4* spill = spill_all + (size_t)blockIdx.x * kSpillPerWg;
     f32x4* vslab = slab_all ? slab_all + (size_t)blockIdx.x * kTrainSlabPerWg : nullptr;        // v_k
     f32x4* vdslab = vslab ? vslab + 6 * kWaves * (kSdfMT * kNT) * 64 : nullptr;                 // vd_k
@@ -135,28 +162,28 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             f32x4 x = {0.f, 0.f, 0.f, 0.f}, gi = {0.f, 0.f, 0.f, 0.f};
             if (tid < rows) {
                 const long long p = row0 + tid;
-                x = f32x4{in.x[p * 3], in.x[p * 3 + 1], in.x[p * 3 + 2], 0.f};
-                if (BWD) gi = f32x4{in.g_rgb[p * 3], in.g_rgb[p * 3 + 1], in.g_rgb[p * 3 + 2], in.g_s[p]};
+                x = f32x4{TI.x[p * 3], TI.x[p * 3 + 1], TI.x[p * 3 + 2], 0.f};
+                if (BWD) gi = f32x4{TI.g_rgb[p * 3], TI.g_rgb[p * 3 + 1], TI.g_rgb[p * 3 + 2], TI.g_s[p]};
             }
             reinterpret_cast<f32x4*>(xin)[tid] = x;
             reinterpret_cast<f32x4*>(gin)[tid] = gi;
         }
         __syncthreads();
         f32x4 dlast[kSdfMT][kNT];
-        const bool geom = in.geom_only != 0;
-        const bool handed = BWD && (geom || in.fwd_rgb != nullptr);   // the forward call left cin, c1..c5 and rgb (or there is
+        const bool geom = TI.geom_only != 0;
+        const bool handed = BWD && (geom || TI.fwd_rgb != nullptr);   // the forward call left cin, c1..c5 and rgb (or there is
         if (handed) {                                                 // no colour MLP): only the trunk is recomputed
             if constexpr (BWD) {
                 TrainTap tap;
                 tap.aslab = vslab;
-                for (int k = 0; k < 6; ++k) tap.h[k] = out.h[k];
+                for (int k = 0; k < 6; ++k) tap.h[k] = TO.h[k];
                 tap.row0 = row0;
                 tap.rows = rows;
                 sdf_trunk<false, kNT, B3, TrainTap>(net, xin, A, ldA, nullptr, dlast, wave, lane, tap);   // v_k, h_k only
                 if (geom) {   // the feature stream of dw_7; the colour MLP's gradient into h_6 is zero
                     if constexpr (B3) unsplit_rows(A, ldA, tid);
                     __syncthreads();
-                    stream_rows(A, ldA, 256, out.c[0], row0, rows, tid);
+                    stream_rows(A, ldA, 256, TO.c[0], row0, rows, tid);
                     __syncthreads();
                     for (int e = tid; e < kTile * 64; e += kThreads)
                         *reinterpret_cast<f32x4*>(A + (e >> 6) * ldA + (e & 63) * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -164,12 +191,12 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 for (int e = tid; e < kTile * 64; e += kThreads) {   // B <- c5
                     const int r = e >> 6, c4 = e & 63;
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (r < rows) v = reinterpret_cast<const f32x4*>(in.tap_c[4] + (row0 + r) * 256)[c4];
+                    if (r < rows) v = reinterpret_cast<const f32x4*>(TI.tap_c[4] + (row0 + r) * 256)[c4];
                     *reinterpret_cast<f32x4*>(B + r * ldB + c4 * 4) = v;
                 }
                 if (!geom && tid < kTile) {
                     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                    if (tid < rows) v = reinterpret_cast<const f32x4*>(in.fwd_rgb)[row0 + tid];
+                    if (tid < rows) v = reinterpret_cast<const f32x4*>(TI.fwd_rgb)[row0 + tid];
                     reinterpret_cast<f32x4*>(rgbv)[tid] = v;
                 }
                 __syncthreads();
@@ -179,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         if constexpr (BWD) {
             TrainTap tap;
             tap.aslab = vslab;
-            for (int k = 0; k < 6; ++k) tap.h[k] = out.h[k];
+            for (int k = 0; k < 6; ++k) tap.h[k] = TO.h[k];
             tap.row0 = row0;
             tap.rows = rows;
             sdf_trunk<true, kNT, B3, TrainTap>(net, xin, A, ldA, spill, dlast, wave, lane, tap);
@@ -198,8 +225,8 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         if (geom) {   // regulariser queries: value and normal are the outputs
             if (tid < rows) {
                 const long long p = row0 + tid;
-                out.sdf[p] = outv[tid * 4];
-                reinterpret_cast<f32x4*>(out.rgb)[p] = f32x4{outv[tid * 4 + 1], outv[tid * 4 + 2], outv[tid * 4 + 3], 0.f};
+                TO.sdf[p] = outv[tid * 4];
+                reinterpret_cast<f32x4*>(TO.rgb)[p] = f32x4{outv[tid * 4 + 1], outv[tid * 4 + 2], outv[tid * 4 + 3], 0.f};
             }
             __syncthreads();
             continue;
@@ -211,8 +238,8 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             float vx = 0.f, vy = 0.f, vz = 0.f;
             if (tid < rows) {
                 const long long p = row0 + tid;
-                if (in.rotate_normal) {                               // IDR:340
-                    const float* Tq = in.T + p * 16;
+                if (TI.rotate_normal) {                               // IDR:340
+                    const float* Tq = TI.T + p * 16;
                     const float ax = Tq[0] * nx + Tq[1] * ny + Tq[2] * nz;
                     const float ay = Tq[4] * nx + Tq[5] * ny + Tq[6] * nz;
                     const float az = Tq[8] * nx + Tq[9] * ny + Tq[10] * nz;
@@ -220,14 +247,14 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     ny = ay;
                     nz = az;
                 }
-                vx = in.view[p * 3];
-                vy = in.view[p * 3 + 1];
-                vz = in.view[p * 3 + 2];
-                if (in.ray_augm) {                                    // IDR:342-350: arccos(n^ . v) >= pi/2  <=>  n . v <= 0
+                vx = TI.view[p * 3];
+                vy = TI.view[p * 3 + 1];
+                vz = TI.view[p * 3 + 2];
+                if (TI.ray_augm) {                                    // IDR:342-350: arccos(n^ . v) >= pi/2  <=>  n . v <= 0
                     if (nx * vx + ny * vy + nz * vz <= 0.f) {
-                        vx = in.view_orig[p * 3];
-                        vy = in.view_orig[p * 3 + 1];
-                        vz = in.view_orig[p * 3 + 2];
+                        vx = TI.view_orig[p * 3];
+                        vy = TI.view_orig[p * 3 + 1];
+                        vz = TI.view_orig[p * 3 + 2];
                     }
                 }
             }
@@ -259,10 +286,10 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         }
         __syncthreads();
         ColTap ctap;
-        const bool taps = BWD || in.tap_cin != nullptr;
+        const bool taps = BWD || TI.tap_cin != nullptr;
         if (taps) {
-            ctap.cin = BWD ? out.cin : in.tap_cin;
-            for (int l = 0; l < 5; ++l) ctap.c[l] = BWD ? out.c[l] : in.tap_c[l];
+            ctap.cin = BWD ? TO.cin : TI.tap_cin;
+            for (int l = 0; l < 5; ++l) ctap.c[l] = BWD ? TO.c[l] : TI.tap_c[l];
             ctap.row0 = row0;
             ctap.rows = rows;
         }
@@ -270,8 +297,8 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
         __syncthreads();
         if (tid < rows) {
             const long long p = row0 + tid;
-            out.sdf[p] = outv[tid * 4];
-            reinterpret_cast<f32x4*>(out.rgb)[p] = f32x4{rgbv[tid * 4], rgbv[tid * 4 + 1], rgbv[tid * 4 + 2], 0.f};
+            TO.sdf[p] = outv[tid * 4];
+            reinterpret_cast<f32x4*>(TO.rgb)[p] = f32x4{rgbv[tid * 4], rgbv[tid * 4 + 1], rgbv[tid * 4 + 2], 0.f};
         }
         }   // !handed
         if constexpr (BWD) {
@@ -280,7 +307,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     const f32x4 nt = {gin[tid * 4], gin[tid * 4 + 1], gin[tid * 4 + 2], 0.f};
                     reinterpret_cast<f32x4*>(ntl)[tid] = nt;
                     reinterpret_cast<f32x4*>(rgbv)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (tid < rows) reinterpret_cast<f32x4*>(out.hd[0])[row0 + tid] = nt;
+                    if (tid < rows) reinterpret_cast<f32x4*>(TO.hd[0])[row0 + tid] = nt;
                 }
                 __syncthreads();
             } else {
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     dl[c] = gin[tid * 4 + c] * y * (1.0f - y);
                 }
                 reinterpret_cast<f32x4*>(d5)[tid] = dl;
-                if (tid < rows) reinterpret_cast<f32x4*>(out.d[5])[row0 + tid] = dl;
+                if (tid < rows) reinterpret_cast<f32x4*>(TO.d[5])[row0 + tid] = dl;
             }
             __syncthreads();
             // delta_4 = (W_5^T delta_5) * [c5 > 0], in place over c5 (every lane rewrites exactly what it read)
@@ -316,7 +343,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 }
             }
             __syncthreads();
-            stream_rows(B, ldB, 256, out.d[4], row0, rows, tid);
+            stream_rows(B, ldB, 256, TO.d[4], row0, rows, tid);
             // one step of the reverse sweep: dst(B) <- (W^T B) * [c > 0] with c read from its stream
             auto mask_store = [&](const f32x4 (&acc)[2][kNT], const float* cstream, int width) {
 #pragma unroll
@@ -342,10 +369,10 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
                 gemm_any<B3, 16, 2>(ct.w4pT, b3.colT[5], mt0, B, ldB, acc, lane);
                 __syncthreads();
-                mask_store(acc, out.c[3], 256);
+                mask_store(acc, TO.c[3], 256);
             }
             __syncthreads();
-            stream_rows(B, ldB, 256, out.d[3], row0, rows, tid);
+            stream_rows(B, ldB, 256, TO.d[3], row0, rows, tid);
             {   // [dCin | dc3] = W_3^T delta_3: dCin part into A (kInPad wide), dc3 (128 wide) masked -> delta_2
                 for (int mt = wave; mt < D::kKC0; mt += kWaves) {
                     f32x4 acc[1][kNT];
@@ -366,7 +393,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 for (int nn = 0; nn < kNT; ++nn) {
                     const int pt = nn * 16 + j;
                     f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                    if (pt < rows) c = *reinterpret_cast<const f32x4*>(out.c[2] + (row0 + pt) * 128 + ch0);
+                    if (pt < rows) c = *reinterpret_cast<const f32x4*>(TO.c[2] + (row0 + pt) * 128 + ch0);
                     f32x4 o;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = c[r] > 0.f ? acc3[0][nn][r] : 0.f;
@@ -374,7 +401,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 }
             }
             __syncthreads();
-            stream_rows(B, ldB, 128, out.d[2], row0, rows, tid);
+            stream_rows(B, ldB, 128, TO.d[2], row0, rows, tid);
             {   // delta_1 = (W_2^T delta_2) * [c2 > 0]   (K = 128)
                 f32x4 acc[2][kNT];
 #pragma unroll
@@ -383,10 +410,10 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
                 gemm_any<B3, 8, 2>(ct.w2pT, b3.colT[2], mt0, B, ldB, acc, lane);
                 __syncthreads();
-                mask_store(acc, out.c[1], 256);
+                mask_store(acc, TO.c[1], 256);
             }
             __syncthreads();
-            stream_rows(B, ldB, 256, out.d[1], row0, rows, tid);
+            stream_rows(B, ldB, 256, TO.d[1], row0, rows, tid);
             {   // delta_0 = (W_1^T delta_1) * [c1 > 0]
                 f32x4 acc[2][kNT];
 #pragma unroll
@@ -395,10 +422,10 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     for (int nn = 0; nn < kNT; ++nn) zero_acc(acc[m][nn]);
                 gemm_any<B3, 16, 2>(ct.w1pT, b3.colT[1], mt0, B, ldB, acc, lane);
                 __syncthreads();
-                mask_store(acc, out.c[0], 256);
+                mask_store(acc, TO.c[0], 256);
             }
             __syncthreads();
-            stream_rows(B, ldB, 256, out.d[0], row0, rows, tid);
+            stream_rows(B, ldB, 256, TO.d[0], row0, rows, tid);
             // dCin += W_0^T delta_0
             for (int mt = wave; mt < D::kKC0; mt += kWaves) {
                 f32x4 acc[1][kNT];
@@ -414,8 +441,8 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             if (tid < kTile) {
                 const float* e = A + tid * ldA + 256;
                 float tx = e[3], ty = e[4], tz = e[5];
-                if (in.rotate_normal && tid < rows) {                 // n_rot = R n  ->  nt = R^T nt_rot
-                    const float* Tq = in.T + (row0 + tid) * 16;
+                if (TI.rotate_normal && tid < rows) {                 // n_rot = R n  ->  nt = R^T nt_rot
+                    const float* Tq = TI.T + (row0 + tid) * 16;
                     const float ax = Tq[0] * tx + Tq[4] * ty + Tq[8] * tz;
                     const float ay = Tq[1] * tx + Tq[5] * ty + Tq[9] * tz;
                     const float az = Tq[2] * tx + Tq[6] * ty + Tq[10] * tz;
@@ -426,7 +453,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 const f32x4 nt = {tx, ty, tz, 0.f};
                 reinterpret_cast<f32x4*>(ntl)[tid] = nt;
                 reinterpret_cast<f32x4*>(rgbv)[tid] = f32x4{e[0], e[1], e[2], 0.f};   // direct dL/dx, kept for the end
-                if (tid < rows) reinterpret_cast<f32x4*>(out.hd[0])[row0 + tid] = nt;
+                if (tid < rows) reinterpret_cast<f32x4*>(TO.hd[0])[row0 + tid] = nt;
             }
             __syncthreads();
             }   // !geom
@@ -461,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
             __syncthreads();
 #pragma unroll 1
             for (int k = 1; k < 6; ++k) {
-                stream_rows(B, ldB, 256, out.hd[k], row0, rows, tid);
+                stream_rows(B, ldB, 256, TO.hd[k], row0, rows, tid);
                 f32x4 acc[kSdfMT][kNT];
 #pragma unroll
                 for (int m = 0; m < kSdfMT; ++m)
@@ -487,7 +514,7 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                 }
                 __syncthreads();
             }
-            stream_rows(B, ldB, 256, out.hd[6], row0, rows, tid);
+            stream_rows(B, ldB, 256, TO.hd[6], row0, rows, tid);
             __syncthreads();
             // =========================================================== 4. reverse sweep of both streams
             // A[:, :256] <- adj h_6 = dL/dh_6 + g_s w_7 ;  B <- adj hd_6 = w_7
@@ -538,11 +565,11 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                         *reinterpret_cast<f32x4*>(B + pt * ldB + ch0) = avd;
                     }
                 }
-                reduce_channels(pf, out.film_f + k * 256, mt0, lane);
-                reduce_channels(pp, out.film_p + k * 256, mt0, lane);
+                reduce_channels(pf, TO.film_f + k * 256, mt0, lane);
+                reduce_channels(pp, TO.film_p + k * 256, mt0, lane);
                 __syncthreads();
-                stream_rows(A, ldA, 256, out.av[k], row0, rows, tid);
-                stream_rows(B, ldB, 256, out.avd[k], row0, rows, tid);
+                stream_rows(A, ldA, 256, TO.av[k], row0, rows, tid);
+                stream_rows(B, ldB, 256, TO.avd[k], row0, rows, tid);
                 if (k > 0) {   // the two streams one after the other: eight accumulators live, not sixteen
 #pragma unroll 1
                     for (int which = 0; which < 2; ++which) {
@@ -586,13 +613,16 @@ __global__ __launch_bounds__(kThreads) void k_shade_train(FrameDev fr, ColNetT c
                     gz += __shfl_xor(gz, o);
                 }
                 if (part == 0 && pt < rows)
-                    reinterpret_cast<f32x4*>(out.gx)[row0 + pt] =
+                    reinterpret_cast<f32x4*>(TO.gx)[row0 + pt] =
                         f32x4{gx + rgbv[pt * 4], gy + rgbv[pt * 4 + 1], gz + rgbv[pt * 4 + 2], 0.f};
             }
         }
         __syncthreads();
     }
 }
+
+#undef TI
+#undef TO
 
 // ---- VolSDF density + alpha compositing of the training forward, with their backward (IDR:363-394) --------------------
 // One thread per ray over its L valid samples, which sit next to each other in the compacted per-sample arrays (offset

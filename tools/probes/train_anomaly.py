@@ -27,7 +27,7 @@ def main():
     torch.cuda.set_device(0)
     model, cfg = config.build_synthetic_model("zju377_mono", 64, 16, 16, device=dev)
     rt = bench.GpuRuntime(1, 0, dev, None, model, cfg, synthetic.SyntheticScene(0), hip)
-    out = {"graph": os.environ.get("ARAH_HYPERNET_GRAPH", "1")}
+    out = {"inference_graph": os.environ.get("ARAH_HYPERNET_GRAPH", "1"), "training_graph": os.environ.get("ARAH_TRAIN_HYPERNET_GRAPH", "0")}
     out["a_fresh"] = dict(rt.training_line(steps=8, warmup=3), **mem())
     frames = [rt.make_inputs(512, k) for k in range(6)]
     with torch.no_grad():
