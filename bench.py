@@ -464,10 +464,18 @@ class GpuRuntime:
                              "ms_per_step": 1e3 * dt / steps}
         return line
 
-    def training_line(self, steps=5, warmup=2):
+    def training_line(self, steps=5, warmup=4):
         """Training step of BASELINE.json configs[2] (ZJUMOCAP-313 shapes, one view of 2048 rays on this GPU): forward
         (HIP ray tracer + hand-written loop D) + IDHRLoss + backward + Adam."""
         from arah_release_amd import config, training
+        # the inference passes before this line leave tens of GB of cached blocks (scratches of five streams, the full-shading
+        # slabs) in torch's allocator; the step's own 350 MB gradient blocks then came out of device allocations / frees in the
+        # timed steps every other run (64 against 25 ms per step on the same box, same build): start from an empty cache and
+        # let the allocator settle during the warm-up steps
+        import gc
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
         model, cfg = config.build_synthetic_model("zju313", device=self.dev)
         model.train()
         opt = training.configure_optimizers(model, cfg)
@@ -485,21 +493,31 @@ class GpuRuntime:
             for k in range(warmup):
                 step(batches[k])
             torch.cuda.synchronize()
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+            stats0 = torch.cuda.memory_stats(self.dev)
             t0, c0 = time.perf_counter(), time.process_time()
+            marks[0].record()
             for k in range(warmup, warmup + steps):
                 step(batches[k])
+                marks[k - warmup + 1].record()
             c1 = time.process_time()
             torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        stats1 = torch.cuda.memory_stats(self.dev)
+        each = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         return {"note": "ZJUMOCAP-313 training step, 1 view x 2048 rays on one GPU: HIP ray tracer (no_grad) + hand-written "
                         "loop-D forward/backward and regulariser queries (k_shade_train) + compositing / loss / hypernetwork on "
                         "autograd + fused Adam",
                 "value": 2048 * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                 "host_cpu_ms_per_step": 1e3 * (c1 - c0) / steps,
-                "host_note": "CPU time of this process until the last step was enqueued: the step is ~1100 launches, 24.9 ms of kernels "
-                             "and ~27 ms of host time on the round's usual boxes (24.7-26.4 ms per step); on a box whose host is "
-                             "slower it is host-bound (60-65 ms seen twice; 41 ms beside a busy loop on the same core, "
-                             "profiles/r05_train_host.txt)"}
+                "ms_each_step": each,
+                "device_allocations_in_the_timed_steps": int(stats1.get("num_device_alloc", 0) - stats0.get("num_device_alloc", 0)),
+                "device_frees_in_the_timed_steps": int(stats1.get("num_device_free", 0) - stats0.get("num_device_free", 0)),
+                "host_note": "CPU time of this process until the last step was enqueued (the step is ~1100 launches, 24.9 ms of kernels, "
+                             "~27-30 ms of host time).  Earlier in round 5 this line came back at 60-65 ms every other run: the step's "
+                             "350 MB gradient blocks were device allocations / frees inside the timed steps when the inference passes "
+                             "had left torch's allocator full of other sizes; the line now starts from an empty cache with four warm-up "
+                             "steps (4 of 4 runs 24.6-25.8 ms, profiles/r05_train_host.txt)"}
 
 
 def pipelined_extra(args, rt, line, limit_s=90.0):
