@@ -585,7 +585,13 @@ def run(args, rt):
         rt.set_adaptive(False)   # the passes measure the path they name; the product's own choice is reported by beta_sweep
         rt.set_precision(precision)
         n_streams = args.streams if n_streams is None else n_streams
-        rt.render_many(warm_inputs, n_streams)
+        # every stream of the timed region sees a warm-up frame (torch's caching allocator keeps a pool per stream: with W < the
+        # frames in flight the cold streams' first frames went to the driver for memory inside the timed region, 16 device
+        # allocations and +1.3 ms per frame over an eight-frame pass, tools/probes/alloc_probe.py): the W frames are repeated
+        warm = list(warm_inputs)
+        while warm_inputs and len(warm) < n_streams:
+            warm += list(warm_inputs)
+        rt.render_many(warm[:max(len(warm_inputs), n_streams)], n_streams)
         sync()
         rt.prepare(n_rays_max, args.n_steps)   # every scratch sized for the largest frame before anything is timed or counted
         rt.reset_counters()
