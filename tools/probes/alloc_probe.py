@@ -22,12 +22,13 @@ def main():
         torch.cuda.synchronize()
         for rep in range(4):
             s0 = torch.cuda.memory_stats(dev)
-            t0 = time.perf_counter()
+            t0, c0 = time.perf_counter(), time.process_time()
             rt.render_many(frames[2:], 4)
+            c1 = time.process_time()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             s1 = torch.cuda.memory_stats(dev)
-            out.append({"ms_per_frame": round(1e3 * dt / 8, 2),
+            out.append({"ms_per_frame": round(1e3 * dt / 8, 2), "host_cpu_ms_per_frame": round(1e3 * (c1 - c0) / 8, 2),
                         "device_alloc": int(s1.get("num_device_alloc", 0) - s0.get("num_device_alloc", 0)),
                         "device_free": int(s1.get("num_device_free", 0) - s0.get("num_device_free", 0)),
                         "reserved_GB": round(torch.cuda.memory_reserved() / 2**30, 2)})
