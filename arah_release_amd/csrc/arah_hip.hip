@@ -124,8 +124,16 @@ FrameDev to_dev(const ArahFrame& f) {
     return d;
 }
 
+struct TierStatsRaw {   // ArahCounters.n_tier_*: rays classified, of them surface rays / promoted / skipped; samples sent to phase 1,
+                        // to phase 2, never evaluated; rays that sent a witness
+    unsigned long long rays, rays_surface, rays_promoted, rays_skipped, samples_p1, samples_p2, samples_skipped, witnesses;
+};
 struct Counters {
     unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, n_density, n_canon, n_split_nonfinite;
+    // tiered eval forward (tier.hpp): ray / sample bookkeeping, and the share of n_canon / n_density that phase 2 ran
+    TierStatsRaw tier;
+    unsigned long long n_canon_p2, n_density_p2;
+    unsigned long long tier_snap[2];
     unsigned long long clk[8 * 16];   // instrumented builds (-DARAH_CLOCKS): s_memtime ticks per wave slot and phase
     unsigned long long clk_shade[8 * 16];   // the same for k_shade
 };
@@ -2669,6 +2677,7 @@ __global__ void k_points_cam(FrameDev fr, int n, RaySet rs, const float* dists, 
     }
 }
 
+#include "tier.hpp"
 }  // namespace
 #include "train.hpp"
 #include "meshquery.hpp"
@@ -2713,6 +2722,10 @@ struct Workspace {
     uint8_t* o_mask;
     uint8_t* q_smask;
     f32x4* shaded;
+    // tiered eval forward: two more sample lists, its device-side counts, the tier of every ray
+    int *listC, *listD;
+    int* tcounts;         // [TC_COUNT]
+    uint8_t* ray_tier;    // [N] 0 skipped (certified zero), 1 surface ray, 2 promoted
     size_t bytes;
 };
 
@@ -2756,6 +2769,10 @@ Workspace carve(void* base, int n_rays, int n_steps) {
     w.o_mask = c.take<uint8_t>(Q);
     w.q_smask = c.take<uint8_t>(Q);
     w.shaded = c.take<f32x4>(Q);
+    w.listC = c.take<int>(Q);
+    w.listD = c.take<int>(Q);
+    w.tcounts = c.take<int>(TC_COUNT);
+    w.ray_tier = c.take<uint8_t>(N);
     w.bytes = align_up(c.off, 256);
     return w;
 }
@@ -3826,10 +3843,14 @@ int arah_nearest_inverse_lbs(const ArahFrame* f, const float* pts, int32_t n, in
 // the target in row 3 -- written there by k_nearest_invlbs<SAMPLES>, or here from tgt); the results replace them.
 // w.counts: [0] = number of entries, [1] = head of the queue (zeroed by the caller's memset of w.counts).
 static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, CanonOut outp, long long max_pts,
-                        hipStream_t s, int mode_arg = ARAH_CANON_KERNEL_WAVE, void* const* ev = nullptr) {
-    int* cnt = w.counts;
+                        hipStream_t s, int mode_arg = ARAH_CANON_KERNEL_WAVE, void* const* ev = nullptr,
+                        const int* list_arg = nullptr, int* cnt_arg = nullptr) {
+    // the list and its two device-side counts {entries, head of the queue}: w.listA / w.counts unless the caller (the tiered
+    // forward) brings its own
+    int* cnt = cnt_arg ? cnt_arg : w.counts;
+    const int* const list = list_arg ? list_arg : w.listA;
     if (tgt)
-        hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, (const int*)w.listA,
+        hipLaunchKernelGGL(k_canon_seed, dim3(grid_for(max_pts, 256)), dim3(256), 0, s, list,
                            (const int*)&cnt[0], tgt, outp.T);
     // mode: ARAH_CANON_KERNEL_WAVE (default: point-owning waves, hi fragments in LDS), _WAVE_L2 (all fragments from L2), _TILE
     // (round 2's channel-sliced tiles).  The exact engine always runs the tile kernel.  A field of the call
@@ -3846,24 +3867,24 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
         // two instances are launched, one returns at once: whether the activations of this frame's skinning MLP need scaling
         // down to stay inside the f16 range is known on the device only (k_skin_probe), and the plain instance is the faster
         if (mode == 1) {
-            hipLaunchKernelGGL((k_canon_wave<true, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
+            hipLaunchKernelGGL((k_canon_wave<true, false>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, list,
                                (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
                                &w.ctr->n_split_nonfinite, clk_arg);
-            hipLaunchKernelGGL((k_canon_wave<true, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, (const int*)w.listA,
+            hipLaunchKernelGGL((k_canon_wave<true, true>), dim3((int)gw), dim3(kCwThreads), kLdsCanonWave, s, fd, list,
                                (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd, &w.ctr->n_canon,
                                &w.ctr->n_split_nonfinite, clk_arg);
         } else {
             const size_t lds_l2 = max(kLdsCanonWave - kCwHiBytes, (size_t)knobs().canon_lds_min);
             hipLaunchKernelGGL((k_canon_wave<false, false>), dim3((int)gw), dim3(kCwThreads), lds_l2, s, fd,
-                               (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
+                               list, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
                                &w.ctr->n_canon, &w.ctr->n_split_nonfinite, clk_arg);
             hipLaunchKernelGGL((k_canon_wave<false, true>), dim3((int)gw), dim3(kCwThreads), lds_l2, s, fd,
-                               (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
+                               list, (const int*)&cnt[0], &cnt[1], outp, &w.ctr->n_skin_fwd,
                                &w.ctr->n_canon, &w.ctr->n_split_nonfinite, clk_arg);
         }
     } else {
         LAUNCH_ENGINE(fd.split, k_canon_solve<true>, k_canon_solve<false>, dim3(grid_for(max_pts, kTile)), dim3(kThreads),
-                      kLdsCanonSolve, s, fd, (const int*)w.listA, (const int*)&cnt[0], &cnt[1], outp,
+                      kLdsCanonSolve, s, fd, list, (const int*)&cnt[0], &cnt[1], outp,
                       &w.ctr->n_skin_fwd, &w.ctr->n_canon, w.ctr->clk);
     }
     if (ev0 && ev1) hipEventRecord(ev1, s);
@@ -4076,6 +4097,30 @@ static unsigned long long* rt_clk_of(const Workspace& w) {
 }
 #endif
 
+// the density pre-pass of lazy shading over list[0 .. *count): sigma of every listed sample -> w.shaded, the samples with
+// sigma > 0 appended to next_list
+static void launch_density(const FrameDev& fd, Workspace& w, const float* pts, long long Q, const int* list, const int* count,
+                           int* next_list, int* next_count, hipStream_t s) {
+    const int g = grid_for(Q, kTile);
+    // long lists on the split engine: 128-point tiles, one workgroup per CU (ARAH_DENSITY_TILE=64 keeps the 64-point kernel)
+#ifdef ARAH_REG_TRUNK
+    if (fd.split && knobs().density_reg && Q >= 128ll * 1024)
+        hipLaunchKernelGGL(k_density_reg, dim3(min(num_cus(), grid_for(Q, kRtTile))), dim3(kRtThreads), kLdsRegTrunk, s, fd,
+                           pts, list, count, w.shaded, next_list, next_count, &w.ctr->n_sdf_fwd, &w.ctr->n_density, rt_clk_of(w));
+    else
+#endif
+    if (fd.split && knobs().density_wide && Q >= 128ll * 1024)
+        hipLaunchKernelGGL((k_density<true, 8>), dim3(min(num_cus(), grid_for(Q, 128))), dim3(kThreads), kLdsDensityWide, s, fd,
+                           pts, list, count, w.shaded, next_list, next_count, &w.ctr->n_sdf_fwd, &w.ctr->n_density);
+    else
+        LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts, list, count,
+                      w.shaded, next_list, next_count, &w.ctr->n_sdf_fwd, &w.ctr->n_density);
+}
+
+static int shade_tail(const ArahFrame* f, const ArahSampling* cfg, Workspace& w, const FrameDev& fd, const float* dirs,
+                      const float* z, const float* pts, const float* T, const uint8_t* mask, int32_t n, const int* slist,
+                      const int* scount, float* rgb, float* acc, uint8_t* vol_mask, hipStream_t s);
+
 // ---- loop D -----------------------------------------------------------------------------------
 static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w, const float* dirs, const float* z,
                       const float* pts, const float* T, const uint8_t* mask, int32_t n, float* rgb, float* acc,
@@ -4090,26 +4135,21 @@ static int shade_impl(const ArahFrame* f, const ArahSampling* cfg, Workspace& w,
     const int* scount = &w.counts[0];
     if (!cfg->full_shading) {   // pass 1: densities; only samples that can receive weight reach k_shade
         if (cfg->ev_density[0] && cfg->ev_density[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[0]), s);
-        // long lists on the split engine: 128-point tiles, one workgroup per CU (ARAH_DENSITY_TILE=64 keeps the 64-point kernel)
-#ifdef ARAH_REG_TRUNK
-        if (fd.split && knobs().density_reg && Q >= 128ll * 1024)
-            hipLaunchKernelGGL(k_density_reg, dim3(min(num_cus(), grid_for(Q, kRtTile))), dim3(kRtThreads), kLdsRegTrunk, s, fd,
-                               pts, (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1],
-                               &w.ctr->n_sdf_fwd, &w.ctr->n_density, rt_clk_of(w));
-        else
-#endif
-        if (fd.split && knobs().density_wide && Q >= 128ll * 1024)
-            hipLaunchKernelGGL((k_density<true, 8>), dim3(min(num_cus(), grid_for(Q, 128))), dim3(kThreads), kLdsDensityWide, s, fd,
-                               pts, (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1],
-                               &w.ctr->n_sdf_fwd, &w.ctr->n_density);
-        else
-            LAUNCH_ENGINE(fd.split, k_density<true>, k_density<false>, dim3(g), dim3(kThreads), kLdsSdfFwd, s, fd, pts,
-                          (const int*)w.listA, (const int*)&w.counts[0], w.shaded, w.listB, &w.counts[1], &w.ctr->n_sdf_fwd,
-                          &w.ctr->n_density);
+        launch_density(fd, w, pts, Q, (const int*)w.listA, (const int*)&w.counts[0], w.listB, &w.counts[1], s);
         if (cfg->ev_density[0] && cfg->ev_density[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[1]), s);
         slist = w.listB;
         scount = &w.counts[1];
     }
+    return shade_tail(f, cfg, w, fd, dirs, z, pts, T, mask, n, slist, scount, rgb, acc, vol_mask, s);
+}
+
+// normal + colour of the samples in slist[0 .. *scount), then the per-ray compositing
+static int shade_tail(const ArahFrame* f, const ArahSampling* cfg, Workspace& w, const FrameDev& fd, const float* dirs,
+                      const float* z, const float* pts, const float* T, const uint8_t* mask, int32_t n, const int* slist,
+                      const int* scount, float* rgb, float* acc, uint8_t* vol_mask, hipStream_t s) {
+    const int S = cfg->n_steps;
+    const long long Q = (long long)n * S;
+    const int g = grid_for(Q, kTile);
     if (cfg->ev_shade[0] && cfg->ev_shade[1]) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_shade[0]), s);
     const B3Nets b3 = b3_of(*f);
     if (fd.split && shade_b3(cfg->shade_engine)) {
@@ -4445,6 +4485,167 @@ int arah_mesh_query(const float* verts, int32_t n_verts, const int32_t* faces, i
     return check_launch();
 }
 
+}  // extern "C"
+
+// ---- tiered eval forward (tier.hpp) --------------------------------------------------------------
+static OccBuf carve_occ(void* base) {
+    OccBuf o;
+    Carver c{reinterpret_cast<char*>(base), 0};
+    o.info = c.take<OccInfo>(1);
+    o.bits = c.take<unsigned>(kOccMaxVox / 32);
+    o.dist = c.take<uint8_t>(kOccMaxVox);
+    o.csdf = c.take<float>((size_t)kOccNc * kOccNc * kOccNc);
+    o.cpts = c.take<float>((size_t)kOccNc * kOccNc * kOccNc * 3);
+    o.cell_lip = c.take<float>(kOccMaxCells);
+    o.fnorm = c.take<float>((size_t)kOccMaxFine * 3);
+    o.fsdf = c.take<float>(kOccMaxFine);
+    o.iota = c.take<int>(kOccMaxFine);
+    o.sel_raw = c.take<float>((size_t)kOccMaxFine * 3);
+    o.sel_bar = c.take<float>((size_t)kOccMaxFine * 3);
+    o.bytes = align_up(c.off, 256);
+    return o;
+}
+
+extern "C" {
+size_t arah_occupancy_bytes(void) { return carve_occ(nullptr).bytes; }
+
+// The posed fat body of a prepared frame as a bitmap (tier.hpp): eleven short launches on `stream`, ~2.5e5 SDF and a few 1e4
+// skinning evaluations.  The buffer is the caller's (arah_occupancy_bytes(), 256-byte aligned) and belongs to THIS frame: hand it
+// to arah_render through ArahSampling.occupancy.
+int arah_prepare_occupancy(const ArahFrame* f, void* occ_buf, size_t occ_bytes, void* workspace, size_t wbytes, void* stream) {
+    if (!f || !occ_buf || !workspace) return ARAH_E_BADARG;
+    OccBuf o = carve_occ(occ_buf);
+    if (occ_bytes < o.bytes) return ARAH_E_WORKSPACE;
+    Workspace w = carve(workspace, 1, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    const int nc3 = kOccNc * kOccNc * kOccNc, m3 = (kOccNc - 1) * (kOccNc - 1) * (kOccNc - 1);
+    hipLaunchKernelGGL(k_occ_begin, dim3(1), dim3(64), 0, s, fd, knn_of(fd).grid, o.info);
+    hipLaunchKernelGGL(k_occ_lattice_pts, dim3((nc3 + 255) / 256), dim3(256), 0, s, kOccNc, kOccL, o.cpts);
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(nc3, kTile)), dim3(kThreads),
+                  kLdsSdfFwd, s, fd, (const float*)o.cpts, (const int*)nullptr, (const int*)nullptr, nc3, o.csdf, (float*)nullptr,
+                  (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(k_occ_cells, dim3((m3 + 255) / 256), dim3(256), 0, s, fd, (const float*)o.csdf, kOccNc, kOccL, o.info,
+                       o.cell_lip, o.fnorm, o.iota);
+    hipLaunchKernelGGL(k_occ_fix, dim3(1), dim3(64), 0, s, o.info);
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(kOccMaxFine, kTile)),
+                  dim3(kThreads), kLdsSdfFwd, s, fd, (const float*)o.fnorm, (const int*)o.iota, (const int*)&o.info->n_fine, 0,
+                  o.fsdf, (float*)nullptr, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(k_occ_select, dim3((kOccMaxFine + 255) / 256), dim3(256), 0, s, fd, kOccNc, kOccL, o.info,
+                       (const float*)o.cell_lip, (const float*)o.fnorm, (const float*)o.fsdf, o.sel_raw);
+    hipLaunchKernelGGL(k_skin_eval, dim3(grid_for(kOccMaxFine, kTile)), dim3(kThreads), kLdsSkin, s, fd, (const float*)o.sel_raw,
+                       kOccMaxFine, (float*)nullptr, o.sel_bar, (float*)nullptr, &w.ctr->n_skin_fwd, (const int*)&o.info->n_sel, 1);
+    hipMemsetAsync(o.bits, 0, sizeof(unsigned) * (kOccMaxVox / 32), s);
+    hipLaunchKernelGGL(k_occ_mark, dim3((kOccMaxFine + 255) / 256), dim3(256), 0, s, fd, kOccNc, kOccL, o.info,
+                       (const float*)o.sel_bar, o.bits);
+    // the distance transform walks lines of the bitmap's box: its dimensions live on the device, the launches cover the
+    // largest box the buffer can hold per pair of axes (lines beyond the box return at once)
+    const int max_lines = kOccMaxVox / 4;   // a box with fewer than 4 voxels along an axis does not occur (>= 0.16 m / voxel)
+    hipLaunchKernelGGL(k_occ_dist_x, dim3((max_lines + 255) / 256), dim3(256), 0, s, (const OccInfo*)o.info, (const unsigned*)o.bits, o.dist);
+    hipLaunchKernelGGL(k_occ_dist_yz<1>, dim3((max_lines + 255) / 256), dim3(256), 0, s, (const OccInfo*)o.info, o.dist);
+    hipLaunchKernelGGL(k_occ_dist_yz<2>, dim3((max_lines + 255) / 256), dim3(256), 0, s, (const OccInfo*)o.info, o.dist);
+    return check_launch();
+}
+
+// tests / bench: the tier of every ray of the workspace's last arah_render (0 certified zero, 1 surface ray, 2 promoted;
+// written by the tiered path only) and whether any valid sample of it carries density > 0 (either path, lazy shading)
+int arah_tier_debug(void* workspace, size_t wbytes, int32_t n_rays, int32_t n_steps, uint8_t* ray_tier, uint8_t* ray_sigma_pos,
+                    void* stream) {
+    if (!workspace || n_rays <= 0 || n_steps <= 0) return ARAH_E_BADARG;
+    Workspace w = carve(workspace, n_rays, n_steps);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (ray_tier && hipMemcpyAsync(ray_tier, w.ray_tier, (size_t)n_rays, hipMemcpyDeviceToDevice, s) != hipSuccess) return ARAH_E_LAUNCH;
+    if (ray_sigma_pos)
+        hipLaunchKernelGGL(k_tier_ray_sigma, dim3((n_rays + 255) / 256), dim3(256), 0, s, n_rays, n_steps, (const uint8_t*)w.o_mask,
+                           (const f32x4*)w.shaded, ray_sigma_pos);
+    return check_launch();
+}
+
+// tests: the per-sample arrays of the workspace's last arah_render (device to device; any pointer may be NULL):
+// z [N,S], pts [N,S,3], T [N,S,16], mask [N,S], shaded [N,S,4] = {rgb, density}, state [N,S] (tiered path: TS_*)
+int arah_debug_samples(void* workspace, size_t wbytes, int32_t n_rays, int32_t n_steps, float* z, float* pts, float* T,
+                       uint8_t* mask, float* shaded, uint8_t* state, void* stream) {
+    if (!workspace || n_rays <= 0 || n_steps <= 0) return ARAH_E_BADARG;
+    Workspace w = carve(workspace, n_rays, n_steps);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t Q = (size_t)n_rays * n_steps;
+    bool ok = true;
+    if (z) ok = ok && hipMemcpyAsync(z, w.o_z, Q * 4, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (pts) ok = ok && hipMemcpyAsync(pts, w.o_pts, Q * 12, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (T) ok = ok && hipMemcpyAsync(T, w.o_T, Q * 64, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (mask) ok = ok && hipMemcpyAsync(mask, w.o_mask, Q, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (shaded) ok = ok && hipMemcpyAsync(shaded, w.shaded, Q * 16, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    if (state) ok = ok && hipMemcpyAsync(state, w.q_smask, Q, hipMemcpyDeviceToDevice, s) == hipSuccess;
+    return ok ? ARAH_OK : ARAH_E_LAUNCH;
+}
+
+// tests: the header of an occupancy buffer (synchronises the stream)
+int arah_occupancy_info(const void* occ_buf, int32_t* h_out16, void* stream) {
+    if (!occ_buf || !h_out16) return ARAH_E_BADARG;
+    static_assert(sizeof(OccInfo) == 64, "OccInfo is 16 words");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemcpyAsync(h_out16, occ_buf, sizeof(OccInfo), hipMemcpyDeviceToHost, s) != hipSuccess) return ARAH_E_LAUNCH;
+    return hipStreamSynchronize(s) == hipSuccess ? ARAH_OK : ARAH_E_LAUNCH;
+}
+}  // extern "C"
+
+// one phase of the tiers: nearest vertex + inverse LBS, loop C, normalisation + masks, density of the converged samples
+static int tier_phase(const ArahFrame* f, const ArahSampling* cfg, const FrameDev& fd, Workspace& w, const RaySet& rs, long long Q,
+                      const int* list, int* cnt /* {n, queue head, n converged} */, int* dens_list, int* n_shade, bool events,
+                      hipStream_t s) {
+    const int S = cfg->n_steps;
+    launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)w.o_z, S, list, (const int*)&cnt[0], 0,
+                                (int*)nullptr, w.o_pts, w.o_T, 1, &w.ctr->n_knn);
+    int rc = run_broyden3(fd, w, nullptr, CanonOut{w.o_pts, w.o_T, w.q_err}, Q, s, cfg->canon_kernel, events ? cfg->ev_canon : nullptr,
+                          list, cnt);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tier_finalize, dim3(grid_for(Q, 256)), dim3(256), 0, s, fd, list, (const int*)&cnt[0],
+                       (const float*)w.q_err, w.o_pts, w.o_mask, dens_list, &cnt[2]);
+    const bool ev = events && cfg->ev_density[0] && cfg->ev_density[1];
+    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[0]), s);
+    launch_density(fd, w, w.o_pts, Q, (const int*)dens_list, (const int*)&cnt[2], w.listB, n_shade, s);
+    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[1]), s);
+    (void)f;
+    return check_launch();
+}
+
+static int render_tiers(const ArahFrame* f, const ArahSampling* cfg, Workspace& w, const float* cam_loc, int32_t rays_per_cam,
+                        const float* dirs, const float* near_far, const uint8_t* conv, const float* start, const float* end,
+                        int32_t n, float* rgb, float* acc, uint8_t* vol_mask, hipStream_t s) {
+    const int S = cfg->n_steps;
+    const FrameDev fd = to_dev(*f);
+    const RaySet rs = make_rays(cam_loc, dirs, rays_per_cam);
+    const long long Q = (long long)n * S;
+    OccBuf o = carve_occ(const_cast<void*>(cfg->occupancy));
+    int* tc = w.tcounts;
+    TierStats* stats = &w.ctr->tier;
+    hipMemsetAsync(tc, 0, sizeof(int) * TC_COUNT, s);
+    hipMemsetAsync(w.o_mask, 0, (size_t)Q, s);
+    hipLaunchKernelGGL(k_sample_depths, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->n_near, cfg->n_far, near_far, conv,
+                       start, end, cfg->lin_steps, cfg->lin_near, cfg->lin_far, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, w.o_z, w.q_smask);
+    hipLaunchKernelGGL(k_tier_classify, dim3((n + 3) / 4), dim3(256), 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
+                       (const OccInfo*)o.info, (const unsigned*)o.bits, (const uint8_t*)o.dist, w.listA, &tc[TC_N1], stats);
+    // phase 1: surface rays, marked samples, witnesses
+    int rc = tier_phase(f, cfg, fd, w, rs, Q, w.listA, &tc[TC_N1], w.listC, &tc[TC_NSHADE], true, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tier_promote, dim3((n + 3) / 4), dim3(256), 0, s, n, S, conv, w.q_smask, (const uint8_t*)w.o_mask,
+                       (const f32x4*)w.shaded, w.listD, &tc[TC_N2], w.ray_tier, stats);
+    // phase 2: the remaining samples of the promoted rays
+    hipLaunchKernelGGL(k_tier_snap, dim3(1), dim3(64), 0, s, (const unsigned long long*)&w.ctr->n_canon,
+                       (const unsigned long long*)&w.ctr->n_density, w.ctr->tier_snap, &w.ctr->n_canon_p2, &w.ctr->n_density_p2, 0);
+    rc = tier_phase(f, cfg, fd, w, rs, Q, w.listD, &tc[TC_N2], w.listA, &tc[TC_NSHADE], false, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tier_snap, dim3(1), dim3(64), 0, s, (const unsigned long long*)&w.ctr->n_canon,
+                       (const unsigned long long*)&w.ctr->n_density, w.ctr->tier_snap, &w.ctr->n_canon_p2, &w.ctr->n_density_p2, 1);
+    return shade_tail(f, cfg, w, fd, dirs, w.o_z, w.o_pts, w.o_T, w.o_mask, n, w.listB, &tc[TC_NSHADE], rgb, acc, vol_mask, s);
+}
+
+extern "C" {
 // ---- whole eval forward -------------------------------------------------------------------------
 int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_loc, int32_t rays_per_cam,
                 const float* dirs, const float* near_far, const float* d_pose34, int32_t n, float* rgb,
@@ -4464,11 +4665,17 @@ int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_lo
     uint8_t* o_conv = surface_conv ? surface_conv : w.o_conv;
     rc = trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, 0, w.o_xnorm, w.o_Tray, o_conv, o_start, w.o_end, s);
     if (rc) return rc;
-    rc = sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, o_conv, o_start, w.o_end, n, nullptr, nullptr,
-                     nullptr, w.o_z, w.o_pts, w.o_T, w.o_mask, s);
-    if (rc) return rc;
-    rc = shade_impl(f, cfg, w, dirs, w.o_z, w.o_pts, w.o_T, w.o_mask, n, rgb, acc ? acc : w.o_acc, vol_mask, s);
-    if (rc) return rc;
+    if (cfg->occupancy && !cfg->full_shading) {
+        rc = render_tiers(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, o_conv, o_start, w.o_end, n, rgb,
+                          acc ? acc : w.o_acc, vol_mask, s);
+        if (rc) return rc;
+    } else {
+        rc = sample_impl(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, o_conv, o_start, w.o_end, n, nullptr, nullptr,
+                         nullptr, w.o_z, w.o_pts, w.o_T, w.o_mask, s);
+        if (rc) return rc;
+        rc = shade_impl(f, cfg, w, dirs, w.o_z, w.o_pts, w.o_T, w.o_mask, n, rgb, acc ? acc : w.o_acc, vol_mask, s);
+        if (rc) return rc;
+    }
     if (points_cam)
         hipLaunchKernelGGL(k_points_cam, dim3((n + 255) / 256), dim3(256), 0, s, to_dev(*f), n,
                            make_rays(cam_loc, dirs, rays_per_cam), (const float*)o_start, (const uint8_t*)o_conv,

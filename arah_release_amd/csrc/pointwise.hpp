@@ -18,9 +18,14 @@ struct V3 {
 };
 
 // RFU:37-44
+// The padding is rounded on its own, like the tensor operation of the reference (RFU:39): under hipcc's default
+// -ffp-contract=fast the sum below became fma(rng, 0.05, .) in some kernels and stayed mul + add in others (where the
+// loop-invariant product was hoisted), and the same point normalised by two kernels differed in its last bit (round 6:
+// k_canon_finalize against k_tier_finalize).  The empty asm keeps the product out of the contraction everywhere.
 __device__ __forceinline__ V3 normalize_pt(const BodyConst& bc, V3 p) {
     const float rng = bc.cmax - bc.cmin;
-    const float pad = rng * 0.05f;
+    float pad = rng * 0.05f;
+    asm volatile("" : "+v"(pad));
     V3 o;
     o.x = (((p.x - bc.center[0]) - bc.cmin + pad) / rng / 1.1f - 0.5f) * 2.0f;
     o.y = (((p.y - bc.center[1]) - bc.cmin + pad) / rng / 1.1f - 0.5f) * 2.0f;

@@ -1,0 +1,469 @@
+// Tiered evaluation of the eval forward (round 6): prove sigma = +0 cheaply, run loops C and D only where the image comes from.
+//
+// The reference canonicalises and evaluates the SDF at EVERY depth sample of EVERY ray (RT:313-380, IDR:261-396), although the
+// VolSDF density (IDR:366-368) is exactly +0 in fp32 once the metric SDF exceeds 17.33 beta (1 - exp(-s / beta) rounds to 1), and
+// a ray whose valid samples all have sigma = +0 renders to rgb = 0, acc = 0 exactly, whatever its samples' canonical points are:
+// 82 % of the rays of the benchmark frame.  What such a ray still owes the output is `network_body_mask = any valid sample`
+// (IDR:148, 232).
+//
+// The certificate.  A converged sample x has a canonical point x* with |LBS(x*) - (x - trans)| < 1e-5 (broyden.py:64,78).  If its
+// density is > 0 then sdf(x*) <= 17.33 beta, i.e. x* lies in the canonical FAT BODY F = {y : sdf(y) <= band}, hence x lies within
+// 1e-5 of the POSED fat body p(F), p(y) = LBS_w(y)(y) + trans the forward skinning with the skinning MLP's weights -- whatever path
+// Broyden's iteration took to x*.  So a sample OUTSIDE p(F) is invalid or has sigma = +0.  p(F) is a fixed region of posed space per
+// frame; k_occ_* below voxelise a conservative superset of it once per frame:
+//   1. the SDF on a coarse lattice of the canonical box [-L, L]^3 (normalised units, L = 1.5: the body lives in [-1, 1]^3);
+//   2. a coarse cell is refined when min(corners) - Lc * half_diagonal <= band, Lc = max(kOccLipMin, kOccLipSlack x the steepest
+//      slope along the cell's own twelve edges): every y in F lies in a refined cell if the SDF's Lipschitz constant over the cell
+//      is at most Lc;
+//   3. the SDF on the f^3 sub-lattice of every refined cell; sub-points with sdf <= band + Lc * half_diagonal_fine are SELECTED:
+//      every y in F is within half_diagonal_fine of a selected sub-point;
+//   4. selected points are skinned forward (the skinning MLP itself, exact engine) and every voxel of the posed-space bitmap whose
+//      centre lies within kOccLipPose * half_diagonal_fine + voxel half-diagonal of an image is marked: every x in p(F) falls into
+//      a marked voxel if p is kOccLipPose-Lipschitz (a rigid blend has constant 1; measured on the synthetic subject: 1.1).
+// Samples in unmarked voxels are "far".  A ray that converged in loops A+B, and every sample in a marked voxel, goes through the
+// exact kernels (phase 1).  A non-surface ray is PROMOTED -- all its remaining samples evaluated exactly (phase 2) -- when one of its
+// phase-1 samples has density > 0 (delta chains and the (1 - alpha + 1e-7) factors of IDR:379-390 need every valid sample), or when
+// none of them converged (any-valid is then decided by the remaining ones).  A ray without a marked sample sends one WITNESS to
+// phase 1, the sample nearest to the fat body (L1 distance transform of the bitmap).  Per-sample results do not depend on which
+// list a sample travels in, so every ray the exact path renders non-zero is rendered bit-identically, and every other ray is 0
+// with the exact mask -- PROVIDED the two Lipschitz assumptions hold (and no fat-body root lies outside [-L, L]^3): they are
+// checked where they can be (tests/test_tiered.py renders both ways and compares bits; ArahCounters.n_tier_* count the work).
+// An occupancy that overflowed its buffers marks itself invalid: every sample then counts as marked (one phase, the old path's work).
+#pragma once
+
+constexpr float kTierBand = 18.0f;          // sigma == +0 beyond 17.33 beta; 18 leaves room for the rounding of the SDF itself
+constexpr float kOccL = 1.5f;               // canonical lattice box [-L, L]^3 in normalised coordinates
+constexpr int kOccNc = 49;                  // coarse lattice points per axis (48 cells: 6.6 cm at a 2.1 m cube)
+constexpr int kOccF = 3;                    // fine sub-lattice per coarse cell and axis
+constexpr int kOccF3 = kOccF * kOccF * kOccF;
+constexpr int kOccMaxCells = 12288;         // refined coarse cells (the synthetic subject needs ~4 000)
+constexpr int kOccMaxFine = kOccMaxCells * kOccF3;
+constexpr int kOccMaxVox = 1 << 22;         // bitmap voxels (512 KB of bits, 4 MB of distances)
+constexpr float kOccVoxel = 0.015f;         // metres; grows when the body's box would need more than kOccMaxVox voxels
+constexpr float kOccLipMin = 1.5f, kOccLipSlack = 1.25f;
+constexpr float kOccLipPose = 2.0f;
+
+struct OccInfo {                 // head of the occupancy buffer (device)
+    float origin[3];
+    float v, inv_v;
+    int dims[3];
+    int n_vox;
+    int valid;                   // 0: unusable -> every sample counts as marked
+    int n_cells, n_fine, n_sel;  // refined cells, fine points (clamped), selected points
+    int overflow;
+    float band_m;                // kTierBand * beta (metres) the bitmap was built for
+    int pad[1];
+};
+
+struct OccBuf {                  // carved view of the caller's occupancy buffer
+    OccInfo* info;
+    unsigned* bits;              // [kOccMaxVox / 32]
+    uint8_t* dist;               // [kOccMaxVox] L1 distance (voxels, saturated at 255) to the nearest marked voxel
+    float* csdf;                 // [kOccNc^3] coarse lattice SDF (normalised units)
+    float* cpts;                 // [kOccNc^3][3]
+    float* cell_lip;             // [kOccMaxCells]
+    float* fnorm;                // [kOccMaxFine][3]
+    float* fsdf;                 // [kOccMaxFine]
+    int* iota;                   // [kOccMaxFine]
+    float* sel_raw;              // [kOccMaxFine][3] raw canonical coordinates of the selected points
+    float* sel_bar;              // [kOccMaxFine][3] their forward-skinned images (without the translation)
+    size_t bytes;
+};
+
+// ---- 1. coarse lattice coordinates
+__global__ void k_occ_lattice_pts(int nc, float L, float* __restrict__ pts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc * nc * nc) return;
+    const float step = 2.0f * L / (float)(nc - 1);
+    const int iz = i % nc, iy = (i / nc) % nc, ix = i / (nc * nc);
+    pts[(size_t)i * 3] = -L + step * (float)ix;
+    pts[(size_t)i * 3 + 1] = -L + step * (float)iy;
+    pts[(size_t)i * 3 + 2] = -L + step * (float)iz;
+}
+
+// bitmap geometry from the nearest-vertex grid of the posed body (its box is the vertices' box + kGridMargin)
+__global__ void k_occ_begin(FrameDev fr, const GridInfo* __restrict__ grid, OccInfo* info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const GridInfo g = *grid;
+    float ext[3];
+    for (int a = 0; a < 3; ++a) ext[a] = (float)g.dims[a] * g.h;
+    float v = kOccVoxel;
+    for (int it = 0; it < 32; ++it) {
+        const double n = ceil((double)ext[0] / v) * ceil((double)ext[1] / v) * ceil((double)ext[2] / v);
+        if (n <= (double)kOccMaxVox) break;
+        v *= 1.1f;
+    }
+    int nv = 1;
+    for (int a = 0; a < 3; ++a) {
+        info->origin[a] = g.origin[a];
+        info->dims[a] = max(1, (int)ceilf(ext[a] / v));
+        nv *= info->dims[a];
+    }
+    info->v = v;
+    info->inv_v = 1.0f / v;
+    info->n_vox = nv;
+    info->valid = nv <= kOccMaxVox ? 1 : 0;
+    info->n_cells = info->n_fine = info->n_sel = info->overflow = 0;
+    const float beta = fminf(fmaxf(fabsf(load_beta(fr)), 1e-6f), 1e6f);
+    info->band_m = kTierBand * beta;
+}
+
+// ---- 2. refine the coarse cells that may hold a point of the fat body; write their fine sub-lattices
+__global__ void k_occ_cells(FrameDev fr, const float* __restrict__ csdf, int nc, float L, OccInfo* info, float* __restrict__ cell_lip,
+                            float* __restrict__ fnorm, int* __restrict__ iota) {
+    const int m = nc - 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m * m * m) return;
+    const BodyConst bc = load_bc(fr);
+    const float scale = sdf_scale(bc);                       // metres per normalised unit (of lengths and of the SDF alike)
+    const float band_n = info->band_m / scale;
+    const int cz = c % m, cy = (c / m) % m, cx = c / (m * m);
+    float v[2][2][2];
+    float mn = 3.4e38f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                v[i][j][k] = csdf[((size_t)(cx + i) * nc + (cy + j)) * nc + (cz + k)];
+                mn = fminf(mn, v[i][j][k]);
+            }
+    const float step = 2.0f * L / (float)m;
+    float sl = 0.f;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            sl = fmaxf(sl, fabsf(v[1][a][b] - v[0][a][b]));
+            sl = fmaxf(sl, fabsf(v[a][1][b] - v[a][0][b]));
+            sl = fmaxf(sl, fabsf(v[a][b][1] - v[a][b][0]));
+        }
+    const float lip = fmaxf(kOccLipMin, kOccLipSlack * sl / step);
+    const float half = step * 0.8660254f;
+    if (!(mn - lip * half <= band_n)) return;                 // (NaN corners refine)
+    const int slot = atomicAdd(&info->n_cells, 1);
+    if (slot >= kOccMaxCells) {
+        info->overflow = 1;
+        return;
+    }
+    cell_lip[slot] = lip;
+    const float fs = step / (float)kOccF;
+    const float x0 = -L + step * (float)cx, y0 = -L + step * (float)cy, z0 = -L + step * (float)cz;
+    for (int j = 0; j < kOccF3; ++j) {
+        const int a = j / (kOccF * kOccF), b = (j / kOccF) % kOccF, d = j % kOccF;
+        const size_t o = (size_t)slot * kOccF3 + j;
+        fnorm[o * 3] = x0 + fs * ((float)a + 0.5f);
+        fnorm[o * 3 + 1] = y0 + fs * ((float)b + 0.5f);
+        fnorm[o * 3 + 2] = z0 + fs * ((float)d + 0.5f);
+        iota[o] = (int)o;
+    }
+}
+
+__global__ void k_occ_fix(OccInfo* info) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (info->overflow) info->valid = 0;
+    info->n_cells = min(info->n_cells, kOccMaxCells);
+    info->n_fine = info->n_cells * kOccF3;
+}
+
+// ---- 3. select the fine points that may lie within half a fine diagonal of the fat body
+__global__ void k_occ_select(FrameDev fr, int nc, float L, OccInfo* info, const float* __restrict__ cell_lip,
+                             const float* __restrict__ fnorm, const float* __restrict__ fsdf, float* __restrict__ sel_raw) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = info->n_fine;
+    const BodyConst bc = load_bc(fr);
+    bool keep = false;
+    V3 raw = V3{0.f, 0.f, 0.f};
+    if (i < n) {
+        const float scale = sdf_scale(bc);
+        const float band_n = info->band_m / scale;
+        const float step = 2.0f * L / (float)(nc - 1) / (float)kOccF;
+        const float half = step * 0.8660254f;
+        const float s = fsdf[i];
+        keep = !(s - cell_lip[i / kOccF3] * half > band_n);   // (a NaN value selects)
+        raw = unnormalize_pt(bc, V3{fnorm[(size_t)i * 3], fnorm[(size_t)i * 3 + 1], fnorm[(size_t)i * 3 + 2]});
+    }
+    const unsigned long long mk = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    int base = 0;
+    if (lane == 0 && mk) base = atomicAdd(&info->n_sel, __popcll(mk));
+    base = __shfl(base, 0);
+    if (keep) {
+        const size_t o = (size_t)(base + __popcll(mk & ((1ull << lane) - 1ull)));
+        sel_raw[o * 3] = raw.x;
+        sel_raw[o * 3 + 1] = raw.y;
+        sel_raw[o * 3 + 2] = raw.z;
+    }
+}
+
+// ---- 4. mark the voxels around the posed images of the selected points
+__global__ void k_occ_mark(FrameDev fr, int nc, float L, OccInfo* info, const float* __restrict__ sel_bar, unsigned* __restrict__ bits) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= info->n_sel || !info->valid) return;
+    const BodyConst bc = load_bc(fr);
+    const float scale = sdf_scale(bc);
+    const float half_m = 2.0f * L / (float)(nc - 1) / (float)kOccF * 0.8660254f * scale;
+    const float v = info->v, inv_v = info->inv_v;
+    const float rad = (kOccLipPose * half_m + 1e-4f) * inv_v + 0.8660254f;     // voxel units, centre to point
+    // position in voxel units relative to voxel centres: centre of voxel k sits at k + 0.5
+    const float px = (sel_bar[(size_t)i * 3] + bc.trans[0] - info->origin[0]) * inv_v - 0.5f;
+    const float py = (sel_bar[(size_t)i * 3 + 1] + bc.trans[1] - info->origin[1]) * inv_v - 0.5f;
+    const float pz = (sel_bar[(size_t)i * 3 + 2] + bc.trans[2] - info->origin[2]) * inv_v - 0.5f;
+    if (!(px == px && py == py && pz == pz)) {   // a non-finite image: nothing can be said about this frame
+        info->valid = 0;
+        return;
+    }
+    (void)v;
+    const int dx = info->dims[0], dy = info->dims[1], dz = info->dims[2];
+    const int z0 = max(0, (int)ceilf(pz - rad)), z1 = min(dz - 1, (int)floorf(pz + rad));
+    const int y0 = max(0, (int)ceilf(py - rad)), y1 = min(dy - 1, (int)floorf(py + rad));
+    for (int z = z0; z <= z1; ++z)
+        for (int y = y0; y <= y1; ++y) {
+            const float rem = rad * rad - ((float)z - pz) * ((float)z - pz) - ((float)y - py) * ((float)y - py);
+            if (rem < 0.f) continue;
+            const float e = sqrtf(rem);
+            const int xa = max(0, (int)ceilf(px - e)), xb = min(dx - 1, (int)floorf(px + e));
+            if (xa > xb) continue;
+            const long long row = ((long long)z * dy + y) * dx;
+            long long b0 = row + xa, b1 = row + xb;
+            for (long long w = b0 >> 5; w <= (b1 >> 5); ++w) {
+                const int lo = (int)max(b0 - (w << 5), 0ll), hi = (int)min(b1 - (w << 5), 31ll);
+                const unsigned mask = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                if ((bits[w] & mask) != mask) atomicOr(&bits[w], mask);
+            }
+        }
+}
+
+// ---- L1 distance transform of the bitmap (voxels, saturated): one thread per line, three passes
+__global__ void k_occ_dist_x(const OccInfo* info, const unsigned* __restrict__ bits, uint8_t* __restrict__ dist) {
+    const int line = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dx = info->dims[0], dy = info->dims[1], dz = info->dims[2];
+    if (line >= dy * dz) return;
+    const long long row = (long long)line * dx;
+    int d = 255;
+    for (int x = 0; x < dx; ++x) {
+        const long long b = row + x;
+        d = ((bits[b >> 5] >> (b & 31)) & 1u) ? 0 : min(255, d + 1);
+        dist[b] = (uint8_t)d;
+    }
+    d = 255;
+    for (int x = dx - 1; x >= 0; --x) {
+        const long long b = row + x;
+        d = min((int)dist[b], min(255, d + 1));
+        dist[b] = (uint8_t)d;
+    }
+}
+template <int AXIS>   // 1: along y, 2: along z
+__global__ void k_occ_dist_yz(const OccInfo* info, uint8_t* __restrict__ dist) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int dx = info->dims[0], dy = info->dims[1], dz = info->dims[2];
+    const int n_lines = AXIS == 1 ? dx * dz : dx * dy;
+    if (t >= n_lines) return;
+    // consecutive threads walk consecutive x: coalesced byte rows
+    const int x = t % dx, o = t / dx;
+    const int len = AXIS == 1 ? dy : dz;
+    const long long stride = AXIS == 1 ? dx : (long long)dx * dy;
+    const long long base = AXIS == 1 ? (long long)o * dx * dy + x : (long long)o * dx + x;
+    int d = 255;
+    for (int k = 0; k < len; ++k) {
+        const long long b = base + k * stride;
+        d = min((int)dist[b], min(255, d + 1));
+        dist[b] = (uint8_t)d;
+    }
+    d = 255;
+    for (int k = len - 1; k >= 0; --k) {
+        const long long b = base + k * stride;
+        d = min((int)dist[b], min(255, d + 1));
+        dist[b] = (uint8_t)d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the tiers of one frame
+// ---------------------------------------------------------------------------------------------------------------------
+enum { TS_NONE = 0, TS_PHASE1 = 1, TS_PENDING = 2, TS_PHASE2 = 3 };
+enum { TC_N1 = 0, TC_HEAD1, TC_ND1, TC_N2, TC_HEAD2, TC_ND2, TC_NSHADE, TC_COUNT = 16 };
+
+typedef TierStatsRaw TierStats;   // tail of Counters (ArahCounters.n_tier_*)
+
+// marked?  (+ the distance byte).  Samples outside the bitmap's box, and every sample of an invalid occupancy, count as marked.
+__device__ __forceinline__ bool occ_lookup(const OccInfo& oi, const unsigned* bits, const uint8_t* dist, V3 p, int& d) {
+    d = 0;
+    if (!oi.valid) return true;
+    const float fx = (p.x - oi.origin[0]) * oi.inv_v, fy = (p.y - oi.origin[1]) * oi.inv_v, fz = (p.z - oi.origin[2]) * oi.inv_v;
+    const int x = (int)floorf(fx), y = (int)floorf(fy), z = (int)floorf(fz);
+    if (!(fx >= 0.f && fy >= 0.f && fz >= 0.f) || x >= oi.dims[0] || y >= oi.dims[1] || z >= oi.dims[2]) return true;
+    const long long b = ((long long)z * oi.dims[1] + y) * oi.dims[0] + x;
+    d = dist[b];
+    return (bits[b >> 5] >> (b & 31)) & 1u;
+}
+
+// One wave per ray, one lane per depth sample (two for n_steps > 64).  state[q]: TS_* of every sample; phase-1 samples -> list1.
+__global__ __launch_bounds__(256) void k_tier_classify(int n, int S, RaySet rs, const uint8_t* __restrict__ conv,
+                                                        const float* __restrict__ z, uint8_t* __restrict__ state,
+                                                        const OccInfo* __restrict__ info, const unsigned* __restrict__ bits,
+                                                        const uint8_t* __restrict__ dist, int* __restrict__ list1, int* count1,
+                                                        TierStats* stats) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const OccInfo oi = *info;
+    const bool surf = conv[ray] != 0;
+    int st[2] = {TS_NONE, TS_NONE};
+    int dd[2] = {255, 255};
+    bool any_marked = false;
+    for (int it = 0; it < 2; ++it) {
+        const int s = lane + it * 64;
+        if (s < S) {
+            const size_t q = (size_t)ray * S + s;
+            if (state[q]) {
+                if (surf) st[it] = TS_PHASE1;
+                else {
+                    int d;
+                    const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
+                    st[it] = mk ? TS_PHASE1 : TS_PENDING;
+                    dd[it] = d;
+                }
+            }
+        }
+        any_marked = any_marked || __ballot(st[it] == TS_PHASE1) != 0ull;
+    }
+    bool witness = false;
+    if (!surf && !any_marked) {   // the pending sample nearest to the fat body witnesses "any valid"
+        unsigned key = 0xffffffffu;
+        for (int it = 0; it < 2; ++it)
+            if (st[it] == TS_PENDING) key = min(key, ((unsigned)dd[it] << 16) | (unsigned)(lane + it * 64));
+        unsigned best = key;
+        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+        if (best != 0xffffffffu) {
+            const int ws = (int)(best & 0xffffu);
+            if ((ws & 63) == lane) st[ws >> 6] = TS_PHASE1;
+            witness = true;
+        }
+    }
+    int n1 = 0, n_pend = 0;
+    unsigned long long m1[2];
+    for (int it = 0; it < 2; ++it) {
+        m1[it] = __ballot(st[it] == TS_PHASE1);
+        n1 += __popcll(m1[it]);
+        n_pend += __popcll(__ballot(st[it] == TS_PENDING));
+    }
+    int base = 0;
+    if (lane == 0) {
+        if (n1) base = atomicAdd(count1, n1);
+        atomicAdd(&stats->rays, 1ull);
+        if (surf) atomicAdd(&stats->rays_surface, 1ull);
+        if (witness) atomicAdd(&stats->witnesses, 1ull);
+        atomicAdd(&stats->samples_p1, (unsigned long long)n1);
+    }
+    base = __shfl(base, 0);
+    for (int it = 0; it < 2; ++it) {
+        const int s = lane + it * 64;
+        if (s < S) {
+            const size_t q = (size_t)ray * S + s;
+            state[q] = (uint8_t)st[it];
+            if (st[it] == TS_PHASE1) list1[base + __popcll(m1[it] & ((1ull << lane) - 1ull))] = (int)q;
+        }
+        base += __popcll(m1[it]);
+    }
+    (void)n_pend;
+}
+
+// RT:447-461, 549-555 for the samples of one phase: normalise the solution, converged = |g|_best < thr; the converged ones go
+// on to the density pass
+__global__ __launch_bounds__(256) void k_tier_finalize(FrameDev fr, const int* __restrict__ list, const int* count,
+                                                        const float* __restrict__ err_best, float* __restrict__ pts,
+                                                        uint8_t* __restrict__ mask, int* __restrict__ dens_list, int* dens_count) {
+    const int n = *count;
+    if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    const BodyConst bc = load_bc(fr);
+    for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
+        const int i = i0 + threadIdx.x;
+        bool ok = false;
+        int q = -1;
+        if (i < n) {
+            q = list[i];
+            const V3 xn = normalize_pt(bc, V3{pts[(size_t)q * 3], pts[(size_t)q * 3 + 1], pts[(size_t)q * 3 + 2]});
+            pts[(size_t)q * 3] = xn.x;
+            pts[(size_t)q * 3 + 1] = xn.y;
+            pts[(size_t)q * 3 + 2] = xn.z;
+            ok = err_best[q] < kRootThresh;
+            mask[q] = ok ? 1 : 0;
+        }
+        append_ids(ok, q, dens_list, dens_count);
+    }
+}
+
+// One wave per ray after phase 1: promote the non-surface rays whose phase-1 samples show density > 0, or of which none
+// converged; their pending samples -> list2.
+__global__ __launch_bounds__(256) void k_tier_promote(int n, int S, const uint8_t* __restrict__ conv, uint8_t* __restrict__ state,
+                                                       const uint8_t* __restrict__ mask, const f32x4* __restrict__ shaded,
+                                                       int* __restrict__ list2, int* count2, uint8_t* __restrict__ ray_tier,
+                                                       TierStats* stats) {
+    const int lane = threadIdx.x & 63;
+    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (ray >= n) return;
+    const bool surf = conv[ray] != 0;
+    int st[2] = {TS_NONE, TS_NONE};
+    bool pos = false, ok = false;
+    for (int it = 0; it < 2; ++it) {
+        const int s = lane + it * 64;
+        if (s < S) {
+            const size_t q = (size_t)ray * S + s;
+            st[it] = state[q];
+            if (st[it] == TS_PHASE1 && mask[q]) {
+                ok = true;
+                pos = pos || shaded[q][3] > 0.f;
+            }
+        }
+    }
+    const bool any_pos = __ballot(pos) != 0ull, any_ok = __ballot(ok) != 0ull;
+    const bool promote = !surf && (any_pos || !any_ok);
+    unsigned long long m2[2];
+    int n2 = 0;
+    for (int it = 0; it < 2; ++it) {
+        m2[it] = __ballot(promote && st[it] == TS_PENDING);
+        n2 += __popcll(m2[it]);
+    }
+    const int n_left = promote ? 0 : __popcll(__ballot(st[0] == TS_PENDING)) + __popcll(__ballot(st[1] == TS_PENDING));
+    int base = 0;
+    if (lane == 0) {
+        if (n2) base = atomicAdd(count2, n2);
+        if (ray_tier) ray_tier[ray] = surf ? 1 : (promote ? 2 : 0);
+        if (promote) atomicAdd(&stats->rays_promoted, 1ull);
+        else if (!surf) atomicAdd(&stats->rays_skipped, 1ull);
+        if (n2) atomicAdd(&stats->samples_p2, (unsigned long long)n2);
+        if (n_left) atomicAdd(&stats->samples_skipped, (unsigned long long)n_left);
+    }
+    base = __shfl(base, 0);
+    for (int it = 0; it < 2; ++it) {
+        const int s = lane + it * 64;
+        if (s < S && promote && st[it] == TS_PENDING) {
+            const size_t q = (size_t)ray * S + s;
+            state[q] = TS_PHASE2;
+            list2[base + __popcll(m2[it] & ((1ull << lane) - 1ull))] = (int)q;
+        }
+        base += __popcll(m2[it]);
+    }
+}
+
+// phase-2 share of the work counters: snapshot before (mode 0), difference after (mode 1)
+__global__ void k_tier_snap(const unsigned long long* n_canon, const unsigned long long* n_density, unsigned long long* snap,
+                            unsigned long long* canon_p2, unsigned long long* density_p2, int mode) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (mode == 0) {
+        snap[0] = *n_canon;
+        snap[1] = *n_density;
+    } else {
+        *canon_p2 += *n_canon - snap[0];
+        *density_p2 += *n_density - snap[1];
+    }
+}
+
+// tests: per ray, does any valid sample carry density > 0 ?  (what the exact path would have to render)
+__global__ void k_tier_ray_sigma(int n, int S, const uint8_t* __restrict__ mask, const f32x4* __restrict__ shaded, uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool pos = false;
+    for (int s = 0; s < S; ++s) {
+        const size_t q = (size_t)i * S + s;
+        pos = pos || (mask[q] && shaded[q][3] > 0.f);
+    }
+    out[i] = pos ? 1 : 0;
+}

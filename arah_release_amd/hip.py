@@ -66,7 +66,8 @@ class ArahSampling(C.Structure):
                 ("cano_view_dirs", C.c_int32), ("render_last_pt", C.c_int32), ("full_shading", C.c_int32),
                 ("lin_steps", _fp), ("lin_near", _fp), ("lin_far", _fp),
                 ("shade_engine", C.c_int32), ("canon_kernel", C.c_int32),
-                ("ev_canon", C.c_void_p * 2), ("ev_density", C.c_void_p * 2), ("ev_shade", C.c_void_p * 2)]
+                ("ev_canon", C.c_void_p * 2), ("ev_density", C.c_void_p * 2), ("ev_shade", C.c_void_p * 2),
+                ("occupancy", C.c_void_p)]
 
 
 class ArahFrame(C.Structure):
@@ -100,7 +101,11 @@ class ArahTrainGrads(C.Structure):
 class ArahCounters(C.Structure):
     _fields_ = [("n_sdf_fwd", C.c_uint64), ("n_sdf_grad", C.c_uint64), ("n_skin_fwd", C.c_uint64),
                 ("n_skin_jac", C.c_uint64), ("n_col", C.c_uint64), ("n_knn", C.c_uint64),
-                ("n_density", C.c_uint64), ("n_canon", C.c_uint64), ("n_split_nonfinite", C.c_uint64)]
+                ("n_density", C.c_uint64), ("n_canon", C.c_uint64), ("n_split_nonfinite", C.c_uint64),
+                ("n_tier_rays", C.c_uint64), ("n_tier_rays_surface", C.c_uint64), ("n_tier_rays_promoted", C.c_uint64),
+                ("n_tier_rays_skipped", C.c_uint64), ("n_tier_samples_p1", C.c_uint64), ("n_tier_samples_p2", C.c_uint64),
+                ("n_tier_samples_skipped", C.c_uint64), ("n_tier_witnesses", C.c_uint64),
+                ("n_canon_p2", C.c_uint64), ("n_density_p2", C.c_uint64)]
 
 
 COUNTER_BYTES = C.sizeof(ArahCounters)
@@ -110,7 +115,8 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
            "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
-           "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes"]
+           "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes",
+           "arah_occupancy_bytes", "arah_prepare_occupancy", "arah_occupancy_info", "arah_tier_debug", "arah_debug_samples"]
 
 _lib = None
 
@@ -133,6 +139,7 @@ def load_library():
     lib.arah_mesh_query_scratch_bytes.restype = C.c_size_t
     lib.arah_marching_cubes_scratch_bytes.restype = C.c_size_t
     lib.arah_marching_cubes_scratch_bytes.argtypes = [C.c_int32]
+    lib.arah_occupancy_bytes.restype = C.c_size_t
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the symbol is missing
     _lib = lib
@@ -237,6 +244,52 @@ class Workspace:
             device = torch.device("cuda", torch.cuda.current_device())
         self.device = device
         self.buf = None
+        self.occ = None   # occupancy bitmap of the frame this scratch is rendering (tiered eval forward)
+
+    def occupancy(self, frame):
+        """arah_prepare_occupancy for `frame` on the current stream, into this scratch's own buffer (a scratch serves one
+        stream: the bitmap of the previous frame is dead by stream order when the next one is built)."""
+        lib = load_library()
+        buf = self.ensure(1, 1)
+        with torch.cuda.device(self.device):
+            if self.occ is None:
+                self.occ = torch.empty(int(lib.arah_occupancy_bytes()), dtype=torch.uint8, device=self.device)
+            _check(lib.arah_prepare_occupancy(C.byref(frame.handle), _ptr(self.occ), C.c_size_t(self.occ.numel()), _ptr(buf),
+                                              C.c_size_t(buf.numel()), _stream(self.device)), "arah_prepare_occupancy")
+        return self.occ
+
+    def occupancy_info(self):
+        """Header of the last occupancy built here (synchronises the stream): dict of its geometry and counts."""
+        import struct
+        out = (C.c_int32 * 16)()
+        with torch.cuda.device(self.device):
+            _check(load_library().arah_occupancy_info(_ptr(self.occ), out, _stream(self.device)), "arah_occupancy_info")
+        raw = bytes(out)
+        f = struct.unpack("5f", raw[:20])
+        i = struct.unpack("9i", raw[20:56])
+        return {"origin": f[:3], "voxel": f[3], "dims": i[:3], "n_vox": i[3], "valid": i[4], "n_cells": i[5], "n_fine": i[6],
+                "n_selected": i[7], "overflow": i[8], "band_m": struct.unpack("f", raw[56:60])[0]}
+
+    def tier_debug(self, n_rays, n_steps):
+        """(ray_tier, ray_sigma_pos) uint8 tensors of the last arah_render on this scratch."""
+        tier = torch.empty(n_rays, dtype=torch.uint8, device=self.device)
+        pos = torch.empty(n_rays, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            _check(load_library().arah_tier_debug(_ptr(self.buf), C.c_size_t(self.buf.numel()), C.c_int32(n_rays), C.c_int32(n_steps),
+                                                  _ptr(tier), _ptr(pos), _stream(self.device)), "arah_tier_debug")
+        return tier, pos
+
+    def debug_samples(self, n_rays, n_steps):
+        """Per-sample arrays of the last arah_render on this scratch: dict of z, pts, T, mask, shaded, state tensors."""
+        d, Q = self.device, n_rays * n_steps
+        out = {"z": torch.empty(Q, device=d), "pts": torch.empty(Q, 3, device=d), "T": torch.empty(Q, 16, device=d),
+               "mask": torch.empty(Q, dtype=torch.uint8, device=d), "shaded": torch.empty(Q, 4, device=d),
+               "state": torch.empty(Q, dtype=torch.uint8, device=d)}
+        with torch.cuda.device(d):
+            _check(load_library().arah_debug_samples(_ptr(self.buf), C.c_size_t(self.buf.numel()), C.c_int32(n_rays), C.c_int32(n_steps),
+                                                     _ptr(out["z"]), _ptr(out["pts"]), _ptr(out["T"]), _ptr(out["mask"]),
+                                                     _ptr(out["shaded"]), _ptr(out["state"]), _stream(d)), "arah_debug_samples")
+        return out
 
     def ensure(self, n_rays, n_steps):
         need = load_library().arah_workspace_bytes(int(n_rays), int(n_steps))
@@ -260,8 +313,7 @@ class Workspace:
         with torch.cuda.device(self.device):
             _check(load_library().arah_counters_read(_ptr(self.buf), C.byref(out), _stream(self.device)),
                    "arah_counters_read")
-        return {k: int(getattr(out, k)) for k in ("n_sdf_fwd", "n_sdf_grad", "n_skin_fwd", "n_skin_jac", "n_col", "n_knn",
-                                                   "n_density", "n_canon", "n_split_nonfinite")}
+        return {k: int(getattr(out, k)) for k, _ in ArahCounters._fields_}
 
 
 _side_streams = {}
@@ -888,13 +940,21 @@ def gram_skinny(a, b):
 
 
 @_guarded
-def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):
+def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34, tiered=False):
     """Whole eval forward. pose34: DEVICE (3,4) world->camera (no host copy, no stream drain).
+    tiered: build the frame's occupancy bitmap first and let arah_render skip the samples it certifies (csrc/tier.hpp;
+    lazy shading only -- with full_shading the flag is ignored).
     Returns rgb, points_cam, vol_mask, acc, dists, conv."""
     lib = load_library()
     cam, d, nf = _f32(cam_loc), _f32(dirs), _f32(near_far)
     n, S = d.shape[0], sampling.n_steps
     buf = ws.ensure(n, S)
+    cfg = sampling.handle
+    if tiered and not cfg.full_shading:
+        occ = ws.occupancy(frame)
+        buf = ws.buf
+        cfg = ArahSampling.from_buffer_copy(sampling.handle)   # the bitmap is this frame's: a private copy of the call's struct
+        cfg.occupancy = occ.data_ptr()
     dev = d.device
     rgb = torch.empty(n, 3, device=dev)
     pcam = torch.empty(n, 3, device=dev)
@@ -903,7 +963,7 @@ def render(frame, ws, sampling, cam_loc, dirs, near_far, pose34):
     dists = torch.empty(n, device=dev)
     conv = torch.empty(n, dtype=torch.uint8, device=dev)
     d_pose = _f32(pose34).reshape(-1)[:12].contiguous()
-    _check(lib.arah_render(C.byref(frame.handle), C.byref(sampling.handle), _ptr(cam), C.c_int32(n // cam.shape[0]),
+    _check(lib.arah_render(C.byref(frame.handle), C.byref(cfg), _ptr(cam), C.c_int32(n // cam.shape[0]),
                            _ptr(d), _ptr(nf), _ptr(d_pose), C.c_int32(n), _ptr(rgb), _ptr(pcam), _ptr(vol), _ptr(acc),
                            _ptr(dists), _ptr(conv), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_render")
     return rgb, pcam, vol, acc, dists, conv

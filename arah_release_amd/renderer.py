@@ -373,6 +373,11 @@ class IDHRNetwork(nn.Module):
         self.shade_ratio = None          # last measured r
         self._shade_full = False
         self._shade_since_probe = 0
+        # Tiered evaluation (csrc/tier.hpp): samples outside the frame's posed fat body are certified sigma = +0 without loops C
+        # and D; same image and masks bit for bit (tests/test_tiered.py).  ARAH_TIERING=0 / .tiering = False: every sample
+        # through the exact kernels, like the reference.  Lazy shading only: a frame that shades everything (large beta) has a
+        # band as wide as the body's box and nothing to skip.
+        self.tiering = os.environ.get("ARAH_TIERING", "1") != "0"
         self.precision = None    # GEMM engine frames are prepared for: None = the process default (ARAH_PRECISION, split),
                                  # hip.PRECISION_FP32 / PRECISION_SPLIT_F16 = this renderer's own choice (bench.py's passes)
         self._precision = None   # becomes hip.PRECISION_FP32 once the range guard has fired: overrides `precision`
@@ -518,7 +523,8 @@ class IDHRNetwork(nn.Module):
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt, full_shading=full)
         pose34 = pose[0, :3, :4].detach().float().contiguous()
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
-                                                      ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
+                                                      ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34,
+                                                      tiered=self.tiering)
         if guard is not None and self.guard_mode == "strict" and frame.precision != hip.PRECISION_FP32:
             now = int(ws.buf[64:72].view(torch.int64).item())   # ArahCounters.n_split_nonfinite; synchronises the stream
             grew = now - guard["seen"] if now >= guard["seen"] else now
@@ -536,7 +542,8 @@ class IDHRNetwork(nn.Module):
                                     precision=hip.PRECISION_FP32, body_tables=input.get("_body_tables"))
                 self.last_frame = frame
                 rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
-                                                              ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34)
+                                                              ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34,
+                                                              tiered=self.tiering)
         elif guard is not None and self.guard_mode != "strict":
             self._split_guard_arm(guard, ws, full)
         pcam = pcam.reshape(B, N, 3)

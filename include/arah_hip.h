@@ -139,6 +139,11 @@ typedef struct ArahSampling {
     void* ev_canon[2];
     void* ev_density[2];
     void* ev_shade[2];
+    /* Tiered evaluation (round 6, csrc/tier.hpp; arah_render with full_shading == 0 only): the occupancy buffer that
+     * arah_prepare_occupancy filled for THIS frame, or NULL = every sample of every ray through loops C and D like the reference
+     * (ray_tracing.py:313-380, implicit_differentiable_renderer.py:261-396).  With it, samples outside the posed fat body are
+     * certified sigma = +0 without being evaluated; images and masks are the untiered path's bit for bit. */
+    const void* occupancy;
 } ArahSampling;
 
 /* Opaque-ish handle filled by arah_prepare_frame: device pointers into the caller's frame
@@ -201,6 +206,12 @@ typedef struct ArahCounters {
     uint64_t n_split_nonfinite; /* loop-C evaluations of the split engine whose residual was not finite (an activation
                                    left the f16 range): non-zero means the frame should be re-prepared with
                                    ARAH_PRECISION_FP32 */
+    /* tiered eval forward: rays classified; of them surface rays (loops A+B converged), promoted to the exact tier, skipped
+     * (certified rgb = 0); samples evaluated in phase 1 (surface rays, marked samples, witnesses), in phase 2 (the rest of the
+     * promoted rays), never evaluated; rays that sent a witness */
+    uint64_t n_tier_rays, n_tier_rays_surface, n_tier_rays_promoted, n_tier_rays_skipped;
+    uint64_t n_tier_samples_p1, n_tier_samples_p2, n_tier_samples_skipped, n_tier_witnesses;
+    uint64_t n_canon_p2, n_density_p2;   /* the share of n_canon / n_density that phase 2 ran */
 } ArahCounters;
 
 /* ---- frame preparation ------------------------------------------------------------------ */
@@ -402,6 +413,28 @@ int arah_render(const ArahFrame* h_frame, const ArahSampling* h_cfg, const float
                 int32_t n_rays, float* rgb, float* points_cam, uint8_t* vol_mask, float* acc,
                 float* dists, uint8_t* surface_conv, void* workspace, size_t workspace_bytes,
                 void* stream);
+
+/* ---- tiered evaluation (csrc/tier.hpp) --------------------------------------------------------- */
+/* The reference evaluates every depth sample of every ray (ray_tracing.py:313-380 -> search_canonical_corr,
+ * implicit_differentiable_renderer.py:336-368); a sample whose canonical point lies outside {sdf <= 18 beta} has density
+ * exactly +0 there.  arah_prepare_occupancy voxelises the POSED image of that set for a prepared frame (SDF lattice of
+ * [-1.5,1.5]^3, refined where the band can be, skinned forward with the skinning MLP, dilated by the lattice's reach) into a
+ * caller buffer of arah_occupancy_bytes() bytes; ArahSampling.occupancy hands it to arah_render. */
+size_t arah_occupancy_bytes(void);
+int arah_prepare_occupancy(const ArahFrame* h_frame, void* occ_buf, size_t occ_bytes, void* workspace,
+                           size_t workspace_bytes, void* stream);
+/* the 16 words at the head of an occupancy buffer: origin[3], voxel, 1/voxel, dims[3], n_vox, valid, n_cells, n_fine,
+ * n_selected, overflow, band (m), pad; synchronises the stream */
+int arah_occupancy_info(const void* occ_buf, int32_t* h_out16, void* stream);
+/* after an arah_render on this workspace: ray_tier [N] (0 certified zero, 1 surface ray, 2 promoted; tiered path only) and
+ * ray_sigma_pos [N] (1: some valid sample of the ray has density > 0); device pointers, either may be NULL */
+int arah_tier_debug(void* workspace, size_t workspace_bytes, int32_t n_rays, int32_t n_steps, uint8_t* ray_tier,
+                    uint8_t* ray_sigma_pos, void* stream);
+
+/* tests: the per-sample arrays of the workspace's last arah_render, copied device to device (any pointer may be NULL):
+ * z [N,S], pts [N,S,3] normalised canonical, T [N,S,16], mask [N,S], shaded [N,S,4] = {rgb, density}, state [N,S] */
+int arah_debug_samples(void* workspace, size_t workspace_bytes, int32_t n_rays, int32_t n_steps, float* z, float* pts,
+                       float* T, uint8_t* mask, float* shaded, uint8_t* state, void* stream);
 
 /* name of the dominant kernel, for profilers */
 const char* arah_dominant_kernel(void);
