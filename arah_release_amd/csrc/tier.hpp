@@ -294,75 +294,112 @@ __device__ __forceinline__ bool occ_lookup(const OccInfo& oi, const unsigned* bi
     return (bits[b >> 5] >> (b & 31)) & 1u;
 }
 
+// A workgroup's share of a list append: every wave brings n (wave-uniform); one device atomic per workgroup and batch -- a single
+// device-scope counter takes ~90 atomics / us, and one per ray made these two kernels 3-4 ms each (155 k rays).
+constexpr int kTierWaves = 16;
+__device__ __forceinline__ int tier_block_base(int n, int wave, int lane, int* count, int* sh /* [kTierWaves + 1] */) {
+    if (lane == 0) sh[wave] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < kTierWaves; ++k) {
+            const int c = sh[k];
+            sh[k] = tot;
+            tot += c;
+        }
+        sh[kTierWaves] = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    const int base = sh[kTierWaves] + sh[wave];
+    __syncthreads();
+    return base;
+}
+// per-wave tallies -> one atomic per counter and workgroup
+template <int NS>
+__device__ __forceinline__ void tier_flush_stats(const unsigned (&loc)[NS], unsigned long long* const (&dst)[NS], int wave, int lane,
+                                                 unsigned* sh /* [kTierWaves][NS] */) {
+    if (lane == 0)
+        for (int k = 0; k < NS; ++k) sh[wave * NS + k] = loc[k];
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        unsigned long long tot = 0;
+        for (int w = 0; w < kTierWaves; ++w) tot += sh[w * NS + threadIdx.x];
+        if (tot) atomicAdd(dst[threadIdx.x], tot);
+    }
+}
+
 // One wave per ray, one lane per depth sample (two for n_steps > 64).  state[q]: TS_* of every sample; phase-1 samples -> list1.
-__global__ __launch_bounds__(256) void k_tier_classify(int n, int S, RaySet rs, const uint8_t* __restrict__ conv,
+__global__ __launch_bounds__(kTierWaves * 64) void k_tier_classify(int n, int S, RaySet rs, const uint8_t* __restrict__ conv,
                                                         const float* __restrict__ z, uint8_t* __restrict__ state,
                                                         const OccInfo* __restrict__ info, const unsigned* __restrict__ bits,
                                                         const uint8_t* __restrict__ dist, int* __restrict__ list1, int* count1,
                                                         TierStats* stats) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (ray >= n) return;
+    __shared__ int sh_base[kTierWaves + 1];
+    __shared__ unsigned sh_stats[kTierWaves * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const OccInfo oi = *info;
-    const bool surf = conv[ray] != 0;
-    int st[2] = {TS_NONE, TS_NONE};
-    int dd[2] = {255, 255};
-    bool any_marked = false;
-    for (int it = 0; it < 2; ++it) {
-        const int s = lane + it * 64;
-        if (s < S) {
-            const size_t q = (size_t)ray * S + s;
-            if (state[q]) {
-                if (surf) st[it] = TS_PHASE1;
-                else {
-                    int d;
-                    const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
-                    st[it] = mk ? TS_PHASE1 : TS_PENDING;
-                    dd[it] = d;
+    unsigned loc[4] = {0u, 0u, 0u, 0u};   // rays, surface rays, witnesses, phase-1 samples
+    for (int r0 = blockIdx.x * kTierWaves; r0 < n; r0 += gridDim.x * kTierWaves) {
+        const int ray = r0 + wave;
+        const bool live = ray < n;
+        const bool surf = live && conv[ray] != 0;
+        int st[2] = {TS_NONE, TS_NONE};
+        int dd[2] = {255, 255};
+        bool any_marked = false;
+        for (int it = 0; it < 2; ++it) {
+            const int s = lane + it * 64;
+            if (live && s < S) {
+                const size_t q = (size_t)ray * S + s;
+                if (state[q]) {
+                    if (surf) st[it] = TS_PHASE1;
+                    else {
+                        int d;
+                        const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
+                        st[it] = mk ? TS_PHASE1 : TS_PENDING;
+                        dd[it] = d;
+                    }
                 }
             }
+            any_marked = any_marked || __ballot(st[it] == TS_PHASE1) != 0ull;
         }
-        any_marked = any_marked || __ballot(st[it] == TS_PHASE1) != 0ull;
-    }
-    bool witness = false;
-    if (!surf && !any_marked) {   // the pending sample nearest to the fat body witnesses "any valid"
-        unsigned key = 0xffffffffu;
-        for (int it = 0; it < 2; ++it)
-            if (st[it] == TS_PENDING) key = min(key, ((unsigned)dd[it] << 16) | (unsigned)(lane + it * 64));
-        unsigned best = key;
-        for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
-        if (best != 0xffffffffu) {
-            const int ws = (int)(best & 0xffffu);
-            if ((ws & 63) == lane) st[ws >> 6] = TS_PHASE1;
-            witness = true;
+        bool witness = false;
+        if (live && !surf && !any_marked) {   // the pending sample nearest to the fat body witnesses "any valid"
+            unsigned key = 0xffffffffu;
+            for (int it = 0; it < 2; ++it)
+                if (st[it] == TS_PENDING) key = min(key, ((unsigned)dd[it] << 16) | (unsigned)(lane + it * 64));
+            unsigned best = key;
+            for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+            if (best != 0xffffffffu) {
+                const int ws = (int)(best & 0xffffu);
+                if ((ws & 63) == lane) st[ws >> 6] = TS_PHASE1;
+                witness = true;
+            }
+        }
+        int n1 = 0;
+        unsigned long long m1[2];
+        for (int it = 0; it < 2; ++it) {
+            m1[it] = __ballot(st[it] == TS_PHASE1);
+            n1 += __popcll(m1[it]);
+        }
+        int base = tier_block_base(n1, wave, lane, count1, sh_base);
+        if (live) {
+            loc[0] += 1u;
+            loc[1] += surf ? 1u : 0u;
+            loc[2] += witness ? 1u : 0u;
+            loc[3] += (unsigned)n1;
+        }
+        for (int it = 0; it < 2; ++it) {
+            const int s = lane + it * 64;
+            if (live && s < S) {
+                const size_t q = (size_t)ray * S + s;
+                state[q] = (uint8_t)st[it];
+                if (st[it] == TS_PHASE1) list1[base + __popcll(m1[it] & ((1ull << lane) - 1ull))] = (int)q;
+            }
+            base += __popcll(m1[it]);
         }
     }
-    int n1 = 0, n_pend = 0;
-    unsigned long long m1[2];
-    for (int it = 0; it < 2; ++it) {
-        m1[it] = __ballot(st[it] == TS_PHASE1);
-        n1 += __popcll(m1[it]);
-        n_pend += __popcll(__ballot(st[it] == TS_PENDING));
-    }
-    int base = 0;
-    if (lane == 0) {
-        if (n1) base = atomicAdd(count1, n1);
-        atomicAdd(&stats->rays, 1ull);
-        if (surf) atomicAdd(&stats->rays_surface, 1ull);
-        if (witness) atomicAdd(&stats->witnesses, 1ull);
-        atomicAdd(&stats->samples_p1, (unsigned long long)n1);
-    }
-    base = __shfl(base, 0);
-    for (int it = 0; it < 2; ++it) {
-        const int s = lane + it * 64;
-        if (s < S) {
-            const size_t q = (size_t)ray * S + s;
-            state[q] = (uint8_t)st[it];
-            if (st[it] == TS_PHASE1) list1[base + __popcll(m1[it] & ((1ull << lane) - 1ull))] = (int)q;
-        }
-        base += __popcll(m1[it]);
-    }
-    (void)n_pend;
+    unsigned long long* const dst[4] = {&stats->rays, &stats->rays_surface, &stats->witnesses, &stats->samples_p1};
+    tier_flush_stats<4>(loc, dst, wave, lane, sh_stats);
 }
 
 // RT:447-461, 549-555 for the samples of one phase: normalise the solution, converged = |g|_best < thr; the converged ones go
@@ -392,55 +429,61 @@ __global__ __launch_bounds__(256) void k_tier_finalize(FrameDev fr, const int* _
 
 // One wave per ray after phase 1: promote the non-surface rays whose phase-1 samples show density > 0, or of which none
 // converged; their pending samples -> list2.
-__global__ __launch_bounds__(256) void k_tier_promote(int n, int S, const uint8_t* __restrict__ conv, uint8_t* __restrict__ state,
+__global__ __launch_bounds__(kTierWaves * 64) void k_tier_promote(int n, int S, const uint8_t* __restrict__ conv, uint8_t* __restrict__ state,
                                                        const uint8_t* __restrict__ mask, const f32x4* __restrict__ shaded,
                                                        int* __restrict__ list2, int* count2, uint8_t* __restrict__ ray_tier,
                                                        TierStats* stats) {
-    const int lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (ray >= n) return;
-    const bool surf = conv[ray] != 0;
-    int st[2] = {TS_NONE, TS_NONE};
-    bool pos = false, ok = false;
-    for (int it = 0; it < 2; ++it) {
-        const int s = lane + it * 64;
-        if (s < S) {
-            const size_t q = (size_t)ray * S + s;
-            st[it] = state[q];
-            if (st[it] == TS_PHASE1 && mask[q]) {
-                ok = true;
-                pos = pos || shaded[q][3] > 0.f;
+    __shared__ int sh_base[kTierWaves + 1];
+    __shared__ unsigned sh_stats[kTierWaves * 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned loc[4] = {0u, 0u, 0u, 0u};   // promoted rays, skipped rays, phase-2 samples, samples never evaluated
+    for (int r0 = blockIdx.x * kTierWaves; r0 < n; r0 += gridDim.x * kTierWaves) {
+        const int ray = r0 + wave;
+        const bool live = ray < n;
+        const bool surf = live && conv[ray] != 0;
+        int st[2] = {TS_NONE, TS_NONE};
+        bool pos = false, ok = false;
+        for (int it = 0; it < 2; ++it) {
+            const int s = lane + it * 64;
+            if (live && s < S) {
+                const size_t q = (size_t)ray * S + s;
+                st[it] = state[q];
+                if (st[it] == TS_PHASE1 && mask[q]) {
+                    ok = true;
+                    pos = pos || shaded[q][3] > 0.f;
+                }
             }
         }
-    }
-    const bool any_pos = __ballot(pos) != 0ull, any_ok = __ballot(ok) != 0ull;
-    const bool promote = !surf && (any_pos || !any_ok);
-    unsigned long long m2[2];
-    int n2 = 0;
-    for (int it = 0; it < 2; ++it) {
-        m2[it] = __ballot(promote && st[it] == TS_PENDING);
-        n2 += __popcll(m2[it]);
-    }
-    const int n_left = promote ? 0 : __popcll(__ballot(st[0] == TS_PENDING)) + __popcll(__ballot(st[1] == TS_PENDING));
-    int base = 0;
-    if (lane == 0) {
-        if (n2) base = atomicAdd(count2, n2);
-        if (ray_tier) ray_tier[ray] = surf ? 1 : (promote ? 2 : 0);
-        if (promote) atomicAdd(&stats->rays_promoted, 1ull);
-        else if (!surf) atomicAdd(&stats->rays_skipped, 1ull);
-        if (n2) atomicAdd(&stats->samples_p2, (unsigned long long)n2);
-        if (n_left) atomicAdd(&stats->samples_skipped, (unsigned long long)n_left);
-    }
-    base = __shfl(base, 0);
-    for (int it = 0; it < 2; ++it) {
-        const int s = lane + it * 64;
-        if (s < S && promote && st[it] == TS_PENDING) {
-            const size_t q = (size_t)ray * S + s;
-            state[q] = TS_PHASE2;
-            list2[base + __popcll(m2[it] & ((1ull << lane) - 1ull))] = (int)q;
+        const bool any_pos = __ballot(pos) != 0ull, any_ok = __ballot(ok) != 0ull;
+        const bool promote = live && !surf && (any_pos || !any_ok);
+        unsigned long long m2[2];
+        int n2 = 0, n_pend = 0;
+        for (int it = 0; it < 2; ++it) {
+            const unsigned long long pend = __ballot(st[it] == TS_PENDING);
+            n_pend += __popcll(pend);
+            m2[it] = promote ? pend : 0ull;
+            n2 += __popcll(m2[it]);
         }
-        base += __popcll(m2[it]);
+        int base = tier_block_base(n2, wave, lane, count2, sh_base);
+        if (live) {
+            if (lane == 0 && ray_tier) ray_tier[ray] = surf ? 1 : (promote ? 2 : 0);
+            loc[0] += promote ? 1u : 0u;
+            loc[1] += (!promote && !surf) ? 1u : 0u;
+            loc[2] += (unsigned)n2;
+            loc[3] += promote ? 0u : (unsigned)n_pend;
+        }
+        for (int it = 0; it < 2; ++it) {
+            const int s = lane + it * 64;
+            if (live && s < S && promote && st[it] == TS_PENDING) {
+                const size_t q = (size_t)ray * S + s;
+                state[q] = TS_PHASE2;
+                list2[base + __popcll(m2[it] & ((1ull << lane) - 1ull))] = (int)q;
+            }
+            base += __popcll(m2[it]);
+        }
     }
+    unsigned long long* const dst[4] = {&stats->rays_promoted, &stats->rays_skipped, &stats->samples_p2, &stats->samples_skipped};
+    tier_flush_stats<4>(loc, dst, wave, lane, sh_stats);
 }
 
 // phase-2 share of the work counters: snapshot before (mode 0), difference after (mode 1)
