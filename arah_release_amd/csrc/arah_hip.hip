@@ -127,6 +127,7 @@ FrameDev to_dev(const ArahFrame& f) {
 struct TierStatsRaw {   // ArahCounters.n_tier_*: rays classified, of them surface rays / promoted / skipped; samples sent to phase 1,
                         // to phase 2, never evaluated; rays that sent a witness
     unsigned long long rays, rays_surface, rays_promoted, rays_skipped, samples_p1, samples_p2, samples_skipped, witnesses;
+    unsigned long long rays_untraced;   // rays whose segment misses the posed fat body: loops A and B not run
 };
 struct Counters {
     unsigned long long n_sdf_fwd, n_sdf_grad, n_skin_fwd, n_skin_jac, n_col, n_knn, n_density, n_canon, n_split_nonfinite;
@@ -137,6 +138,7 @@ struct Counters {
     unsigned long long clk[8 * 16];   // instrumented builds (-DARAH_CLOCKS): s_memtime ticks per wave slot and phase
     unsigned long long clk_shade[8 * 16];   // the same for k_shade
 };
+static_assert(offsetof(Counters, tier_snap) == sizeof(ArahCounters), "the head of Counters is the ABI's ArahCounters");
 #ifdef ARAH_CLOCKS
 typedef PhaseClk KernelClk;
 #else
@@ -2036,7 +2038,7 @@ __global__ __launch_bounds__(kThreads) void k_joint_iter(FrameDev fr, Broyden4St
 // small per-ray / per-sample kernels of loops A..C
 // ------------------------------------------------------------------------------------------
 __global__ void k_trace_begin(const float* near_far, int n, float* t, float* far, uint8_t* diverged, float* xcur,
-                              float* Tcur, int* list, int* count) {
+                              float* Tcur, int* list, int* count, const uint8_t* skip) {
     // RT:179-193: unfinished = near < far, diverged = near >= far; x/T start as zeros (RT:530-531)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
@@ -2044,8 +2046,10 @@ __global__ void k_trace_begin(const float* near_far, int n, float* t, float* far
         const float nr = near_far[i * 2], fr_ = near_far[i * 2 + 1];
         t[i] = nr;
         far[i] = fr_;
-        diverged[i] = nr >= fr_ ? 1 : 0;
-        keep = nr < fr_;
+        // skip (tiered forward, tier.hpp: k_tier_rays): a ray that cannot meet the surface starts as diverged
+        const bool sk = skip && skip[i];
+        diverged[i] = (nr >= fr_ || sk) ? 1 : 0;
+        keep = nr < fr_ && !sk;
         xcur[(size_t)i * 3] = xcur[(size_t)i * 3 + 1] = xcur[(size_t)i * 3 + 2] = 0.f;
         for (int e = 0; e < 16; ++e) Tcur[(size_t)i * 16 + e] = 0.f;
     }
@@ -3953,7 +3957,7 @@ static void joint_impl(const FrameDev& fd, Workspace& w, const RaySet& rs, int n
 // ---- loops A + B -----------------------------------------------------------------------------
 static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, int32_t rays_per_cam,
                       const float* dirs, const float* near_far, int32_t n, int root_find_all, float* points_hat_norm,
-                      float* T, uint8_t* conv, float* start, float* end, hipStream_t s) {
+                      float* T, uint8_t* conv, float* start, float* end, hipStream_t s, const uint8_t* skip = nullptr) {
     const FrameDev fd = to_dev(*f);
     const RaySet rs = make_rays(cam_loc, dirs, rays_per_cam);
     const int gb = (n + 255) / 256;
@@ -3962,7 +3966,7 @@ static int trace_impl(const ArahFrame* f, Workspace& w, const float* cam_loc, in
     hipMemsetAsync(w.counts, 0, sizeof(int) * 3 * kNumCounts, s);
     hipMemsetAsync(w.nn_idx, 0xff, sizeof(int) * (size_t)n, s);   // -1: no previous nearest vertex yet
     hipLaunchKernelGGL(k_trace_begin, dim3(gb), dim3(256), 0, s, near_far, n, w.t, w.far, w.diverged, w.xcur, w.Tcur,
-                       w.listA, &cntA[0]);
+                       w.listA, &cntA[0], skip);
     TraceState ts{w.t, w.far, w.xcur, w.diverged};
     const int gm = grid_for(n, kTile);
     // the first steps as launches over the compacted list; after ARAH_TRACE_BULK_STEPS of them the resident finisher takes the
@@ -4595,20 +4599,21 @@ int arah_occupancy_info(const void* occ_buf, int32_t* h_out16, void* stream) {
 
 // one phase of the tiers: nearest vertex + inverse LBS, loop C, normalisation + masks, density of the converged samples
 static int tier_phase(const ArahFrame* f, const ArahSampling* cfg, const FrameDev& fd, Workspace& w, const RaySet& rs, long long Q,
-                      const int* list, int* cnt /* {n, queue head, n converged} */, int* dens_list, int* n_shade, bool events,
+                      const int* list, int* cnt /* {n, queue head, n converged} */, int* dens_list, int* n_shade, int phase,
                       hipStream_t s) {
     const int S = cfg->n_steps;
     launch_nearest<SRC_SAMPLES>(s, fd, Q, (const float*)nullptr, rs, (const float*)w.o_z, S, list, (const int*)&cnt[0], 0,
                                 (int*)nullptr, w.o_pts, w.o_T, 1, &w.ctr->n_knn);
-    int rc = run_broyden3(fd, w, nullptr, CanonOut{w.o_pts, w.o_T, w.q_err}, Q, s, cfg->canon_kernel, events ? cfg->ev_canon : nullptr,
-                          list, cnt);
+    void* const* evd = phase == 1 ? cfg->ev_density : cfg->ev_density2;
+    int rc = run_broyden3(fd, w, nullptr, CanonOut{w.o_pts, w.o_T, w.q_err}, Q, s, cfg->canon_kernel,
+                          phase == 1 ? cfg->ev_canon : cfg->ev_canon2, list, cnt);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tier_finalize, dim3(grid_for(Q, 256)), dim3(256), 0, s, fd, list, (const int*)&cnt[0],
                        (const float*)w.q_err, w.o_pts, w.o_mask, dens_list, &cnt[2]);
-    const bool ev = events && cfg->ev_density[0] && cfg->ev_density[1];
-    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[0]), s);
+    const bool ev = evd[0] && evd[1];
+    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(evd[0]), s);
     launch_density(fd, w, w.o_pts, Q, (const int*)dens_list, (const int*)&cnt[2], w.listB, n_shade, s);
-    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(cfg->ev_density[1]), s);
+    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(evd[1]), s);
     (void)f;
     return check_launch();
 }
@@ -4631,14 +4636,14 @@ static int render_tiers(const ArahFrame* f, const ArahSampling* cfg, Workspace& 
     hipLaunchKernelGGL(k_tier_classify, dim3(min(2048, (n + kTierWaves - 1) / kTierWaves)), dim3(kTierWaves * 64), 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
                        (const OccInfo*)o.info, (const unsigned*)o.bits, (const uint8_t*)o.dist, w.listA, &tc[TC_N1], stats);
     // phase 1: surface rays, marked samples, witnesses
-    int rc = tier_phase(f, cfg, fd, w, rs, Q, w.listA, &tc[TC_N1], w.listC, &tc[TC_NSHADE], true, s);
+    int rc = tier_phase(f, cfg, fd, w, rs, Q, w.listA, &tc[TC_N1], w.listC, &tc[TC_NSHADE], 1, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tier_promote, dim3(min(2048, (n + kTierWaves - 1) / kTierWaves)), dim3(kTierWaves * 64), 0, s, n, S, conv, w.q_smask, (const uint8_t*)w.o_mask,
                        (const f32x4*)w.shaded, w.listD, &tc[TC_N2], w.ray_tier, stats);
     // phase 2: the remaining samples of the promoted rays
     hipLaunchKernelGGL(k_tier_snap, dim3(1), dim3(64), 0, s, (const unsigned long long*)&w.ctr->n_canon,
                        (const unsigned long long*)&w.ctr->n_density, w.ctr->tier_snap, &w.ctr->n_canon_p2, &w.ctr->n_density_p2, 0);
-    rc = tier_phase(f, cfg, fd, w, rs, Q, w.listD, &tc[TC_N2], w.listA, &tc[TC_NSHADE], false, s);
+    rc = tier_phase(f, cfg, fd, w, rs, Q, w.listD, &tc[TC_N2], w.listA, &tc[TC_NSHADE], 2, s);
     if (rc) return rc;
     hipLaunchKernelGGL(k_tier_snap, dim3(1), dim3(64), 0, s, (const unsigned long long*)&w.ctr->n_canon,
                        (const unsigned long long*)&w.ctr->n_density, w.ctr->tier_snap, &w.ctr->n_canon_p2, &w.ctr->n_density_p2, 1);
@@ -4663,7 +4668,14 @@ int arah_render(const ArahFrame* f, const ArahSampling* cfg, const float* cam_lo
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* o_start = dists ? dists : w.o_start;
     uint8_t* o_conv = surface_conv ? surface_conv : w.o_conv;
-    rc = trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, 0, w.o_xnorm, w.o_Tray, o_conv, o_start, w.o_end, s);
+    const uint8_t* skip = nullptr;
+    if (cfg->occupancy) {   // rays whose segment misses the posed fat body cannot converge in loops A+B (tier.hpp)
+        OccBuf o = carve_occ(const_cast<void*>(cfg->occupancy));
+        hipLaunchKernelGGL(k_tier_rays, dim3((n + 255) / 256), dim3(256), 0, s, n, make_rays(cam_loc, dirs, rays_per_cam), near_far,
+                           (const OccInfo*)o.info, (const uint8_t*)o.dist, w.ray_tier, &w.ctr->tier);
+        skip = w.ray_tier;   // (the promote step overwrites it with the rays' tiers once the tracer is done)
+    }
+    rc = trace_impl(f, w, cam_loc, rays_per_cam, dirs, near_far, n, 0, w.o_xnorm, w.o_Tray, o_conv, o_start, w.o_end, s, skip);
     if (rc) return rc;
     if (cfg->occupancy && !cfg->full_shading) {
         rc = render_tiers(f, cfg, w, cam_loc, rays_per_cam, dirs, near_far, o_conv, o_start, w.o_end, n, rgb,

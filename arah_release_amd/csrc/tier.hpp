@@ -294,6 +294,68 @@ __device__ __forceinline__ bool occ_lookup(const OccInfo& oi, const unsigned* bi
     return (bits[b >> 5] >> (b & 31)) & 1u;
 }
 
+// Rays that cannot meet the surface.  A ray on which loops A+B converge has a surface point x(z), z in [near, far], with
+// |sdf| < 1e-5 at its canonical point and |LBS - x| < 1e-5 (RFU:426-457, RT:266): x(z) lies in a marked voxel.  A ray whose
+// segment [near, far] walks through no voxel that is marked or shares a face with a marked one (distance byte <= 1: the slack
+// covers a voxel walk that clips a corner differently from floor()) is therefore a certain miss: skip[ray] = 1, loops A and B are
+// not run for it, the tracer reports converged = 0, start = near like the reference does for a ray that left the box (RT:235,
+// 274-277).  Segments that leave the bitmap's box, and every ray of an invalid occupancy, are traced.
+__global__ void k_tier_rays(int n, RaySet rs, const float* __restrict__ near_far, const OccInfo* __restrict__ info,
+                            const uint8_t* __restrict__ dist, uint8_t* __restrict__ skip, TierStats* stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool sk = false;
+    if (i < n) {
+        const OccInfo oi = *info;
+        const float t0 = near_far[i * 2] - 1e-4f, t1 = near_far[i * 2 + 1] + 1e-4f;
+        if (oi.valid && t0 < t1) {
+            const int cam = i / rs.rays_per_cam;
+            const float o[3] = {(rs.cam_loc[cam * 3] - oi.origin[0]) * oi.inv_v, (rs.cam_loc[cam * 3 + 1] - oi.origin[1]) * oi.inv_v,
+                                (rs.cam_loc[cam * 3 + 2] - oi.origin[2]) * oi.inv_v};
+            const float d[3] = {rs.dirs[i * 3] * oi.inv_v, rs.dirs[i * 3 + 1] * oi.inv_v, rs.dirs[i * 3 + 2] * oi.inv_v};
+            // both ends inside the box (the segment is then inside: the box is convex)
+            bool inside = true;
+            int c[3];
+            float tmax[3], tdel[3];
+            int stp[3];
+            for (int a = 0; a < 3; ++a) {
+                const float p0 = o[a] + d[a] * t0, p1 = o[a] + d[a] * t1;
+                inside = inside && p0 >= 0.f && p1 >= 0.f && p0 < (float)oi.dims[a] && p1 < (float)oi.dims[a];
+                c[a] = (int)floorf(p0);
+                stp[a] = d[a] > 0.f ? 1 : -1;
+                if (d[a] != 0.f) {
+                    const float nb = d[a] > 0.f ? (float)(c[a] + 1) : (float)c[a];
+                    tmax[a] = t0 + (nb - p0) / d[a];
+                    tdel[a] = fabsf(1.0f / d[a]);
+                } else {
+                    tmax[a] = 3.4e38f;
+                    tdel[a] = 3.4e38f;
+                }
+            }
+            if (inside) {
+                sk = true;
+                for (int it = 0; it < 4096; ++it) {
+                    if (c[0] < 0 || c[1] < 0 || c[2] < 0 || c[0] >= oi.dims[0] || c[1] >= oi.dims[1] || c[2] >= oi.dims[2]) {
+                        sk = false;   // rounding walked it out of the box: trace it
+                        break;
+                    }
+                    if (dist[((long long)c[2] * oi.dims[1] + c[1]) * oi.dims[0] + c[0]] <= 1) {
+                        sk = false;
+                        break;
+                    }
+                    const int a = tmax[0] <= tmax[1] ? (tmax[0] <= tmax[2] ? 0 : 2) : (tmax[1] <= tmax[2] ? 1 : 2);
+                    if (tmax[a] > t1) break;
+                    c[a] += stp[a];
+                    tmax[a] += tdel[a];
+                    if (it == 4095) sk = false;
+                }
+            }
+        }
+        skip[i] = sk ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(sk);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(&stats->rays_untraced, (unsigned long long)__popcll(m));
+}
+
 // A workgroup's share of a list append: every wave brings n (wave-uniform); one device atomic per workgroup and batch -- a single
 // device-scope counter takes ~90 atomics / us, and one per ray made these two kernels 3-4 ms each (155 k rays).
 constexpr int kTierWaves = 16;

@@ -67,7 +67,7 @@ class ArahSampling(C.Structure):
                 ("lin_steps", _fp), ("lin_near", _fp), ("lin_far", _fp),
                 ("shade_engine", C.c_int32), ("canon_kernel", C.c_int32),
                 ("ev_canon", C.c_void_p * 2), ("ev_density", C.c_void_p * 2), ("ev_shade", C.c_void_p * 2),
-                ("occupancy", C.c_void_p)]
+                ("occupancy", C.c_void_p), ("ev_canon2", C.c_void_p * 2), ("ev_density2", C.c_void_p * 2)]
 
 
 class ArahFrame(C.Structure):
@@ -105,6 +105,7 @@ class ArahCounters(C.Structure):
                 ("n_tier_rays", C.c_uint64), ("n_tier_rays_surface", C.c_uint64), ("n_tier_rays_promoted", C.c_uint64),
                 ("n_tier_rays_skipped", C.c_uint64), ("n_tier_samples_p1", C.c_uint64), ("n_tier_samples_p2", C.c_uint64),
                 ("n_tier_samples_skipped", C.c_uint64), ("n_tier_witnesses", C.c_uint64),
+                ("n_tier_rays_untraced", C.c_uint64),
                 ("n_canon_p2", C.c_uint64), ("n_density_p2", C.c_uint64)]
 
 
@@ -463,7 +464,8 @@ class Sampling:
         """Profiling hook of THIS sampling object: every call that takes it records the torch.cuda.Event pair on its stream
         around loop C's solver ("canon"), the density pre-pass ("density") or the shading kernel ("shade").  None switches
         it off.  (Round 3 kept the handles in process-wide variables of the library.)"""
-        field = getattr(self.handle, {"canon": "ev_canon", "density": "ev_density", "shade": "ev_shade"}[which])
+        field = getattr(self.handle, {"canon": "ev_canon", "density": "ev_density", "shade": "ev_shade", "canon2": "ev_canon2",
+                                      "density2": "ev_density2"}[which])
         for ev in (start, stop):   # torch creates the hipEvent lazily, on the first record
             if ev is not None and not ev.cuda_event:
                 ev.record()

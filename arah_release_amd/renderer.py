@@ -378,6 +378,13 @@ class IDHRNetwork(nn.Module):
         # through the exact kernels, like the reference.  Lazy shading only: a frame that shades everything (large beta) has a
         # band as wide as the body's box and nothing to skip.
         self.tiering = os.environ.get("ARAH_TIERING", "1") != "0"
+        # ... and only while it pays: the band is 18 beta wide, and with a large learned beta (or a subject whose bitmap overflows
+        # its buffers) hardly a sample lies outside it.  The share of never-evaluated samples of earlier tiered frames arrives with
+        # the range guard's counters; below a third the following frames run untiered (one phase, no bitmap), every 16th one
+        # tiered again to keep the share current.  Follows `adaptive_shading` (bench.py pins both for its named passes).
+        self.tier_share = None
+        self._tier_off = False
+        self._tier_since_probe = 0
         self.precision = None    # GEMM engine frames are prepared for: None = the process default (ARAH_PRECISION, split),
                                  # hip.PRECISION_FP32 / PRECISION_SPLIT_F16 = this renderer's own choice (bench.py's passes)
         self._precision = None   # becomes hip.PRECISION_FP32 once the range guard has fired: overrides `precision`
@@ -476,6 +483,12 @@ class IDHRNetwork(nn.Module):
             if d_den > 0 and d_col >= 0 and not win_full:            # lazily shaded frame(s) went by: their share of sigma > 0 samples
                 self.shade_ratio = d_col / d_den
                 self._shade_full = self.shade_ratio > 0.7
+            tier_now = (ctr[13], ctr[14], ctr[15])                   # n_tier_samples_p1 / _p2 / _skipped
+            d_t = [a - b for a, b in zip(tier_now, g["tier"])]
+            g["tier"] = tier_now
+            if min(d_t) >= 0 and sum(d_t) > 0:                       # tiered frame(s) went by
+                self.tier_share = d_t[2] / sum(d_t)
+                self._tier_off = self.tier_share < 1.0 / 3.0
             if grew > 0:
                 self.split_nonfinite += grew
                 if self._precision != hip.PRECISION_FP32:
@@ -486,14 +499,14 @@ class IDHRNetwork(nn.Module):
         if g is None:
             if len(self._guard) >= 8:
                 self._guard.pop(next(iter(self._guard)))
-            g = self._guard[key] = {"host": torch.zeros(9, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(), "seen": 0,
-                                    "col": 0, "den": 0, "win_full": False}
+            g = self._guard[key] = {"host": torch.zeros(hip.COUNTER_BYTES // 8, dtype=torch.int64).pin_memory(), "event": torch.cuda.Event(),
+                                    "seen": 0, "col": 0, "den": 0, "win_full": False, "tier": (0, 0, 0)}
         return g
 
     def _split_guard_arm(self, g, ws, full=False):
         g["win_full"] = g["win_full"] or bool(full)   # a frame that shaded everything says nothing about the share
         # n_split_nonfinite is the ninth 64-bit counter at the head of the workspace (include/arah_hip.h: ArahCounters)
-        g["host"].copy_(ws.buf[0:72].view(torch.int64), non_blocking=True)
+        g["host"].copy_(ws.buf[0:hip.COUNTER_BYTES].view(torch.int64), non_blocking=True)
         g["event"].record()
 
     def forward(self, input):
@@ -522,9 +535,13 @@ class IDHRNetwork(nn.Module):
             full = self._shade_since_probe % 16 != 0       # every 16th frame lazily: refreshes the measured share
         samp = self.ray_tracer.sampling(dev, self.cano_view_dirs, self.render_last_pt, full_shading=full)
         pose34 = pose[0, :3, :4].detach().float().contiguous()
+        tiered = self.tiering and not full
+        if tiered and self.adaptive_shading and self._tier_off and guard is not None and self.guard_mode != "strict":
+            self._tier_since_probe += 1
+            tiered = self._tier_since_probe % 16 == 0          # every 16th frame tiered: refreshes the measured share
         rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                       ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34,
-                                                      tiered=self.tiering)
+                                                      tiered=tiered)
         if guard is not None and self.guard_mode == "strict" and frame.precision != hip.PRECISION_FP32:
             now = int(ws.buf[64:72].view(torch.int64).item())   # ArahCounters.n_split_nonfinite; synchronises the stream
             grew = now - guard["seen"] if now >= guard["seen"] else now
@@ -543,7 +560,7 @@ class IDHRNetwork(nn.Module):
                 self.last_frame = frame
                 rgb, pcam, vol, acc, dists, conv = hip.render(frame, ws, samp, cam_loc.reshape(B, 3),
                                                               ray_dirs.reshape(B * N, 3), nf.reshape(B * N, 2), pose34,
-                                                              tiered=self.tiering)
+                                                              tiered=tiered)
         elif guard is not None and self.guard_mode != "strict":
             self._split_guard_arm(guard, ws, full)
         pcam = pcam.reshape(B, N, 3)

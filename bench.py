@@ -294,6 +294,8 @@ class GpuRuntime:
         self.ev1 = torch.cuda.Event(enable_timing=True)
         self.cv0 = torch.cuda.Event(enable_timing=True)   # around loop C's solver (k_canon_solve)
         self.cv1 = torch.cuda.Event(enable_timing=True)
+        # the tiered forward launches loop C's solver and the density pass twice per frame (phase 1 / phase 2)
+        self.cw0, self.cw1, self.dw0, self.dw1 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
 
     def make_inputs(self, size, frame_idx):
         return self.scene.make_inputs(size, size, frame_idx=frame_idx, device=self.dev)
@@ -332,6 +334,24 @@ class GpuRuntime:
         which = "shade" if full_shading else "density"
         self.tracer.set_events(which, self.ev0 if on else None, self.ev1 if on else None)
         self.tracer.set_events("canon", self.cv0 if on else None, self.cv1 if on else None)
+        self.tracer.set_events("canon2", self.cw0 if on else None, self.cw1 if on else None)
+        self.tracer.set_events("density2", self.dw0 if on else None, self.dw1 if on else None)
+        if on:   # a frame that does not reach the second launches leaves these at zero
+            for e in (self.cw0, self.cw1, self.dw0, self.dw1):
+                e.record()
+
+    def set_tiering(self, on):
+        """Tiered evaluation (csrc/tier.hpp) on / off for the following frames; returns the previous setting."""
+        idhr = self.model.idhr_network
+        was, idhr.tiering = idhr.tiering, bool(on)
+        return was
+
+    def tiered(self):
+        return bool(self.model.idhr_network.tiering)
+
+    def phase2_ms(self):
+        """(loop C, density) durations of the tiered forward's second launches of the last event-timed frame."""
+        return self.cw0.elapsed_time(self.cw1), self.dw0.elapsed_time(self.dw1)
 
     def set_adaptive(self, on):
         """Lazy / full shading chosen per frame from the measured share of sigma > 0 samples (renderer.IDHRNetwork) or pinned."""
@@ -381,15 +401,16 @@ class GpuRuntime:
                     self.set_adaptive(False)
                     row = {"beta": b, "lazy_shading_pinned": one_pass()}
                     self.set_adaptive(True)
-                    idhr._shade_full, idhr.shade_ratio = False, None
+                    idhr._shade_full, idhr.shade_ratio, idhr._tier_off, idhr.tier_share = False, None, False, None
                     row["product_default"] = one_pass()       # lazy or full per frame, from the measured share
                     row["product_default"]["measured_share_of_shaded_samples"] = idhr.shade_ratio
+                    row["product_default"]["measured_share_of_samples_the_tiers_skip"] = getattr(idhr, "tier_share", None)
                 rows.append(row)
         finally:
             with torch.no_grad():
                 var.copy_(keep)
             self.set_adaptive(True)
-            idhr._shade_full, idhr.shade_ratio = False, None
+            idhr._shade_full, idhr.shade_ratio, idhr._tier_off, idhr.tier_share = False, None, False, None
         return {"note": "the same %d frames (%d in flight) with the VolSDF beta overridden; beta = 1e-3 is the subject's own value "
                         "(the reference's initial value).  lazy_shading_pinned: the density pre-pass + normal / colour for the "
                         "sigma > 0 samples only (what `value` measures); product_default: the renderer picks lazy or full "
@@ -577,11 +598,16 @@ def run(args, rt):
 
     canon_ms = {}
 
-    def timed_pass(full_shading, precision="split", n_streams=None):
+    phase2_ms = {}
+    has_tiers = hasattr(rt, "set_tiering")
+
+    def timed_pass(full_shading, precision="split", n_streams=None, tiering=None):
         """K timed steps (barrier + sync on both sides), then the same K steps again with HIP events
-        around the dominant kernel (reading an event needs a sync per step, so it stays outside)."""
+        around the dominant kernel (reading an event needs a sync per step, so it stays outside).
+        tiering: None = the product's setting, False = every sample through loops C and D (the reference's amount of work)."""
         # ARAH_FULL_SHADING=1 forces the shade-everything path in every pass (the profiler's full-shading PMC passes)
         tracer.full_shading = full_shading or os.environ.get("ARAH_FULL_SHADING") == "1"
+        was_tiering = rt.set_tiering(rt.tiered() if tiering is None else tiering) if has_tiers else None
         rt.set_adaptive(False)   # the passes measure the path they name; the product's own choice is reported by beta_sweep
         rt.set_precision(precision)
         n_streams = args.streams if n_streams is None else n_streams
@@ -602,16 +628,21 @@ def run(args, rt):
         dt = time.perf_counter() - t0
         ctr = rt.counters()
         rt.set_events(full_shading, True)
-        ms, cms = [], []
+        ms, cms, p2 = [], [], []
         for inp in timed_inputs:
             rt.render(inp)
             rt.device_sync()
             ms.append(rt.event_ms())
             cms.append(rt.canon_ms())
+            if has_tiers and rt.tiered() and not tracer.full_shading:
+                p2.append(rt.phase2_ms())
         rt.set_events(full_shading, False)
         rt.set_adaptive(True)
         rt.set_precision(default_engine)
-        canon_ms[(full_shading, precision)] = cms
+        canon_ms[(full_shading, precision, tiering)] = cms
+        phase2_ms[(full_shading, precision, tiering)] = p2
+        if has_tiers:
+            rt.set_tiering(was_tiering)
         return dt, ctr, ms
 
     default_engine = os.environ.get("ARAH_PRECISION", "split")
@@ -635,7 +666,9 @@ def run(args, rt):
                         "were not reached" + ("; value = one frame at a time" if elapsed_one else "")}
         if elapsed_one is not None:
             elapsed, counters, dens_ms = timed_pass(False, default_engine)      # the product's default path: frames in flight
-        elapsed_full = elapsed_exact = elapsed_strict = None
+        elapsed_full = elapsed_exact = elapsed_strict = elapsed_untiered = None
+        if args.passes == "all" and has_tiers and rt.tiered():   # every sample through loops C and D, like the reference
+            elapsed_untiered, counters_untiered, dens_ms_untiered = timed_pass(False, default_engine, tiering=False)
         if args.passes == "all":
             elapsed_full, counters_full, shade_ms = timed_pass(True, default_engine)  # shade every valid sample, like the reference
         if split and args.passes == "all":                      # same frames on the exact fp32 MFMA engine
@@ -648,6 +681,7 @@ def run(args, rt):
     t_max_full = aggregate(n_rays_local, elapsed_full, dist)[1] if elapsed_full else None
     t_max_exact = aggregate(n_rays_local, elapsed_exact, dist)[1] if elapsed_exact else None
     t_max_strict = aggregate(n_rays_local, elapsed_strict, dist)[1] if elapsed_strict else None
+    t_max_untiered = aggregate(n_rays_local, elapsed_untiered, dist)[1] if elapsed_untiered else None
     line = None
     if rank == 0:
         mode = cfg["model"]["renderer_kwargs"]["mode"]
@@ -658,15 +692,24 @@ def run(args, rt):
 
         # largest launch of the default path: k_canon_solve = loop C, every Broyden iteration of every valid sample in one
         # resident kernel (skinning MLP 3 -> 128 x4 -> 25 on the split engine + softmax tree + LBS blend + update)
-        cms = canon_ms[(False, default_engine)]
-        canon_avg_ms = sum(cms) / max(len(cms), 1)
-        canon_evals = counters["n_canon"] / max(len(cms), 1)
-        canon_achieved = canon_evals * F_SKIN / (canon_avg_ms * 1e-3) / 1e12
+        # Tiered forward (csrc/tier.hpp): the solver and the density pass are launched twice per frame, over the phase-1 samples
+        # (surface rays, samples inside the posed fat body, witnesses) and over the rest of the promoted rays; `achieved` is
+        # the evaluations of both launches over the time of both, avg_launch_ms the mean of the two.
+        tiers_on = has_tiers and rt.tiered()
+        cms = canon_ms[(False, default_engine, None)]
+        p2 = phase2_ms.get((False, default_engine, None)) or []
+        n_frames_ev = max(len(cms), 1)
+        canon_launches = 2 if p2 else 1
+        canon_total_ms = sum(cms) + sum(a for a, _ in p2)
+        canon_avg_ms = canon_total_ms / (n_frames_ev * canon_launches)
+        canon_evals = counters["n_canon"] / (n_frames_ev * canon_launches)
+        canon_achieved = counters["n_canon"] * F_SKIN / (canon_total_ms * 1e-3) / 1e12
         # second largest: k_density = the SDF MLP forward on every valid sample
-        n_launch = max(len(dens_ms), 1)
-        dens_samples = counters["n_density"] / n_launch           # == number of valid (converged) samples
-        dens_avg_ms = sum(dens_ms) / n_launch
-        achieved = dens_samples * F_SDF / (dens_avg_ms * 1e-3) / 1e12
+        n_launch = max(len(dens_ms), 1) * canon_launches
+        dens_total_ms = sum(dens_ms) + sum(b for _, b in p2)
+        dens_samples = counters["n_density"] / n_launch           # == number of valid (converged) samples that were evaluated
+        dens_avg_ms = dens_total_ms / n_launch
+        achieved = counters["n_density"] * F_SDF / (dens_total_ms * 1e-3) / 1e12
         flops_per_sample = F_SDF + F_SDF_GRAD + F_COL[mode]
         total_flops = path_flops(counters)
         tf = {True: "true", False: "false"}
@@ -701,6 +744,7 @@ def run(args, rt):
                          "unit": "TFLOP/s", "frac": canon_achieved / peak_fwd, "traffic": canon_traffic,
                          "traffic_unit": "bytes/launch", "traffic_source": canon_src, "traffic_live": False,
                          "avg_launch_ms": canon_avg_ms, "evaluations_per_launch": canon_evals,
+                         "launches_per_frame": canon_launches, "ms_per_frame_in_this_kernel": canon_total_ms / n_frames_ev,
                          "flops_per_evaluation": F_SKIN,
                          "peak_note": ("dense f16 MFMA peak / 3: three v_mfma_f32_16x16x32_f16 per fp32 product "
                                        "(MI355X_MICROARCH.md)" if split else "dense fp32 MFMA peak"),
@@ -726,6 +770,36 @@ def run(args, rt):
                                                    "another one renders): the latency figure",
                                            "value": total_rays / t_max_one, "unit": "rays/s",
                                            "ms_per_step": 1e3 * t_max_one / max(args.steps, 1)}
+        line["roofline"]["k_density_frac"] = achieved / peak_fwd
+        if t_max_untiered:
+            # the same frames with every sample of every ray through loops C and D, as the reference runs them
+            # (ray_tracing.py:313-380, implicit_differentiable_renderer.py:261-396): one launch of each kernel per frame
+            ucms = canon_ms[(False, default_engine, False)]
+            u_ms = sum(ucms) / max(len(ucms), 1)
+            u_ach = counters_untiered["n_canon"] / max(len(ucms), 1) * F_SKIN / (u_ms * 1e-3) / 1e12
+            d_ms = sum(dens_ms_untiered) / max(len(dens_ms_untiered), 1)
+            d_ach = counters_untiered["n_density"] / max(len(dens_ms_untiered), 1) * F_SDF / (d_ms * 1e-3) / 1e12
+            line["untiered"] = {"note": "same frames with tiered evaluation off (ARAH_TIERING=0): loops C and D over every depth sample "
+                                        "of every ray, like the reference; bit-identical images and masks",
+                                "value": total_rays / t_max_untiered, "unit": "rays/s",
+                                "ms_per_step": 1e3 * t_max_untiered / max(args.steps, 1),
+                                "algorithmic_mflop_per_ray": path_flops(counters_untiered) / max(n_rays_local, 1) / 1e6,
+                                "roofline": {"bound": "mfma", "kernel": canon_kernel, "achieved": u_ach, "peak": peak_fwd,
+                                             "unit": "TFLOP/s", "frac": u_ach / peak_fwd, "avg_launch_ms": u_ms,
+                                             "evaluations_per_launch": counters_untiered["n_canon"] / max(len(ucms), 1)},
+                                "roofline_k_density": {"bound": "mfma", "kernel": "k_density", "achieved": d_ach, "peak": peak_fwd,
+                                                       "unit": "TFLOP/s", "frac": d_ach / peak_fwd, "avg_launch_ms": d_ms}}
+            line["roofline"]["untiered_frac"] = u_ach / peak_fwd
+            line["roofline"]["untiered_k_density_frac"] = d_ach / peak_fwd
+        if tiers_on:
+            per = max(n_rays_local, 1)
+            line["tiers"] = {"note": "tiered evaluation (csrc/tier.hpp): rays whose segment misses the posed fat body skip loops A+B; "
+                                     "samples outside it are certified sigma = +0 and never evaluated; a non-surface ray is promoted "
+                                     "to full evaluation when a phase-1 sample shows density > 0 or none converged",
+                             "share_of_rays": {k[7:]: counters[k] / max(counters["n_tier_rays"], 1) for k in
+                                               ("n_tier_rays_surface", "n_tier_rays_promoted", "n_tier_rays_skipped", "n_tier_rays_untraced")},
+                             "samples_per_ray": {"phase1": counters["n_tier_samples_p1"] / per, "phase2": counters["n_tier_samples_p2"] / per,
+                                                 "never_evaluated": counters["n_tier_samples_skipped"] / per}}
         if t_max_full:
             # dominant kernel of the shade-everything path: k_shade (forward trunk on the default engine, reverse sweep
             # and colour MLP on the bf16 x 3 engine)
@@ -764,10 +838,22 @@ def run(args, rt):
         # the reference shades every valid sample in fp32: the two reference-equivalent figures next to the headline
         line["value_full_shading"] = line["full_shading"]["value"] if "full_shading" in line else None
         line["value_strict"] = line["strict"]["value"] if "strict" in line else None
+        line["value_untiered"] = line["untiered"]["value"] if "untiered" in line else None
+        # the conditions of the headline as scalars inside `config` (the driver's record keeps config / roofline / cpu_baseline)
+        line["config"].update({
+            "tiered_evaluation": bool(tiers_on), "lazy_shading": True,
+            "value_untiered": line["value_untiered"], "value_full_shading": line["value_full_shading"],
+            "value_strict": line["value_strict"],
+            "one_frame_at_a_time_ms": (1e3 * t_max_one / max(args.steps, 1)) if t_max_one else None,
+            "beta": getattr(args, "beta", None) or 1e-3,
+            "shaded_samples_per_ray": counters["n_col"] / max(n_rays_local, 1),
+            "evaluated_samples_per_ray": counters["n_density"] / max(n_rays_local, 1),
+            "skinning_evaluations_per_ray": counters["n_canon"] / max(n_rays_local, 1)})
         if world == 1 and args.passes == "all" and getattr(args, "beta", None) is None and hasattr(rt, "beta_sweep"):
             line["beta_sweep"] = rt.beta_sweep(timed_inputs, warm_inputs, args.streams, args.n_steps)
         if world == 1 and not args.no_train:
             line["training"] = rt.training_line()
+            line["config"]["training_ms_per_step"] = line["training"]["ms_per_step"]
             line["test_py_frame"] = rt.test_py_frame(args.size)
         if world == 1 and hasattr(rt, "reference_frame_parity"):
             line["parity_vs_reference_frame"] = rt.reference_frame_parity(args)

@@ -144,6 +144,9 @@ typedef struct ArahSampling {
      * (ray_tracing.py:313-380, implicit_differentiable_renderer.py:261-396).  With it, samples outside the posed fat body are
      * certified sigma = +0 without being evaluated; images and masks are the untiered path's bit for bit. */
     const void* occupancy;
+    /* the tiered path launches loop C's solver and the density pass twice (phase 1 / phase 2): event pairs of the second launches */
+    void* ev_canon2[2];
+    void* ev_density2[2];
 } ArahSampling;
 
 /* Opaque-ish handle filled by arah_prepare_frame: device pointers into the caller's frame
@@ -211,6 +214,7 @@ typedef struct ArahCounters {
      * promoted rays), never evaluated; rays that sent a witness */
     uint64_t n_tier_rays, n_tier_rays_surface, n_tier_rays_promoted, n_tier_rays_skipped;
     uint64_t n_tier_samples_p1, n_tier_samples_p2, n_tier_samples_skipped, n_tier_witnesses;
+    uint64_t n_tier_rays_untraced;       /* rays whose [near, far] segment misses the posed fat body: loops A+B not run */
     uint64_t n_canon_p2, n_density_p2;   /* the share of n_canon / n_density that phase 2 ran */
 } ArahCounters;
 

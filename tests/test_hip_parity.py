@@ -84,9 +84,10 @@ def test_struct_sizes_match_header():
     assert C.sizeof(hip.ArahBody) == 8 * 7 + 8 + 8   # seven device pointers, n_verts (+ padding), prepared tables
     n_ptr = 1 + 5 + 5 + 1 + 1 + 3 + 5 + 3 + 1 + 3 + 1 + 1 + 4 + 1 + 2 + 8 + 6 + 22 + 4 + 3 + 1   # sdf, skin (+2: point-owning-wave operands), colour (+6 transposed, +22 bf16 x 3 operands), knn, body, scalars
     assert C.sizeof(hip.ArahFrame) == 8 * n_ptr + 4 * 3 + 4   # three ints (+ padding)
-    assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6   # + two per-call switches, three event pairs
+    # + two per-call switches, three event pairs, the occupancy pointer and the two phase-2 event pairs of the tiered forward
+    assert C.sizeof(hip.ArahSampling) == 4 * 6 + 8 * 3 + 4 * 2 + 8 * 6 + 8 + 8 * 4
     assert C.sizeof(hip.ArahTrainIn) == 4 * 4 + 8 * (6 + 1 + 5 + 1)
-    assert C.sizeof(hip.ArahCounters) == 72
+    assert C.sizeof(hip.ArahCounters) == 72 + 8 * 11   # + the tiered forward's bookkeeping
     # ... and what the C compiler makes of the header itself
     import shutil
     import subprocess
@@ -620,6 +621,7 @@ def test_work_counters_against_oracle(scene):
     model, cfg = config.build_synthetic_model("zju377_mono", 64, 16, 16, device=dev)
     tracer = model.idhr_network.ray_tracer
     tracer.full_shading = True
+    model.idhr_network.tiering = False   # the reference's amount of work: every sample through loops C and D (tests/test_tiered.py has the tiers)
     with torch.no_grad():
         model(scene.make_inputs(96, 96, frame_idx=3, max_rays=1024, device=dev), eval=True)
         ws = tracer.workspace(dev)
