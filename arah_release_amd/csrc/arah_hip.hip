@@ -4633,12 +4633,17 @@ static int render_tiers(const ArahFrame* f, const ArahSampling* cfg, Workspace& 
     hipLaunchKernelGGL(k_sample_depths, dim3((n + 127) / 128), dim3(128), 0, s, n, S, cfg->n_near, cfg->n_far, near_far, conv,
                        start, end, cfg->lin_steps, cfg->lin_near, cfg->lin_far, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, w.o_z, w.q_smask);
-    hipLaunchKernelGGL(k_tier_classify, dim3(min(2048, (n + kTierWaves - 1) / kTierWaves)), dim3(kTierWaves * 64), 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
+    const dim3 gt(min(2048, (n + kTierWaves - 1) / kTierWaves)), bt(kTierWaves * 64);
+    hipLaunchKernelGGL(k_tier_classify<0>, gt, bt, 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
+                       (const OccInfo*)o.info, (const unsigned*)o.bits, (const uint8_t*)o.dist, w.listA, &tc[TC_N1], stats);
+    hipLaunchKernelGGL(k_tier_classify<1>, gt, bt, 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
                        (const OccInfo*)o.info, (const unsigned*)o.bits, (const uint8_t*)o.dist, w.listA, &tc[TC_N1], stats);
     // phase 1: surface rays, marked samples, witnesses
     int rc = tier_phase(f, cfg, fd, w, rs, Q, w.listA, &tc[TC_N1], w.listC, &tc[TC_NSHADE], 1, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tier_promote, dim3(min(2048, (n + kTierWaves - 1) / kTierWaves)), dim3(kTierWaves * 64), 0, s, n, S, conv, w.q_smask, (const uint8_t*)w.o_mask,
+    hipLaunchKernelGGL(k_tier_promote<0>, gt, bt, 0, s, n, S, conv, w.q_smask, (const uint8_t*)w.o_mask,
+                       (const f32x4*)w.shaded, w.listD, &tc[TC_N2], w.ray_tier, stats);
+    hipLaunchKernelGGL(k_tier_promote<1>, gt, bt, 0, s, n, S, conv, w.q_smask, (const uint8_t*)w.o_mask,
                        (const f32x4*)w.shaded, w.listD, &tc[TC_N2], w.ray_tier, stats);
     // phase 2: the remaining samples of the promoted rays
     hipLaunchKernelGGL(k_tier_snap, dim3(1), dim3(64), 0, s, (const unsigned long long*)&w.ctr->n_canon,

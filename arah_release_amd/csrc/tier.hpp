@@ -277,7 +277,7 @@ __global__ void k_occ_dist_yz(const OccInfo* info, uint8_t* __restrict__ dist) {
 // ---------------------------------------------------------------------------------------------------------------------
 // the tiers of one frame
 // ---------------------------------------------------------------------------------------------------------------------
-enum { TS_NONE = 0, TS_PHASE1 = 1, TS_PENDING = 2, TS_PHASE2 = 3 };
+enum { TS_NONE = 0, TS_PHASE1 = 1, TS_PENDING = 2, TS_PHASE2 = 3, TS_WITNESS = 4 /* between the two classify passes only */ };
 enum { TC_N1 = 0, TC_HEAD1, TC_ND1, TC_N2, TC_HEAD2, TC_ND2, TC_NSHADE, TC_COUNT = 16 };
 
 typedef TierStatsRaw TierStats;   // tail of Counters (ArahCounters.n_tier_*)
@@ -391,6 +391,10 @@ __device__ __forceinline__ void tier_flush_stats(const unsigned (&loc)[NS], unsi
 }
 
 // One wave per ray, one lane per depth sample (two for n_steps > 64).  state[q]: TS_* of every sample; phase-1 samples -> list1.
+// Two passes so that the WITNESSES head the list: they are the samples farthest from the body, the slow ones of Broyden's
+// iteration (up to 51 evaluations; near the body two) -- loop C's resident kernel takes the list front to back, and long jobs
+// first is what keeps its tail short.  PASS 0 classifies and appends the witnesses, PASS 1 appends the rest.
+template <int PASS>
 __global__ __launch_bounds__(kTierWaves * 64) void k_tier_classify(int n, int S, RaySet rs, const uint8_t* __restrict__ conv,
                                                         const float* __restrict__ z, uint8_t* __restrict__ state,
                                                         const OccInfo* __restrict__ info, const unsigned* __restrict__ bits,
@@ -406,62 +410,74 @@ __global__ __launch_bounds__(kTierWaves * 64) void k_tier_classify(int n, int S,
         const bool live = ray < n;
         const bool surf = live && conv[ray] != 0;
         int st[2] = {TS_NONE, TS_NONE};
-        int dd[2] = {255, 255};
-        bool any_marked = false;
-        for (int it = 0; it < 2; ++it) {
-            const int s = lane + it * 64;
-            if (live && s < S) {
-                const size_t q = (size_t)ray * S + s;
-                if (state[q]) {
-                    if (surf) st[it] = TS_PHASE1;
-                    else {
-                        int d;
-                        const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
-                        st[it] = mk ? TS_PHASE1 : TS_PENDING;
-                        dd[it] = d;
+        bool witness = false;
+        if (PASS == 0) {
+            int dd[2] = {255, 255};
+            bool any_marked = false;
+            for (int it = 0; it < 2; ++it) {
+                const int s = lane + it * 64;
+                if (live && s < S) {
+                    const size_t q = (size_t)ray * S + s;
+                    if (state[q]) {
+                        if (surf) st[it] = TS_PHASE1;
+                        else {
+                            int d;
+                            const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
+                            st[it] = mk ? TS_PHASE1 : TS_PENDING;
+                            dd[it] = d;
+                        }
                     }
                 }
+                any_marked = any_marked || __ballot(st[it] == TS_PHASE1) != 0ull;
             }
-            any_marked = any_marked || __ballot(st[it] == TS_PHASE1) != 0ull;
-        }
-        bool witness = false;
-        if (live && !surf && !any_marked) {   // the pending sample nearest to the fat body witnesses "any valid"
-            unsigned key = 0xffffffffu;
-            for (int it = 0; it < 2; ++it)
-                if (st[it] == TS_PENDING) key = min(key, ((unsigned)dd[it] << 16) | (unsigned)(lane + it * 64));
-            unsigned best = key;
-            for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
-            if (best != 0xffffffffu) {
-                const int ws = (int)(best & 0xffffu);
-                if ((ws & 63) == lane) st[ws >> 6] = TS_PHASE1;
-                witness = true;
+            if (live && !surf && !any_marked) {   // the pending sample nearest to the fat body witnesses "any valid"
+                unsigned key = 0xffffffffu;
+                for (int it = 0; it < 2; ++it)
+                    if (st[it] == TS_PENDING) key = min(key, ((unsigned)dd[it] << 16) | (unsigned)(lane + it * 64));
+                unsigned best = key;
+                for (int o = 32; o > 0; o >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, o));
+                if (best != 0xffffffffu) {
+                    const int ws = (int)(best & 0xffffu);
+                    if ((ws & 63) == lane) st[ws >> 6] = TS_WITNESS;
+                    witness = true;
+                }
+            }
+        } else {
+            for (int it = 0; it < 2; ++it) {
+                const int s = lane + it * 64;
+                if (live && s < S) st[it] = state[(size_t)ray * S + s];
             }
         }
-        int n1 = 0;
+        // what this pass appends: the witnesses (PASS 0) / the other phase-1 samples (PASS 1)
+        int n1 = 0, n_p1 = 0;
         unsigned long long m1[2];
         for (int it = 0; it < 2; ++it) {
-            m1[it] = __ballot(st[it] == TS_PHASE1);
+            m1[it] = __ballot(st[it] == (PASS == 0 ? TS_WITNESS : TS_PHASE1));
             n1 += __popcll(m1[it]);
+            n_p1 += __popcll(__ballot(st[it] == TS_PHASE1 || st[it] == TS_WITNESS));
         }
         int base = tier_block_base(n1, wave, lane, count1, sh_base);
-        if (live) {
+        if (live && PASS == 0) {
             loc[0] += 1u;
             loc[1] += surf ? 1u : 0u;
             loc[2] += witness ? 1u : 0u;
-            loc[3] += (unsigned)n1;
+            loc[3] += (unsigned)n_p1;
         }
         for (int it = 0; it < 2; ++it) {
             const int s = lane + it * 64;
             if (live && s < S) {
                 const size_t q = (size_t)ray * S + s;
-                state[q] = (uint8_t)st[it];
-                if (st[it] == TS_PHASE1) list1[base + __popcll(m1[it] & ((1ull << lane) - 1ull))] = (int)q;
+                if (PASS == 0) state[q] = (uint8_t)st[it];
+                else if (st[it] == TS_WITNESS) state[q] = TS_PHASE1;
+                if (st[it] == (PASS == 0 ? TS_WITNESS : TS_PHASE1)) list1[base + __popcll(m1[it] & ((1ull << lane) - 1ull))] = (int)q;
             }
             base += __popcll(m1[it]);
         }
     }
-    unsigned long long* const dst[4] = {&stats->rays, &stats->rays_surface, &stats->witnesses, &stats->samples_p1};
-    tier_flush_stats<4>(loc, dst, wave, lane, sh_stats);
+    if (PASS == 0) {
+        unsigned long long* const dst[4] = {&stats->rays, &stats->rays_surface, &stats->witnesses, &stats->samples_p1};
+        tier_flush_stats<4>(loc, dst, wave, lane, sh_stats);
+    }
 }
 
 // RT:447-461, 549-555 for the samples of one phase: normalise the solution, converged = |g|_best < thr; the converged ones go
@@ -491,6 +507,9 @@ __global__ __launch_bounds__(256) void k_tier_finalize(FrameDev fr, const int* _
 
 // One wave per ray after phase 1: promote the non-surface rays whose phase-1 samples show density > 0, or of which none
 // converged; their pending samples -> list2.
+// PASS 0 decides and appends the rays promoted because NONE of their phase-1 samples converged (far from the body: the slow
+// samples, see k_tier_classify), PASS 1 appends the rays promoted for a density > 0.
+template <int PASS>
 __global__ __launch_bounds__(kTierWaves * 64) void k_tier_promote(int n, int S, const uint8_t* __restrict__ conv, uint8_t* __restrict__ state,
                                                        const uint8_t* __restrict__ mask, const f32x4* __restrict__ shaded,
                                                        int* __restrict__ list2, int* count2, uint8_t* __restrict__ ray_tier,
@@ -518,25 +537,26 @@ __global__ __launch_bounds__(kTierWaves * 64) void k_tier_promote(int n, int S, 
         }
         const bool any_pos = __ballot(pos) != 0ull, any_ok = __ballot(ok) != 0ull;
         const bool promote = live && !surf && (any_pos || !any_ok);
+        const bool mine = promote && (PASS == 0 ? !any_ok : any_ok);   // the rays this pass appends
         unsigned long long m2[2];
         int n2 = 0, n_pend = 0;
         for (int it = 0; it < 2; ++it) {
             const unsigned long long pend = __ballot(st[it] == TS_PENDING);
             n_pend += __popcll(pend);
-            m2[it] = promote ? pend : 0ull;
+            m2[it] = mine ? pend : 0ull;
             n2 += __popcll(m2[it]);
         }
         int base = tier_block_base(n2, wave, lane, count2, sh_base);
-        if (live) {
+        if (live && PASS == 0) {
             if (lane == 0 && ray_tier) ray_tier[ray] = surf ? 1 : (promote ? 2 : 0);
             loc[0] += promote ? 1u : 0u;
             loc[1] += (!promote && !surf) ? 1u : 0u;
-            loc[2] += (unsigned)n2;
+            loc[2] += promote ? (unsigned)n_pend : 0u;
             loc[3] += promote ? 0u : (unsigned)n_pend;
         }
         for (int it = 0; it < 2; ++it) {
             const int s = lane + it * 64;
-            if (live && s < S && promote && st[it] == TS_PENDING) {
+            if (live && s < S && mine && st[it] == TS_PENDING) {
                 const size_t q = (size_t)ray * S + s;
                 state[q] = TS_PHASE2;
                 list2[base + __popcll(m2[it] & ((1ull << lane) - 1ull))] = (int)q;
@@ -544,8 +564,10 @@ __global__ __launch_bounds__(kTierWaves * 64) void k_tier_promote(int n, int S, 
             base += __popcll(m2[it]);
         }
     }
-    unsigned long long* const dst[4] = {&stats->rays_promoted, &stats->rays_skipped, &stats->samples_p2, &stats->samples_skipped};
-    tier_flush_stats<4>(loc, dst, wave, lane, sh_stats);
+    if (PASS == 0) {
+        unsigned long long* const dst[4] = {&stats->rays_promoted, &stats->rays_skipped, &stats->samples_p2, &stats->samples_skipped};
+        tier_flush_stats<4>(loc, dst, wave, lane, sh_stats);
+    }
 }
 
 // phase-2 share of the work counters: snapshot before (mode 0), difference after (mode 1)

@@ -125,7 +125,7 @@ def live_traffic(args, kernels, limit_s=150.0):
         return None, "this run is itself under a profiler: no nested rocprofv3 passes"
     tmp = tempfile.mkdtemp(prefix="arah_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--streams", "1", "--no-cpu-baseline",
-             "--no-train", "--passes", "default", "--no-live-traffic", "--size", str(args.size), "--n-steps", str(args.n_steps),
+             "--no-gpu-baseline", "--no-train", "--passes", "default", "--no-live-traffic", "--size", str(args.size), "--n-steps", str(args.n_steps),
              "--config", args.config]
     per = {}
     try:
@@ -185,6 +185,38 @@ def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays, model_g
     return out
 
 
+def gpu_torch_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu, dev):
+    """The stand-in for "the reference's single-GPU rays/s" (BASELINE.json: ">= 10x the reference single-GPU
+    rays/sec"): the reference's op sequence -- the oracle, pinned against the reference's own outputs -- on PyTorch-ROCm tensors
+    on THIS GPU, with the reference's chunk sizes and its per-batch host round trips of eval_sdf (oracle/gpu_standin.py), on
+    `sample_rays` rays spread evenly over frame 0 of the workload; the HIP path renders the same rays for the parity figures.
+    Outside the timed region of `value`, like cpu_baseline."""
+    import numpy as np
+    from arah_release_amd import config
+    from oracle import gpu_standin as G
+    cfg = config.builtin_config(cfg_name, n_steps, near, far)
+    cvd = cfg["model"]["cano_view_dirs"]
+    mk = lambda n: scene.make_inputs(size, size, frame_idx=0, max_rays=n if n else None, device=dev)   # noqa: E731
+    ref, dt, n = G.timed(model_gpu, mk, cvd, sample_rays, 2048, n_steps, near, far)
+    with torch.no_grad():
+        got = model_gpu(mk(sample_rays), eval=True)
+    rgb = got["rgb_values"][0].double().cpu().numpy()
+    mask = got["network_body_mask"][0].cpu().numpy()
+    rgb_ref = ref["rgb_values"].double().cpu().numpy()
+    mask_ref = ref["network_body_mask"].cpu().numpy()
+    mse = float(np.mean((rgb - rgb_ref) ** 2))
+    return {"value": n / dt, "unit": "rays/s", "kind": "stand-in (BASELINE.md section 2): the reference's op sequence on PyTorch-ROCm on this "
+                                                       "GPU -- oracle/arah_oracle.py on cuda tensors, exact brute-force 1-NN on the device for "
+                                                       "pytorch3d.knn_points, eval_sdf in 1e5-point batches with a host round trip each "
+                                                       "(root_finding_utils.py:116-144), loop C in 1e6-point chunks, loop D in 20 480-ray chunks; "
+                                                       "the reference itself publishes no rays/s and cannot run here",
+            "sample": "%d rays %s frame 0 of the %dx%dx%d workload, one render after a 2048-ray warm-up, %.2f s"
+                      % (n, "evenly subsampled from" if sample_rays else "= every ray of", size, size, n_steps, dt),
+            "seconds": dt, "torch": torch.__version__,
+            "psnr_hip_vs_standin_db": None if mse == 0 else -10.0 * float(np.log10(mse)),
+            "mask_agreement_hip_vs_standin": float((mask == mask_ref).mean())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +227,10 @@ def main():
     ap.add_argument("--config", default="zju377_mono")
     ap.add_argument("--cpu-sample-rays", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gpu-baseline-rays", type=int, default=0,
+                    help="rays of frame 0 the PyTorch-ROCm stand-in of the reference's GPU path renders (vs_baseline's denominator); "
+                         "0 = the whole frame (the reference's own batch sizes then see a full frame's points)")
+    ap.add_argument("--no-gpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the training-step line (configs[2], one GPU)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="do not spawn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) that measure roofline.traffic on "
@@ -447,6 +483,10 @@ class GpuRuntime:
                 "surface_points_within_2e-4": float((np.abs(pc[both] - g["points_cam"][both]).max(-1) <= 2e-4).mean()),
                 "reference_cpu_rays_per_s": float(rgb.shape[0] / float(g["reference_seconds"])),
                 "reference_cpu_threads": int(g["reference_threads"])}
+
+    def gpu_torch_baseline(self, args, near, far):
+        return gpu_torch_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.gpu_baseline_rays,
+                                  self.model, self.dev)
 
     def cpu_baseline(self, args, near, far):
         return cpu_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.cpu_sample_rays,
@@ -857,6 +897,17 @@ def run(args, rt):
             line["test_py_frame"] = rt.test_py_frame(args.size)
         if world == 1 and hasattr(rt, "reference_frame_parity"):
             line["parity_vs_reference_frame"] = rt.reference_frame_parity(args)
+        if world == 1 and not getattr(args, "no_gpu_baseline", True) and hasattr(rt, "gpu_torch_baseline"):
+            try:
+                gb = rt.gpu_torch_baseline(args, near, far)
+            except Exception as e:   # the baseline leg must not cost the measurement
+                gb = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
+            line["gpu_torch_baseline"] = gb
+            if gb.get("value"):
+                line["vs_baseline"] = line["value"] / world / gb["value"]   # per GPU, like the denominator
+                line["vs_baseline_kind"] = ("value per GPU / gpu_torch_baseline.value: a measured stand-in (BASELINE.md section 2), "
+                                            "not a number the reference publishes")
+                line["config"]["gpu_torch_baseline_rays_per_s"] = gb["value"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = rt.cpu_baseline(args, near, far)
             line["psnr_vs_oracle_db"] = line["cpu_baseline"].get("psnr_vs_oracle_db")

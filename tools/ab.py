@@ -13,7 +13,7 @@ res = {l: [] for l in libs}
 for r in range(rounds):
     for l in libs:
         env = dict(os.environ, ARAH_LIB_PATH=os.path.abspath(l))
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--passes", "default",
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-gpu-baseline", "--passes", "default",
                               "--no-train", "--steps", "8", "--warmup", "2"], env=env, capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])

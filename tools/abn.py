@@ -26,7 +26,7 @@ for a in args:
 res = {n: [] for n, _ in variants}
 for r in range(rounds):
     for name, env in variants:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--passes", "default",
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-gpu-baseline", "--passes", "default",
                               "--no-train", "--steps", "6", "--warmup", "2", "--streams", os.environ.get("ABN_STREAMS", "1")], env=dict(os.environ, **env), capture_output=True, text=True)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1])

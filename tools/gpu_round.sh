@@ -20,7 +20,8 @@ try:
     d = json.load(open("$OUT/bench_default.json"))
     print("rays/s", d["value"], "ms", d["ms_per_step"], "canon frac", d["roofline"]["frac"], "canon_ms", d["roofline"]["avg_launch_ms"],
           "density frac", d["roofline_k_density"]["frac"], "dens_ms", d["roofline_k_density"]["avg_launch_ms"])
-    for k in ("full_shading", "exact_fp32_engine", "strict"):
+    print("vs_baseline", d.get("vs_baseline"), (d.get("gpu_torch_baseline") or {}).get("value"), "tiers", d.get("tiers", {}).get("samples_per_ray"))
+    for k in ("untiered", "full_shading", "exact_fp32_engine", "strict"):
         if k in d: print(k, d[k]["value"], d[k]["ms_per_step"])
     print("one frame at a time", d.get("one_frame_at_a_time"))
     print("training", d.get("training"))
@@ -30,7 +31,7 @@ except Exception as e:
 PY
 fi
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o kt -- python $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/bench_prof.json 2> $OUT/prof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o kt -- python $ROOT/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-gpu-baseline --no-train --passes default > $OUT/bench_prof.json 2> $OUT/prof.err
 cd $ROOT
 DB=$(ls -S $(find $OUT/prof -name "*.db") | head -1)
 [ -n "$DB" ] && python tools/rocpd_stats.py $DB > $OUT/kernel_stats.txt && head -30 $OUT/kernel_stats.txt
@@ -39,13 +40,13 @@ if [ "$2" = "pmc" ]; then
   cd /tmp
   for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY"; do
     N=$(echo $C | cut -d' ' -f1)
-    timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/pmc_$N.log 2>&1
+    timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmc_$N -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-gpu-baseline --no-train --passes default > $OUT/pmc_$N.log 2>&1
   done
   # the shade-everything path (the reference's amount of work): its own FETCH / WRITE passes
   for C in FETCH_SIZE WRITE_SIZE; do
-    ARAH_FULL_SHADING=1 timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmcfull_$C -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/pmcfull_$C.log 2>&1
+    ARAH_FULL_SHADING=1 timeout 900 rocprofv3 --kernel-trace --pmc $C -d $OUT/pmcfull_$C -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-gpu-baseline --no-train --passes default > $OUT/pmcfull_$C.log 2>&1
   done
-  ARAH_FULL_SHADING=1 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmcfull_SQ -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-train --passes default > $OUT/pmcfull_SQ.log 2>&1
+  ARAH_FULL_SHADING=1 timeout 900 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY -d $OUT/pmcfull_SQ -o pmc -- python $ROOT/bench.py --steps 1 --warmup 1 --streams 1 --no-cpu-baseline --no-gpu-baseline --no-train --passes default > $OUT/pmcfull_SQ.log 2>&1
   cd $ROOT
   big() { ls -S $(find $1 -name "*.db") 2>/dev/null | head -1; }
   F=$(big $OUT/pmc_FETCH_SIZE); W=$(big $OUT/pmc_WRITE_SIZE)
