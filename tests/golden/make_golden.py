@@ -6,7 +6,7 @@ Runs only in the build container (needs /root/reference, see ref_shim.py).  The 
 reference's functions are called directly and their inputs/outputs are stored.
 
     python tests/golden/make_golden.py            # writes F1..F7 (about 9 MB)
-    python tests/golden/make_golden.py f8         # writes F8 (training step, about 1 MB)
+    python tests/golden/make_golden.py f8         # writes F8 (training step, about 3 MB: with strided gradient vectors since round 6)
 
 Fixtures:
   f1_broyden3.npz      broyden() KAT, D=3 (g = LBS(x) - target)
@@ -144,6 +144,23 @@ def make_f8():
     grads = {"grad." + n: p.grad.norm() for n, p in model.named_parameters() if p.grad is not None}
     n_no_grad = sum(1 for n, p in model.named_parameters() if p.grad is None)
     print("parameters with / without gradient:", len(grads), n_no_grad)
+    # round 6: gradient DIRECTIONS, not only norms.  Every tensor's gradient, strided so that the fixture stays ~2 MB:
+    # whole tensors for beta, the latent code, the skinning MLP, the pose encoder and the colour MLP's gains and biases; every 4th
+    # element of the FiLM mapping network, every 8th of the colour MLP's weight_v, every 512th of the hypernetwork's layers.
+    # ("gvec.<name>" = grad.reshape(-1)[::stride], "gstride.<name>" = stride)
+    def stride_of(n, p):
+        if n.startswith("sdf_decoder.net.layers"):
+            return 512
+        if n.startswith("sdf_decoder.net.mapping_network"):
+            return 4
+        if n.startswith("color_decoder") and n.endswith("weight_v"):
+            return 8
+        return 1
+    for n, p in model.named_parameters():
+        if p.grad is not None:
+            st = stride_of(n, p)
+            grads["gvec." + n] = p.grad.reshape(-1)[::st].clone()
+            grads["gstride." + n] = torch.tensor(st)
     save("f8_train_step_zju313.npz", frame_idx=2, H=128, W=128, max_rays=2048, view_noise=view_noise,
          rand_steps=draws[0][0], rand_near=draws[1][0], rand_far=draws[2][0], rand_eikonal=draws[3][0],
          rgb_values=out["rgb_values"][0], sdf_output=out["sdf_output"][0], network_body_mask=out["network_body_mask"][0],
