@@ -146,11 +146,12 @@ def make_f8():
     print("parameters with / without gradient:", len(grads), n_no_grad)
     # round 6: gradient DIRECTIONS, not only norms.  Every tensor's gradient, strided so that the fixture stays ~2 MB:
     # whole tensors for beta, the latent code, the skinning MLP, the pose encoder and the colour MLP's gains and biases; every 4th
-    # element of the FiLM mapping network, every 8th of the colour MLP's weight_v, every 512th of the hypernetwork's layers.
+    # element of the FiLM mapping network, every 8th of the colour MLP's weight_v, every 509th / 13th of the hypernetwork's large /
+    # medium tensors (its small ones whole).
     # ("gvec.<name>" = grad.reshape(-1)[::stride], "gstride.<name>" = stride)
     def stride_of(n, p):
         if n.startswith("sdf_decoder.net.layers"):
-            return 512
+            return 509 if p.numel() >= (1 << 20) else (13 if p.numel() >= (1 << 14) else 1)   # primes: a power of two walks one column
         if n.startswith("sdf_decoder.net.mapping_network"):
             return 4
         if n.startswith("color_decoder") and n.endswith("weight_v"):

@@ -887,7 +887,7 @@ def test_training_step_against_reference(scene, eng):
     assert n == 211 and not bad, bad
     # round 6: directions.  gvec.<name> = the reference's gradient, flattened and strided (whole tensors for beta, the latent
     # code, the skinning MLP, the pose encoder, the colour MLP's gains and biases; every 4th element of the FiLM mapping network,
-    # every 8th of the colour MLP's weight_v, every 512th of the hypernetwork's layers): cosine and relative L2 per tensor
+    # every 8th of the colour MLP's weight_v, every 509th / 13th of the hypernetwork's large / medium tensors): cosine and relative L2 per tensor
     worst_cos, worst_rel, report = 1.0, 0.0, []
     for name, p in model.named_parameters():
         ref = g["gvec." + name].astype(np.float64)
