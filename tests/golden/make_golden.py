@@ -709,7 +709,8 @@ def make_f17():
     print("hidden |activation| max per layer:", amax, "converged", int(r3["valid_ids"].sum()), "of", Pb)
 
 
-F7_FULL = (("zju377_mono", (256, 256), (32, 8, 8), 1), ("zju377_mono", (512, 512), (64, 16, 16), 0))   # BASELINE configs 1 and 2
+F7_FULL = (("zju377_mono", (256, 256), (32, 8, 8), 1), ("zju377_mono", (512, 512), (64, 16, 16), 0),   # BASELINE configs 1 and 2
+           ("h36m", (128, 128), (128, 32, 32), 4))   # round 6: BASELINE config 5's shapes and sampling on a 128 x 128 frame (`f7full 2`)
 F7_SET = (("zju377_mono", (64, 64), (64, 16, 16), 0), ("zju313", (64, 64), (64, 16, 16), 1), ("h36m", (48, 48), (32, 8, 8), 2),
           ("zju377_mono", (128, 128), (32, 8, 8), 5), ("h36m", (40, 40), (128, 32, 32), 3))
 

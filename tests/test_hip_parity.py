@@ -586,6 +586,7 @@ def test_shade_composite_against_reference(scene, name, tag, eng):
                                         ("f7_forward_h36m_48x48_s32.npz", "h36m"),
                                         ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono"),
                                         ("f7_forward_h36m_40x40_s128.npz", "h36m"),   # BASELINE config 5's sampling (128, 32, 32)
+                                        ("f7_forward_h36m_128x128_s128.npz", "h36m"),   # round 6: config 5's shapes and sampling, 128 x 128 (the reference, 8 threads)
                                         ("f7_forward_zju377_mono_256x256_s32.npz", "zju377_mono"),   # BASELINE config 1, full size
                                         ("f7_forward_zju377_mono_512x512_s64.npz", "zju377_mono")])  # BASELINE config 2: the benchmark frame, rendered by the reference
 @pytest.mark.parametrize("eng", ENGINES)

@@ -180,15 +180,16 @@ def test_f7_forward(scene, fname, name):
     np.testing.assert_allclose(out["points_cam"].numpy()[both], g["points_cam"][both], rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("fname,n_sub", [("f7_forward_zju377_mono_256x256_s32.npz", 2048),    # BASELINE config 1 at its full size
-                                         ("f7_forward_zju377_mono_512x512_s64.npz", 1024)])   # BASELINE config 2: the benchmark frame
-def test_f7_full_frames_on_a_ray_subset(scene, fname, n_sub):
+@pytest.mark.parametrize("fname,n_sub,name", [("f7_forward_zju377_mono_256x256_s32.npz", 2048, "zju377_mono"),    # BASELINE config 1 at its full size
+                                              ("f7_forward_zju377_mono_512x512_s64.npz", 1024, "zju377_mono"),    # BASELINE config 2: the benchmark frame
+                                              ("f7_forward_h36m_128x128_s128.npz", 512, "h36m")])   # round 6: config 5's shapes and sampling (128, 32, 32)
+def test_f7_full_frames_on_a_ray_subset(scene, fname, n_sub, name):
     """The reference's own render of BASELINE configs 1 and 2 at FULL size (tests/golden/make_golden.py f7full: 256 x 256 x 32 and
     the 512 x 512 x 64 benchmark frame, one and nine minutes of the reference on eight cores).  The oracle renders an evenly
     spread subset of the frame's rays -- rays are independent, the subset is what make_inputs(max_rays=...) picks -- and must
     agree with the reference's rows for those rays; the GPU test holds the HIP path to the whole frame."""
     g = golden(fname)
-    model, cfg = get_model("zju377_mono")
+    model, cfg = get_model(name)
     H, W, fidx = int(g["H"]), int(g["W"]), int(g["frame_idx"])
     n_full = int(g["rgb_values"].shape[0])
     inputs = scene.make_inputs(H, W, frame_idx=fidx, max_rays=n_sub)

@@ -65,6 +65,7 @@ def _assert_same(res, label):
                                         ("f7_forward_h36m_48x48_s32.npz", "h36m"),
                                         ("f7_forward_zju377_mono_128x128_s32.npz", "zju377_mono"),
                                         ("f7_forward_h36m_40x40_s128.npz", "h36m"),
+                                        ("f7_forward_h36m_128x128_s128.npz", "h36m"),   # round 6: config 5's shapes and sampling, 128 x 128 (the reference, 8 threads)
                                         ("f7_forward_zju377_mono_256x256_s32.npz", "zju377_mono"),
                                         ("f7_forward_zju377_mono_512x512_s64.npz", "zju377_mono")])
 def test_tiers_equal_the_exact_path_on_the_reference_fixtures(scene, fname, name):
