@@ -4608,12 +4608,16 @@ static int tier_phase(const ArahFrame* f, const ArahSampling* cfg, const FrameDe
     int rc = run_broyden3(fd, w, nullptr, CanonOut{w.o_pts, w.o_T, w.q_err}, Q, s, cfg->canon_kernel,
                           phase == 1 ? cfg->ev_canon : cfg->ev_canon2, list, cnt);
     if (rc) return rc;
+    // phase 1: the witnesses at the head of the list are certified sigma = +0; phase 2: every sample is (tier.hpp)
     hipLaunchKernelGGL(k_tier_finalize, dim3(grid_for(Q, 256)), dim3(256), 0, s, fd, list, (const int*)&cnt[0],
-                       (const float*)w.q_err, w.o_pts, w.o_mask, dens_list, &cnt[2]);
-    const bool ev = evd[0] && evd[1];
-    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(evd[0]), s);
-    launch_density(fd, w, w.o_pts, Q, (const int*)dens_list, (const int*)&cnt[2], w.listB, n_shade, s);
-    if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(evd[1]), s);
+                       phase == 1 ? (const int*)&w.tcounts[TC_NWIT] : (const int*)&cnt[0], (const float*)w.q_err, w.o_pts, w.o_mask,
+                       w.shaded, dens_list, &cnt[2]);
+    if (phase == 1) {
+        const bool ev = evd[0] && evd[1];
+        if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(evd[0]), s);
+        launch_density(fd, w, w.o_pts, Q, (const int*)dens_list, (const int*)&cnt[2], w.listB, n_shade, s);
+        if (ev) hipEventRecord(reinterpret_cast<hipEvent_t>(evd[1]), s);
+    }
     (void)f;
     return check_launch();
 }
@@ -4636,6 +4640,7 @@ static int render_tiers(const ArahFrame* f, const ArahSampling* cfg, Workspace& 
     const dim3 gt(min(2048, (n + kTierWaves - 1) / kTierWaves)), bt(kTierWaves * 64);
     hipLaunchKernelGGL(k_tier_classify<0>, gt, bt, 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
                        (const OccInfo*)o.info, (const unsigned*)o.bits, (const uint8_t*)o.dist, w.listA, &tc[TC_N1], stats);
+    hipMemcpyAsync(&tc[TC_NWIT], &tc[TC_N1], sizeof(int), hipMemcpyDeviceToDevice, s);   // the witnesses head the list
     hipLaunchKernelGGL(k_tier_classify<1>, gt, bt, 0, s, n, S, rs, conv, (const float*)w.o_z, w.q_smask,
                        (const OccInfo*)o.info, (const unsigned*)o.bits, (const uint8_t*)o.dist, w.listA, &tc[TC_N1], stats);
     // phase 1: surface rays, marked samples, witnesses

@@ -278,7 +278,7 @@ __global__ void k_occ_dist_yz(const OccInfo* info, uint8_t* __restrict__ dist) {
 // the tiers of one frame
 // ---------------------------------------------------------------------------------------------------------------------
 enum { TS_NONE = 0, TS_PHASE1 = 1, TS_PENDING = 2, TS_PHASE2 = 3, TS_WITNESS = 4 /* between the two classify passes only */ };
-enum { TC_N1 = 0, TC_HEAD1, TC_ND1, TC_N2, TC_HEAD2, TC_ND2, TC_NSHADE, TC_COUNT = 16 };
+enum { TC_N1 = 0, TC_HEAD1, TC_ND1, TC_N2, TC_HEAD2, TC_ND2, TC_NSHADE, TC_NWIT, TC_COUNT = 16 };
 
 typedef TierStatsRaw TierStats;   // tail of Counters (ArahCounters.n_tier_*)
 
@@ -481,12 +481,17 @@ __global__ __launch_bounds__(kTierWaves * 64) void k_tier_classify(int n, int S,
 }
 
 // RT:447-461, 549-555 for the samples of one phase: normalise the solution, converged = |g|_best < thr; the converged ones go
-// on to the density pass
+// on to the density pass -- except the CERTIFIED ones, list[0 .. *n_certified): witnesses (they head phase 1's list) and every
+// phase-2 sample lie outside the posed fat body, their density is +0 by the certificate that let their ray's other samples go
+// unevaluated, and only their convergence is asked for (the ray's mask, the delta chain and the (1 - alpha + 1e-7) factors of
+// a promoted ray): sigma = +0 is written, the SDF is not evaluated (29 % of the density pass's samples on the benchmark).
 __global__ __launch_bounds__(256) void k_tier_finalize(FrameDev fr, const int* __restrict__ list, const int* count,
-                                                        const float* __restrict__ err_best, float* __restrict__ pts,
-                                                        uint8_t* __restrict__ mask, int* __restrict__ dens_list, int* dens_count) {
+                                                        const int* n_certified, const float* __restrict__ err_best,
+                                                        float* __restrict__ pts, uint8_t* __restrict__ mask,
+                                                        f32x4* __restrict__ shaded, int* __restrict__ dens_list, int* dens_count) {
     const int n = *count;
     if ((int)(blockIdx.x * blockDim.x) >= n) return;
+    const int n_cert = *n_certified;
     const BodyConst bc = load_bc(fr);
     for (int i0 = blockIdx.x * blockDim.x; i0 < n; i0 += gridDim.x * blockDim.x) {
         const int i = i0 + threadIdx.x;
@@ -500,6 +505,10 @@ __global__ __launch_bounds__(256) void k_tier_finalize(FrameDev fr, const int* _
             pts[(size_t)q * 3 + 2] = xn.z;
             ok = err_best[q] < kRootThresh;
             mask[q] = ok ? 1 : 0;
+            if (i < n_cert) {
+                if (ok) shaded[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ok = false;
+            }
         }
         append_ids(ok, q, dens_list, dens_count);
     }

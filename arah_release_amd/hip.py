@@ -280,16 +280,17 @@ class Workspace:
                                                   _ptr(tier), _ptr(pos), _stream(self.device)), "arah_tier_debug")
         return tier, pos
 
-    def debug_samples(self, n_rays, n_steps):
-        """Per-sample arrays of the last arah_render on this scratch: dict of z, pts, T, mask, shaded, state tensors."""
+    def debug_samples(self, n_rays, n_steps, which=("z", "pts", "T", "mask", "shaded", "state")):
+        """Per-sample arrays of the last arah_render on this scratch: dict of the tensors named in `which`."""
         d, Q = self.device, n_rays * n_steps
-        out = {"z": torch.empty(Q, device=d), "pts": torch.empty(Q, 3, device=d), "T": torch.empty(Q, 16, device=d),
-               "mask": torch.empty(Q, dtype=torch.uint8, device=d), "shaded": torch.empty(Q, 4, device=d),
-               "state": torch.empty(Q, dtype=torch.uint8, device=d)}
+        make = {"z": lambda: torch.empty(Q, device=d), "pts": lambda: torch.empty(Q, 3, device=d), "T": lambda: torch.empty(Q, 16, device=d),
+                "mask": lambda: torch.empty(Q, dtype=torch.uint8, device=d), "shaded": lambda: torch.empty(Q, 4, device=d),
+                "state": lambda: torch.empty(Q, dtype=torch.uint8, device=d)}
+        out = {k: make[k]() for k in which}
         with torch.cuda.device(d):
             _check(load_library().arah_debug_samples(_ptr(self.buf), C.c_size_t(self.buf.numel()), C.c_int32(n_rays), C.c_int32(n_steps),
-                                                     _ptr(out["z"]), _ptr(out["pts"]), _ptr(out["T"]), _ptr(out["mask"]),
-                                                     _ptr(out["shaded"]), _ptr(out["state"]), _stream(d)), "arah_debug_samples")
+                                                     _ptr(out.get("z")), _ptr(out.get("pts")), _ptr(out.get("T")), _ptr(out.get("mask")),
+                                                     _ptr(out.get("shaded")), _ptr(out.get("state")), _stream(d)), "arah_debug_samples")
         return out
 
     def ensure(self, n_rays, n_steps):

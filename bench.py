@@ -744,9 +744,10 @@ def run(args, rt):
         canon_avg_ms = canon_total_ms / (n_frames_ev * canon_launches)
         canon_evals = counters["n_canon"] / (n_frames_ev * canon_launches)
         canon_achieved = counters["n_canon"] * F_SKIN / (canon_total_ms * 1e-3) / 1e12
-        # second largest: k_density = the SDF MLP forward on every valid sample
-        n_launch = max(len(dens_ms), 1) * canon_launches
-        dens_total_ms = sum(dens_ms) + sum(b for _, b in p2)
+        # second largest: k_density = the SDF MLP forward on every valid sample that is not certified sigma = +0 (one launch
+        # per frame: phase 2's samples and the witnesses lie outside the posed fat body)
+        n_launch = max(len(dens_ms), 1)
+        dens_total_ms = sum(dens_ms)
         dens_samples = counters["n_density"] / n_launch           # == number of valid (converged) samples that were evaluated
         dens_avg_ms = dens_total_ms / n_launch
         achieved = counters["n_density"] * F_SDF / (dens_total_ms * 1e-3) / 1e12

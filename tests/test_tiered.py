@@ -36,9 +36,11 @@ def _both_ways(model, inputs, n_steps):
                 out = model(dict(inputs), eval=True)
                 ws = idhr.ray_tracer.workspace(dev)
                 tier, pos = ws.tier_debug(n, n_steps)
+                smp = ws.debug_samples(n, n_steps, which=("mask", "shaded"))
                 torch.cuda.synchronize()
                 res[name] = {"out": {k: v.clone() for k, v in out.items() if torch.is_tensor(v)}, "tier": tier.clone(),
-                             "pos": pos.clone(), "ctr": ws.counters(), "occ": ws.occupancy_info() if on else None}
+                             "pos": pos.clone(), "ctr": ws.counters(), "occ": ws.occupancy_info() if on else None,
+                             "mask": smp["mask"].clone(), "sigma": smp["shaded"][:, 3].clone()}
     finally:
         idhr.tiering, idhr.adaptive_shading = keep
     return res
@@ -51,11 +53,18 @@ def _assert_same(res, label):
             label, key, int((e["out"][key] != t["out"][key]).reshape(e["out"][key].shape[1], -1).any(-1).sum()))
     violations = int(((e["pos"] == 1) & (t["tier"] == 0)).sum())
     assert violations == 0, "%s: %d rays with density > 0 in the exact path were certified zero" % (label, violations)
+    # sample level: whatever the tiers evaluated is valid or not exactly as in the exact path, and carries the exact path's
+    # density bit for bit -- in particular the samples whose density the tiers only CERTIFY as +0 (witnesses, phase 2)
+    ev = t["mask"] == 1
+    assert bool((e["mask"][ev] == 1).all()), label
+    assert torch.equal(e["sigma"][ev], t["sigma"][ev]), "%s: %d evaluated samples differ in density" % (
+        label, int((e["sigma"][ev] != t["sigma"][ev]).sum()))
     c = t["ctr"]
     assert c["n_tier_rays"] == e["pos"].numel()
     assert c["n_tier_rays_surface"] + c["n_tier_rays_promoted"] + c["n_tier_rays_skipped"] == c["n_tier_rays"]
     # the tiers evaluate a subset of the exact path's samples and shade exactly the same ones
     assert c["n_col"] == e["ctr"]["n_col"] and c["n_density"] <= e["ctr"]["n_density"] and c["n_canon"] <= e["ctr"]["n_canon"]
+    assert c["n_density_p2"] == 0   # phase 2's samples are certified: convergence only
     return c
 
 
