@@ -217,6 +217,11 @@ def _mc_poll(st, wait=False):
             n = int(host[0])
             st["last_count"] = n
             st["free"].append((ev, host))
+            if n <= cap and not st["overflowed"]:
+                # every frame pushes the whole buffer through un-normalisation, skinning, projection and three rasterisations:
+                # size it for the level set this subject actually has (twice the last count, a power of two, never above the
+                # default; one overflow pins the raised capacity for good)
+                st["cap"] = min(MC_DEFAULT_CAP, max(1 << 16, 1 << int(math.ceil(math.log2(2.0 * max(n, 1))))))
             if n > cap:
                 st["overflowed"] += 1
                 st["cap"] = max(st["cap"], 1 << int(math.ceil(math.log2(1.5 * n))))

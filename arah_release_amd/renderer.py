@@ -42,14 +42,32 @@ def _emitted_sdf_layers(sdf_network):
     return layers, torch.cat(freqs), torch.cat(phases)
 
 
+# Inference caches live OUTSIDE the modules (weakly keyed by them): a torch.cuda.Event or a CUDAGraph in a module's __dict__ made
+# copy.deepcopy / pickle / torch.save(model) of a model that had rendered a frame raise.
+import weakref
+_FOLDED = weakref.WeakKeyDictionary()          # weight-normed MLP -> (key, folded layers, event, device, stream)
+_GRAPHED = weakref.WeakKeyDictionary()         # MetaAvatarRender -> {"eval": _GraphedDecoder, "train": _TrainGraphedDecoder}
+
+
+def invalidate_caches(module):
+    """Forget the folded weights / captured hypernetworks of `module` and everything below it.  The caches notice a parameter
+    that was re-allocated or written in place through autograd's version counter, NOT a write through `p.data` (a broadcast
+    into `p.data`, an EMA update, manual surgery): callers that write that way call this (train.broadcast_state does; a
+    load_state_dict post-hook of MetaAvatarRender does)."""
+    for m in module.modules():
+        _FOLDED.pop(m, None)
+        _GRAPHED.pop(m, None)
+
+
 def _mlp_layers(module):
     """Row-major (W, b) of a weight-normed MLP, W = g v / |v| folded.  Without gradients (inference) the folded weights are
-    kept on the module until a parameter changes (data pointer or in-place version): a test sequence folds the skinning and
-    colour networks once instead of eleven launches per frame.  An event orders other streams behind the fold."""
+    kept (weakly keyed by the module) until a parameter changes (data pointer or in-place version; see invalidate_caches for
+    writes through .data): a test sequence folds the skinning and colour networks once instead of eleven launches per frame.
+    An event orders other streams behind the fold."""
     cache = not torch.is_grad_enabled()
     if cache:
         key = tuple((p.data_ptr(), p._version) for p in module.parameters())
-        hit = module.__dict__.get("_arah_folded")
+        hit = _FOLDED.get(module)
         if hit is not None and hit[0] == key:
             if hit[2] is not None and torch.cuda.current_stream(hit[3]).cuda_stream != hit[4]:
                 torch.cuda.current_stream(hit[3]).wait_event(hit[2])
@@ -66,7 +84,7 @@ def _mlp_layers(module):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(dev))
             sid = torch.cuda.current_stream(dev).cuda_stream
-        module.__dict__["_arah_folded"] = (key, out, ev, dev, sid)
+        _FOLDED[module] = (key, out, ev, dev, sid)
     return out
 
 
@@ -529,6 +547,12 @@ class IDHRNetwork(nn.Module):
                             precision=self._precision if self._precision is not None else self.precision,
                             body_tables=input.get("_body_tables"))
         self.last_frame = frame   # the gen_cano_mesh branch of the model entry meshes the same emitted network
+        var = getattr(self.deviation_network, "variance", None)
+        if var is not None:   # the measured shares (sigma > 0 samples, samples the tiers skip) belong to ONE beta
+            vkey = (var.data_ptr(), var._version)
+            if getattr(self, "_beta_key", vkey) != vkey:
+                self._shade_full, self.shade_ratio, self._tier_off, self.tier_share = False, None, False, None
+            self._beta_key = vkey
         full = self.ray_tracer.full_shading
         if not full and self.adaptive_shading and self._shade_full and guard is not None and self.guard_mode != "strict":
             self._shade_since_probe += 1
@@ -593,6 +617,7 @@ class MetaAvatarRender(nn.Module):
         self.idhr_network = IDHRNetwork(deviation_decoder, color_decoder, skinning_model, ray_tracer,
                                         cano_view_dirs=cano_view_dirs, train_skinning_net=train_skinning_net,
                                         render_last_pt=render_last_pt, low_vram=low_vram)
+        self.register_load_state_dict_post_hook(lambda module, incompatible: invalidate_caches(module))
         self.train_cameras = train_cameras
         if train_cameras:   # models/__init__.py:81-89: per-camera extrinsics (XYZW quaternion + translation) become parameters
             cam_trans, cam_rots = kwargs.get("cam_trans"), kwargs.get("cam_rots")
@@ -680,9 +705,9 @@ class MetaAvatarRender(nn.Module):
                                          % self.nv_noise_type)
         if (eval and dev.type == "cuda" and not torch.is_grad_enabled() and "rots_noise" not in decoder_input
                 and "latent" in decoder_input and os.environ.get("ARAH_HYPERNET_GRAPH", "1") != "0"):
-            graphed = self.__dict__.get("_graphed_decoder")
+            graphed = _GRAPHED.setdefault(self, {}).get("eval")
             if graphed is None or graphed.decoder is not self.sdf_decoder:
-                graphed = self.__dict__["_graphed_decoder"] = _GraphedDecoder(self.sdf_decoder)
+                graphed = _GRAPHED[self]["eval"] = _GraphedDecoder(self.sdf_decoder)
             try:
                 out = graphed(decoder_input) if not graphed.broken else self.sdf_decoder(decoder_input)
             except RuntimeError as err:   # a capture the runtime refuses: the same launches, eagerly, from here on
@@ -693,9 +718,9 @@ class MetaAvatarRender(nn.Module):
         elif (not eval and dev.type == "cuda" and torch.is_grad_enabled() and "latent" in decoder_input
               and not rots.requires_grad and not Jtrs.requires_grad and decoder_input["latent"].requires_grad
               and os.environ.get("ARAH_TRAIN_HYPERNET_GRAPH", "0") == "1"):
-            tg = self.__dict__.get("_train_graphed_decoder")
+            tg = _GRAPHED.setdefault(self, {}).get("train")
             if tg is None or tg.decoder is not self.sdf_decoder:
-                tg = self.__dict__["_train_graphed_decoder"] = _TrainGraphedDecoder(self.sdf_decoder)
+                tg = _GRAPHED[self]["train"] = _TrainGraphedDecoder(self.sdf_decoder)
             try:
                 out = tg(decoder_input) if not tg.broken else self.sdf_decoder(decoder_input)
             except RuntimeError as err:   # a capture the runtime refuses: the eager call from here on

@@ -54,6 +54,12 @@ def render(lm, dataset, device, rank=0, world=1):
     for c in range(0, len(mine), 20):   # twenty frames resident at a time, renderer.frames_in_flight of them in flight
         items = [dataset.item(i, device) for i in mine[c:c + 20]]
         outs += renderer.map_in_flight(lm.test_step, items, owner=lm.model)
+    # the triangle counts of the last frames' meshes are still on their way to the host: drain them, so that a level set that
+    # outgrew the device buffer in the sequence's LAST frames is reported too (meshing._mc_poll only runs from a later call)
+    from . import meshing
+    _, truncated = meshing.mesh_counts(device, wait=True)
+    if truncated:
+        print("rank %d: %d canonical meshes of this sequence were truncated (see the warnings above)" % (rank, truncated))
     return lm.test_epoch_end(outs, first_index=rank, index_stride=world, clear=(world == 1))
 
 

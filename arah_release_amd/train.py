@@ -183,6 +183,8 @@ def broadcast_state(module, world, dist):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, 0)
+    from .renderer import invalidate_caches
+    invalidate_caches(module)   # the broadcast wrote through .data: version counters did not move
 
 
 def save_checkpoint(path, lm, opt, epoch, global_step):
@@ -248,8 +250,9 @@ def main(argv=None, body=None, faces=None, log=print):
     # From here on the global generators drive per-step draws only (eikonal probe points, stratified jitter, pose / view input
     # noise): every rank and every resumed run gets its own stream, like the unseeded ranks of the reference.  (The common seed
     # above only made construction repeatable; broadcast_state has made it redundant.)
-    torch.manual_seed(4321 + rank + 1000 * (ckpt_epoch or 0))
-    np.random.seed((4321 + rank + 1000 * (ckpt_epoch or 0)) % (2 ** 32))
+    # (+ 7919 * step: a run stopped mid-epoch resumes in the same epoch at a later step and must not replay the epoch's draws)
+    torch.manual_seed(4321 + rank + 1000 * (ckpt_epoch or 0) + 7919 * step)
+    np.random.seed((4321 + rank + 1000 * (ckpt_epoch or 0) + 7919 * step) % (2 ** 32))
     max_epochs = epochs_to_run(t_cfg["max_epochs"], args.epochs_per_run, ckpt_epoch)
     every = t_cfg.get("checkpoint_every_n_epochs", 1)
     params = [p for p in lm.model.parameters() if p.requires_grad]

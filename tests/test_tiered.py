@@ -168,3 +168,27 @@ def test_tiers_batch_of_two_views_and_empty_rays(scene):
     idhr.tiering, idhr.adaptive_shading = True, True
     for key in ("rgb_values", "network_body_mask", "points_cam"):
         assert torch.equal(outs[False][key], outs[True][key]), key
+
+
+@gpu
+def test_a_model_that_has_rendered_can_be_copied_and_pickled(scene):
+    """The inference caches (folded weight-norm layers with their event, the captured hypernetwork graph) are keyed weakly by
+    the modules, not stored in them: copy.deepcopy / pickle of a model that has rendered a frame work, and the copy renders the
+    same image.  A write through .data is invisible to the caches' version keys: renderer.invalidate_caches drops them."""
+    import copy
+    import pickle
+    from arah_release_amd import config, renderer
+    dev = torch.device("cuda:0")
+    model, _ = config.build_synthetic_model("zju377_mono", 64, 16, 16, device=dev)
+    inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
+    with torch.no_grad():
+        a = model(dict(inputs), eval=True)["rgb_values"].clone()
+        twin = copy.deepcopy(model)
+        pickle.loads(pickle.dumps(model.skinning_model))
+        b = twin(dict(inputs), eval=True)["rgb_values"]
+        assert torch.equal(a, b)
+        lin = model.color_decoder.lin5
+        lin.weight_g.data.mul_(0.5)                     # a write the version counter does not see ...
+        renderer.invalidate_caches(model)               # ... announced
+        c = model(dict(inputs), eval=True)["rgb_values"]
+        assert not torch.equal(a, c)
