@@ -151,6 +151,78 @@ def live_traffic(args, kernels, limit_s=150.0):
                  "--passes default) spawned by this run on this box; FETCH_SIZE x 2 (gfx950), KiB -> bytes")
 
 
+def _cpu_worker_init(cfg_name, n_steps, near, far, threads):
+    # one process of the multi-process CPU baseline: its own model, its own thread pool
+    global _CPU_WORKER
+    torch.set_num_threads(threads)
+    from arah_release_amd import config, synthetic
+    model, cfg = config.build_synthetic_model(cfg_name, n_steps, near, far, device="cpu")
+    _CPU_WORKER = (model, cfg, synthetic.SyntheticScene(0), n_steps, near, far)
+
+
+def _slice_rays(inputs, lo, hi):
+    n = inputs["ray_dirs"].shape[1]
+    out = {}
+    for k, v in inputs.items():
+        if torch.is_tensor(v) and v.dim() >= 2 and v.shape[1] == n and k not in ("smpl_verts", "skinning_weights", "minimal_shape"):
+            out[k] = v[:, lo:hi].contiguous()
+        else:
+            out[k] = v
+    return out
+
+
+def _cpu_worker_render(job):
+    size, sample_rays, lo, hi = job
+    from oracle import arah_oracle as O
+    model, cfg, scene, n_steps, near, far = _CPU_WORKER
+    inputs = _slice_rays(scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays), lo, hi)
+    t0 = time.perf_counter()
+    ref = O.render_inputs(model, inputs, cfg["model"]["cano_view_dirs"], n_steps, near, far)
+    return (lo, hi, ref["rgb_values"].numpy(), ref["network_body_mask"].numpy(), dict(ref["frame"].counters), time.perf_counter() - t0)
+
+
+def cpu_baseline_multiprocess(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu, dev, threads_per_worker=8):
+    """The oracle on ALL host cores: the oracle is a Python loop around torch operators on shrinking active sets and does not
+    scale past a handful of threads (round 5: 208 rays/s on 128 threads against the reference's own 348 rays/s on 8), but rays are
+    independent -- cores / 8 worker processes of 8 threads each render disjoint slices of the same evenly subsampled rays of
+    frame 0.  Timed: the pool's map over the slices, after every worker has built its model and rendered a warm-up slice."""
+    import multiprocessing as mp
+    import numpy as np
+    cores = os.cpu_count() or 8
+    workers = max(1, min(32, cores // threads_per_worker))
+    n = int(scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays)["ray_dirs"].shape[1])
+    per = (n + workers - 1) // workers
+    jobs = [(size, sample_rays, lo, min(n, lo + per)) for lo in range(0, n, per)]
+    ctx = mp.get_context("spawn")
+    with ctx.Pool(workers, initializer=_cpu_worker_init, initargs=(cfg_name, n_steps, near, far, threads_per_worker)) as pool:
+        pool.map(_cpu_worker_render, [(size, sample_rays, 0, 64)] * workers)          # warm-up: every worker is up
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_worker_render, jobs)
+        dt = time.perf_counter() - t0
+    rgb_ref = np.zeros((n, 3), np.float64)
+    mask_ref = np.zeros(n, bool)
+    work = {}
+    for lo, hi, rgb, mask, ctr, _ in parts:
+        rgb_ref[lo:hi], mask_ref[lo:hi] = rgb, mask
+        for k, v in ctr.items():
+            work[k] = work.get(k, 0) + v
+    out = {"value": n / dt, "unit": "rays/s", "cores": workers * threads_per_worker, "kind": "port",
+           "sample": "%d rays evenly subsampled from frame 0 of the %dx%dx%d workload, oracle/arah_oracle.py (torch CPU fp32, cKDTree "
+                     "1-NN) in %d processes x %d threads on disjoint ray slices, %.1f s (slowest slice %.1f s)"
+                     % (n, size, size, n_steps, workers, threads_per_worker, dt, max(p[5] for p in parts)),
+           "work": {"per_ray": {k: v / max(n, 1) for k, v in work.items()}}}
+    if model_gpu is not None:
+        with torch.no_grad():
+            got = model_gpu(scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays, device=dev), eval=True)
+        rgb = got["rgb_values"][0].double().cpu().numpy()
+        mask = got["network_body_mask"][0].cpu().numpy()
+        mse = float(np.mean((rgb - rgb_ref) ** 2))
+        out["psnr_vs_oracle_db"] = None if mse == 0 else -10.0 * float(np.log10(mse))
+        out["mask_agreement"] = float((mask == mask_ref).mean())
+        out["parity_sample"] = "HIP render of the same %d rays vs the oracle's image" % n
+    return out
+
+
 def cpu_baseline(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu=None, dev=None):
     """Oracle on `sample_rays` rays spread evenly over frame 0 of the benchmark workload, timed on the host cores;
     the same rays are rendered by the HIP path and compared (BASELINE.json's "+ PSNR vs ref": the oracle is the
@@ -489,6 +561,12 @@ class GpuRuntime:
                                   self.model, self.dev)
 
     def cpu_baseline(self, args, near, far):
+        if (os.cpu_count() or 1) >= 16 and os.environ.get("ARAH_CPU_BASELINE_PROCESSES", "1") != "0":
+            try:   # all host cores: processes x threads (a Python-loop oracle does not scale with threads alone)
+                return cpu_baseline_multiprocess(self.scene, args.config, args.size, args.n_steps, near, far,
+                                                 max(args.cpu_sample_rays, 32768), self.model, self.dev)
+            except Exception as e:   # a box that cannot spawn: the single-process figure
+                sys.stderr.write("multi-process CPU baseline failed (%s: %s); single process\n" % (type(e).__name__, e))
         return cpu_baseline(self.scene, args.config, args.size, args.n_steps, near, far, args.cpu_sample_rays,
                             model_gpu=self.model, dev=self.dev)
 
