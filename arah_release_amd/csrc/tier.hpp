@@ -440,6 +440,16 @@ __global__ __launch_bounds__(kTierWaves * 64) void k_tier_classify(int n, int S,
                     const int ws = (int)(best & 0xffffu);
                     if ((ws & 63) == lane) st[ws >> 6] = TS_WITNESS;
                     witness = true;
+                    // ... and two more, a quarter of the ray in from either end.  Whether Broyden's iteration converges is
+                    // mostly a property of the REGION (far from the body the skinning field is unlike the nearest vertex's
+                    // weights), so a second witness next to a failed one fails too, one elsewhere on the ray often does not:
+                    // with the nearest sample alone 2.6-23 % of these rays had to be promoted (63 slow samples each, 25-75
+                    // skinning evaluations per ray of the frame), with three witnesses 0.8-18 % (oracle study, profiles/
+                    // r06_tier_design_study.txt: 18-49 evaluations per ray including the extra witnesses)
+                    for (int it = 0; it < 2; ++it) {
+                        const int sidx = lane + it * 64;
+                        if (st[it] == TS_PENDING && (sidx == S / 4 || sidx == (3 * S) / 4)) st[it] = TS_WITNESS;
+                    }
                 }
             }
         } else {
