@@ -156,6 +156,8 @@ def _cpu_worker_init(cfg_name, n_steps, near, far, threads):
     global _CPU_WORKER
     torch.set_num_threads(threads)
     from arah_release_amd import config, synthetic
+    from oracle import arah_oracle as O
+    O.KDTREE_WORKERS = threads          # the 1-NN search's own pool: this process's share of the cores, not all of them
     model, cfg = config.build_synthetic_model(cfg_name, n_steps, near, far, device="cpu")
     _CPU_WORKER = (model, cfg, synthetic.SyntheticScene(0), n_steps, near, far)
 

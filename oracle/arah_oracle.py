@@ -24,6 +24,7 @@ from typing import List, Optional, Tuple
 import numpy as np
 import torch
 
+KDTREE_WORKERS = -1      # threads of the exact 1-NN search (-1: all cores; bench.py's worker processes set their own share)
 ROOT_THRESH = 1e-5       # RT:18, models/__init__.py:75
 SPHERE_ITERS = 50        # RT:19
 SURFACE_RANGE = 0.05     # RT:23
@@ -222,7 +223,7 @@ def nearest_vertex(fr, pts):
     if not hasattr(fr, "_kdtree"):
         from scipy.spatial import cKDTree
         fr._kdtree = cKDTree(fr.verts.double().numpy())
-    _, idx = fr._kdtree.query(pts.double().numpy(), k=1, workers=-1)
+    _, idx = fr._kdtree.query(pts.double().numpy(), k=1, workers=KDTREE_WORKERS)
     return torch.from_numpy(np.ascontiguousarray(idx)).long()
 
 
