@@ -183,15 +183,19 @@ def _cpu_worker_render(job):
     return (lo, hi, ref["rgb_values"].numpy(), ref["network_body_mask"].numpy(), dict(ref["frame"].counters), time.perf_counter() - t0)
 
 
-def cpu_baseline_multiprocess(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu, dev, threads_per_worker=8):
+def cpu_baseline_multiprocess(scene, cfg_name, size, n_steps, near, far, sample_rays, model_gpu, dev, threads_per_worker=4):
     """The oracle on ALL host cores: the oracle is a Python loop around torch operators on shrinking active sets and does not
     scale past a handful of threads (round 5: 208 rays/s on 128 threads against the reference's own 348 rays/s on 8), but rays are
-    independent -- cores / 8 worker processes of 8 threads each render disjoint slices of the same evenly subsampled rays of
-    frame 0.  Timed: the pool's map over the slices, after every worker has built its model and rendered a warm-up slice."""
+    independent -- worker processes render disjoint slices of the same evenly subsampled rays of frame 0.  The split was
+    measured on the MI355X box's host (256 logical cores, 16 384 rays, idle OpenMP threads sleeping): 16 x 8 threads 2 226 rays/s,
+    32 x 4 2 661, 64 x 2 1 990, 128 x 1 1 122, 64 x 4 1 709 (and 32 x 8 with spinning OpenMP threads: 912) -- min(32, cores / 8)
+    processes of 4 threads.  Timed: the pool's map over the slices, after every worker has built its model and rendered a
+    warm-up slice."""
     import multiprocessing as mp
     import numpy as np
     cores = os.cpu_count() or 8
-    workers = max(1, min(32, cores // threads_per_worker))
+    workers = int(os.environ.get("ARAH_CPU_BASELINE_WORKERS", "0")) or max(1, min(32, cores // 8))
+    os.environ.setdefault("OMP_WAIT_POLICY", "passive")   # inherited by the workers: idle OpenMP threads sleep instead of spinning
     n = int(scene.make_inputs(size, size, frame_idx=0, max_rays=sample_rays)["ray_dirs"].shape[1])
     per = (n + workers - 1) // workers
     jobs = [(size, sample_rays, lo, min(n, lo + per)) for lo in range(0, n, per)]
