@@ -4553,6 +4553,60 @@ int arah_prepare_occupancy(const ArahFrame* f, void* occ_buf, size_t occ_bytes, 
     return check_launch();
 }
 
+struct BandScratch {
+    int* count;       // points evaluated exactly (first word of the buffer)
+    float *cpts, *csdf;
+    uint8_t *flag, *flag2;
+    size_t bytes;
+};
+static BandScratch carve_band(void* base) {
+    constexpr int nc3 = kBandNc * kBandNc * kBandNc, m3 = (kBandNc - 1) * (kBandNc - 1) * (kBandNc - 1);
+    BandScratch b;
+    Carver c{reinterpret_cast<char*>(base), 0};
+    b.count = c.take<int>(1);
+    b.cpts = c.take<float>((size_t)nc3 * 3);
+    b.csdf = c.take<float>(nc3);
+    b.flag = c.take<uint8_t>(m3);
+    b.flag2 = c.take<uint8_t>(m3);
+    b.bytes = align_up(c.off, 256);
+    return b;
+}
+size_t arah_sdf_grid_band_scratch_bytes(void) { return carve_band(nullptr).bytes; }
+
+// The lattice of arah_sdf_grid for marching cubes at level 0: exact values wherever the level set can pass (and one coarse cell
+// around), the right sign elsewhere (tier.hpp).  list: [n_side^3] ints of scratch; scratch: arah_sdf_grid_band_scratch_bytes().
+// The number of evaluated points stays on the device (first word of `scratch`); n_side >= 33.
+int arah_sdf_grid_band(const ArahFrame* f, int32_t n_side, float* sdf, int32_t* list, void* scratch, size_t scratch_bytes,
+                       void* workspace, size_t wbytes, void* stream) {
+    if (!f || !sdf || !list || !scratch || !workspace || n_side < kBandNc || n_side > 1024) return ARAH_E_BADARG;
+    if (scratch_bytes < arah_sdf_grid_band_scratch_bytes()) return ARAH_E_WORKSPACE;
+    Workspace w = carve(workspace, 1, 1);
+    if (wbytes < w.bytes) return ARAH_E_WORKSPACE;
+    if (int arc = setup_attributes()) return arc;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const FrameDev fd = to_dev(*f);
+    const long long n = (long long)n_side * n_side * n_side;
+    if (n > 0x7fffffffLL) return ARAH_E_BADARG;
+    constexpr int nc3 = kBandNc * kBandNc * kBandNc, m3 = (kBandNc - 1) * (kBandNc - 1) * (kBandNc - 1);
+    const BandScratch b = carve_band(scratch);
+    float *cpts = b.cpts, *csdf = b.csdf;
+    uint8_t *flag = b.flag, *flag2 = b.flag2;
+    int* count = b.count;
+    hipMemsetAsync(count, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_occ_lattice_pts, dim3((nc3 + 255) / 256), dim3(256), 0, s, kBandNc, 1.0f, cpts);
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(nc3, kTile)), dim3(kThreads),
+                  kLdsSdfFwd, s, fd, (const float*)cpts, (const int*)nullptr, (const int*)nullptr, nc3, csdf, (float*)nullptr,
+                  (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(k_band_cells, dim3((m3 + 255) / 256), dim3(256), 0, s, (const float*)csdf, flag);
+    hipLaunchKernelGGL(k_band_dilate, dim3((m3 + 255) / 256), dim3(256), 0, s, (const uint8_t*)flag, flag2);
+    hipLaunchKernelGGL(k_band_fill, dim3((int)((n + 1023) / 1024)), dim3(1024), 0, s, (int)n_side, (const float*)csdf,
+                       (const uint8_t*)flag2, sdf, list, count);
+    LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(n, kTile)), dim3(kThreads),
+                  kLdsSdfFwd, s, fd, (const float*)nullptr, (const int*)list, (const int*)count, 0, sdf, (float*)nullptr,
+                  (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, (int)n_side);
+    return check_launch();
+}
+
 // tests / bench: the tier of every ray of the workspace's last arah_render (0 certified zero, 1 surface ray, 2 promoted;
 // written by the tiered path only) and whether any valid sample of it carries density > 0 (either path, lazy shading)
 int arah_tier_debug(void* workspace, size_t wbytes, int32_t n_rays, int32_t n_steps, uint8_t* ray_tier, uint8_t* ray_sigma_pos,

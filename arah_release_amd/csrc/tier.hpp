@@ -613,3 +613,99 @@ __global__ void k_tier_ray_sigma(int n, int S, const uint8_t* __restrict__ mask,
     }
     out[i] = pos ? 1 : 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The canonical-mesh branch's lattice, evaluated only where the level set can be (arah_sdf_grid_band)
+// ---------------------------------------------------------------------------------------------------------------------
+// utils/sdf_meshing.py:44-57 evaluates the SDF at all N^3 = 16.8 M lattice points of [-1,1]^3 and hands the volume to marching
+// cubes (:95), which only LOOKS at the values of cells whose corners change sign.  The same Lipschitz test that refines the
+// occupancy's lattice says where that can happen: a coarse cell (1/32 of the box, 6.6 cm) may hold a zero of the SDF only if
+// min(corners) - Lc * half_diagonal <= 0 <= max(corners) + Lc * half_diagonal, Lc = max(kOccLipMin, kOccLipSlack x its steepest
+// edge slope).  Lattice points in such cells AND in their 26 neighbours (so that every corner of a lattice cell with a sign
+// change is one of them) are evaluated exactly; every other point gets the value of its coarse cell's first corner -- the right
+// SIGN, which is all marching cubes asks of a cell without a sign change.  The triangle soup is the full lattice's, triangle
+// for triangle and bit for bit (tests/test_meshing.py), at ~6 % of the evaluations.
+constexpr int kBandNc = 33;   // coarse lattice points per axis over [-1, 1]
+
+__global__ void k_band_cells(const float* __restrict__ csdf, uint8_t* __restrict__ flag) {
+    constexpr int nc = kBandNc, m = nc - 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m * m * m) return;
+    const int cz = c % m, cy = (c / m) % m, cx = c / (m * m);
+    float v[2][2][2], mn = 3.4e38f, mx = -3.4e38f;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+            for (int k = 0; k < 2; ++k) {
+                v[i][j][k] = csdf[((size_t)(cx + i) * nc + (cy + j)) * nc + (cz + k)];
+                mn = fminf(mn, v[i][j][k]);
+                mx = fmaxf(mx, v[i][j][k]);
+            }
+    const float step = 2.0f / (float)m;
+    float sl = 0.f;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) {
+            sl = fmaxf(sl, fabsf(v[1][a][b] - v[0][a][b]));
+            sl = fmaxf(sl, fabsf(v[a][1][b] - v[a][0][b]));
+            sl = fmaxf(sl, fabsf(v[a][b][1] - v[a][b][0]));
+        }
+    const float reach = fmaxf(kOccLipMin, kOccLipSlack * sl / step) * step * 0.8660254f;
+    flag[c] = (!(mn - reach > 0.f) && !(mx + reach < 0.f)) ? 1 : 0;   // (NaN corners flag the cell)
+}
+
+__global__ void k_band_dilate(const uint8_t* __restrict__ flag, uint8_t* __restrict__ out) {
+    constexpr int m = kBandNc - 1;
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= m * m * m) return;
+    const int cz = c % m, cy = (c / m) % m, cx = c / (m * m);
+    uint8_t f = 0;
+    for (int dx = -1; dx <= 1; ++dx)
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dz = -1; dz <= 1; ++dz) {
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x >= 0 && y >= 0 && z >= 0 && x < m && y < m && z < m) f |= flag[((size_t)x * m + y) * m + z];
+            }
+    out[c] = f;
+}
+
+// every lattice point: in the band -> on the list (evaluated next); else the value of its coarse cell's first corner
+__global__ __launch_bounds__(1024) void k_band_fill(int N, const float* __restrict__ csdf, const uint8_t* __restrict__ flag2,
+                                                    float* __restrict__ sdf, int* __restrict__ list, int* count) {
+    constexpr int nc = kBandNc, m = nc - 1;
+    __shared__ int wave_cnt[16];
+    __shared__ int block_base;
+    const long long n = (long long)N * N * N;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool band = false;
+    if (id < n) {
+        const int iz = (int)(id % N), iy = (int)((id / N) % N), ix = (int)(id / ((long long)N * N));
+        // the coarse cells whose CLOSED box holds the point: floor(i m / (N - 1)), and the one below when the point sits on a face
+        int c0[3], c1[3];
+        const int idx[3] = {ix, iy, iz};
+        for (int a = 0; a < 3; ++a) {
+            const long long t = (long long)idx[a] * m;
+            int c = (int)(t / (N - 1));
+            const bool on_face = t % (N - 1) == 0;
+            c1[a] = min(c, m - 1);
+            c0[a] = on_face ? max(c - 1, 0) : c1[a];
+        }
+        for (int x = c0[0]; x <= c1[0]; ++x)
+            for (int y = c0[1]; y <= c1[1]; ++y)
+                for (int z = c0[2]; z <= c1[2]; ++z) band = band || flag2[((size_t)x * m + y) * m + z] != 0;
+        if (!band) sdf[id] = csdf[((size_t)c1[0] * nc + c1[1]) * nc + c1[2]];
+    }
+    const unsigned long long mk = __ballot(band);
+    if (lane == 0) wave_cnt[wave] = __popcll(mk);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < 16; ++k) {
+            const int c = wave_cnt[k];
+            wave_cnt[k] = tot;
+            tot += c;
+        }
+        block_base = tot ? atomicAdd(count, tot) : 0;
+    }
+    __syncthreads();
+    if (band) list[block_base + wave_cnt[wave] + __popcll(mk & ((1ull << lane) - 1ull))] = (int)id;
+}

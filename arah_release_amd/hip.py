@@ -117,7 +117,8 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
            "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
            "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes",
-           "arah_occupancy_bytes", "arah_prepare_occupancy", "arah_occupancy_info", "arah_tier_debug", "arah_debug_samples"]
+           "arah_occupancy_bytes", "arah_prepare_occupancy", "arah_occupancy_info", "arah_tier_debug", "arah_debug_samples",
+           "arah_sdf_grid_band_scratch_bytes", "arah_sdf_grid_band"]
 
 _lib = None
 
@@ -141,6 +142,7 @@ def load_library():
     lib.arah_marching_cubes_scratch_bytes.restype = C.c_size_t
     lib.arah_marching_cubes_scratch_bytes.argtypes = [C.c_int32]
     lib.arah_occupancy_bytes.restype = C.c_size_t
+    lib.arah_sdf_grid_band_scratch_bytes.restype = C.c_size_t
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the symbol is missing
     _lib = lib
@@ -501,6 +503,31 @@ def sdf_grid(frame, ws, n_side=256):
     _check(lib.arah_sdf_grid(C.byref(frame.handle), C.c_int32(int(n_side)), _ptr(out), _ptr(buf), C.c_size_t(buf.numel()),
                              _stream()), "arah_sdf_grid")
     return out
+
+
+_band_scratch = {}
+
+
+@_guarded
+def sdf_grid_band(frame, ws, n_side=256):
+    """The lattice of sdf_grid for marching cubes at level 0: exact where the level set can pass, the right sign elsewhere
+    (csrc/tier.hpp; ~6 % of the evaluations).  -> (volume (n_side,)*3, n_evaluated (1,) int32 on the device)."""
+    lib = load_library()
+    buf = ws.ensure(1, 1)
+    dev = frame.device
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, int(n_side))
+    sc = _band_scratch.get(key)
+    if sc is None:
+        if len(_band_scratch) >= 8:
+            _band_scratch.pop(next(iter(_band_scratch)))
+        sc = _band_scratch[key] = (torch.empty(int(lib.arah_sdf_grid_band_scratch_bytes()), dtype=torch.uint8, device=dev),
+                                   torch.empty(n_side ** 3, dtype=torch.int32, device=dev))
+    scratch, lst = sc
+    out = torch.empty(n_side, n_side, n_side, device=dev)
+    _check(lib.arah_sdf_grid_band(C.byref(frame.handle), C.c_int32(int(n_side)), _ptr(out), _ptr(lst), _ptr(scratch),
+                                  C.c_size_t(scratch.numel()), _ptr(buf), C.c_size_t(buf.numel()), _stream()), "arah_sdf_grid_band")
+    n_eval = scratch[0:4].view(torch.int32)
+    return out, n_eval
 
 
 _mc_tables = {}

@@ -242,6 +242,13 @@ int arah_sdf_eval(const ArahFrame* h_frame, const float* x_norm, int32_t n_pts, 
 /* SDF on the N^3 lattice of [-1,1]^3 (utils/sdf_meshing.py:13-70): sdf[(ix*N + iy)*N + iz], normalised units */
 int arah_sdf_grid(const ArahFrame* h_frame, int32_t n_side, float* sdf, void* workspace, size_t workspace_bytes,
                   void* stream);
+/* The same lattice for marching cubes at level 0 (utils/sdf_meshing.py:95 only reads the corners of cells that change sign):
+ * exact values wherever the level set can pass -- coarse cells (1/32 of the box) whose corner values and own slope admit a zero,
+ * plus their 26 neighbours -- and a value of the right sign elsewhere.  list: [N^3] int32 scratch; scratch:
+ * arah_sdf_grid_band_scratch_bytes() bytes.  Same triangle soup as arah_sdf_grid + arah_marching_cubes; N >= 33. */
+size_t arah_sdf_grid_band_scratch_bytes(void);
+int arah_sdf_grid_band(const ArahFrame* h_frame, int32_t n_side, float* sdf, int32_t* list, void* scratch,
+                       size_t scratch_bytes, void* workspace, size_t workspace_bytes, void* stream);
 /* nearest covering face per pixel (pix_to_face of the rasteriser models/__init__.py:232-237 uses): tri [F,3,3] =
  * (u, v, z) per corner in pixel coordinates / view depth; zbuf [H*W] keys (depth bits << 32 | face), pre-set to ~0 */
 int arah_rasterize(const float* tri_uvz, int32_t n_faces, int32_t height, int32_t width, float z_near,

@@ -365,3 +365,30 @@ def test_canonical_mesh_outputs_against_the_reference_branch(scene):
         assert a.shape == b.shape == (1, 512, 512, 3)
         same = (np.abs(a - b) <= 2e-4).all(-1)
         assert same.mean() >= 0.9995, (k, same.mean())   # edge pixels: the projections run in the GPU's fp32 (and, posed view, on the build's own skinning)
+
+
+@gpu
+@pytest.mark.parametrize("name,frame_idx", [("zju377_mono", 1), ("zju377_mono", 5), ("h36m", 3)])
+def test_band_lattice_gives_the_full_lattices_mesh(scene, name, frame_idx):
+    """arah_sdf_grid_band (the 256^3 lattice evaluated only where the level set can pass, csrc/tier.hpp) against arah_sdf_grid:
+    the values are EQUAL wherever the band evaluated, the signs are equal everywhere, and marching cubes gives the same triangle
+    soup bit for bit -- with a few per cent of the evaluations."""
+    from arah_release_amd import hip
+    dev = torch.device("cuda:0")
+    model, cfg = get_model(name, dev)
+    inputs = scene.make_inputs(256, 256, frame_idx=frame_idx, device=dev, max_rays=1024)
+    with torch.no_grad():
+        model(inputs, eval=True)
+    frame, ws = model.idhr_network.last_frame, model.idhr_network.ray_tracer.workspace(dev)
+    full = hip.sdf_grid(frame, ws, 256)
+    band, n_eval = hip.sdf_grid_band(frame, ws, 256)
+    n_eval = int(n_eval.item())
+    assert 0 < n_eval < 0.25 * 256 ** 3
+    same = band == full
+    assert int(same.sum()) >= n_eval                                        # every evaluated point carries the full lattice's value
+    assert bool(((band < 0) == (full < 0)).all())                            # the sign pattern marching cubes sees is the full one
+    t_full, n_full = hip.marching_cubes(full, 0.0)
+    t_band, n_band = hip.marching_cubes(band, 0.0)
+    assert int(n_full.item()) == int(n_band.item()) > 1000
+    assert torch.equal(t_full, t_band)
+    print("band lattice: %d of %d points evaluated (%.1f %%), %d triangles" % (n_eval, 256 ** 3, 100.0 * n_eval / 256 ** 3, int(n_full.item())))
