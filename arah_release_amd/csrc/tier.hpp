@@ -419,13 +419,14 @@ __global__ __launch_bounds__(kTierWaves * 64) void k_tier_classify(int n, int S,
                 if (live && s < S) {
                     const size_t q = (size_t)ray * S + s;
                     if (state[q]) {
-                        if (surf) st[it] = TS_PHASE1;
-                        else {
-                            int d;
-                            const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
-                            st[it] = mk ? TS_PHASE1 : TS_PENDING;
-                            dd[it] = d;
-                        }
+                        int d;
+                        const bool mk = occ_lookup(oi, bits, dist, ray_point(rs, ray, z[q]), d);
+                        // a surface ray's samples are all evaluated (its delta chain needs every valid one), but those outside
+                        // the fat body -- most of the n_far samples in front of the surface -- are CERTIFIED sigma = +0 like a
+                        // witness: convergence only, no density pass (and they head the list with the witnesses)
+                        if (surf) st[it] = mk ? TS_PHASE1 : TS_WITNESS;
+                        else st[it] = mk ? TS_PHASE1 : TS_PENDING;
+                        dd[it] = d;
                     }
                 }
                 any_marked = any_marked || __ballot(st[it] == TS_PHASE1) != 0ull;
