@@ -2798,6 +2798,7 @@ struct Knobs {
                          //                        more than half of the CU's 160 KB a half-size build (-DCW_WAVES=4) owns one slot per CU
     int canon_wg_per_cu; // ARAH_CANON_WG_PER_CU   resident workgroups of that kernel per CU (grid = this x CUs; 1)
     bool train_b3;       // ARAH_TRAIN_ENGINE!=fp32  bf16 x 3 / f16 split training kernels on split frames
+    int canon_tier_wgs;  // ARAH_CANON_TIER_WGS    workgroups of loop C's solver on the tiered forward's lists (0 = one per CU)
 };
 inline const Knobs& knobs() {
     static const Knobs k = [] {
@@ -2820,6 +2821,7 @@ inline const Knobs& knobs() {
         v.density_reg = env_int("ARAH_DENSITY_REG", 0) == 1;
         v.canon_lds_min = max(0, min((int)kLdsCanonWave, env_int("ARAH_CANON_LDS_MIN", 0)));
         v.canon_wg_per_cu = max(1, min(4, env_int("ARAH_CANON_WG_PER_CU", 1)));
+        v.canon_tier_wgs = max(0, env_int("ARAH_CANON_TIER_WGS", 0));
         const char* e = getenv("ARAH_TRAIN_ENGINE");
         v.train_b3 = !(e && strcmp(e, "fp32") == 0);
         return v;
@@ -3865,7 +3867,8 @@ static int run_broyden3(const FrameDev& fd, Workspace& w, const float* tgt, Cano
     unsigned long long* const clk_arg = w.ctr->clk;
     if (fd.split && mode != 0) {
         long long gw = (max_pts + kCwWaves * kCwSlots - 1) / (kCwWaves * kCwSlots);
-        const int cus = num_cus() * knobs().canon_wg_per_cu;
+        int cus = num_cus() * knobs().canon_wg_per_cu;
+        if (list_arg && knobs().canon_tier_wgs > 0) cus = min(cus, knobs().canon_tier_wgs);   // the tiers' short lists (see Knobs)
         if (gw > cus) gw = cus;
         if (gw < 1) gw = 1;
         // two instances are launched, one returns at once: whether the activations of this frame's skinning MLP need scaling
