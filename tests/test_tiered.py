@@ -92,6 +92,20 @@ def test_tiers_equal_the_exact_path_on_the_reference_fixtures(scene, fname, name
 
 
 @gpu
+def test_tiers_equal_the_exact_path_on_the_fp32_engine(scene, monkeypatch):
+    """The exact engine (ARAH_PRECISION=fp32: v_mfma_f32_16x16x4_f32 everywhere, loop C's tile kernel): the bitmap is built with
+    that engine's SDF and the same certificate holds."""
+    from arah_release_amd import config
+    monkeypatch.setenv("ARAH_PRECISION", "fp32")
+    dev = torch.device("cuda:0")
+    model, _ = config.build_synthetic_model("zju377_mono", 64, 16, 16, device=dev)
+    for fi in (0, 5):
+        inputs = scene.make_inputs(192, 192, frame_idx=fi, device=dev)
+        c = _assert_same(_both_ways(model, inputs, 64), "fp32 engine, frame %d" % fi)
+        assert c["n_tier_samples_skipped"] > c["n_tier_samples_p1"]
+
+
+@gpu
 def test_tiers_equal_the_exact_path_on_the_benchmark_frames(scene):
     """bench.py's workload: frames 0..19 at 512 x 512 x 64 (BASELINE config 2), every ray."""
     from arah_release_amd import config
