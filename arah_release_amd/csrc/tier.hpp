@@ -26,7 +26,8 @@
 // none of them converged (any-valid is then decided by the remaining ones).  A ray without a marked sample sends one WITNESS to
 // phase 1, the sample nearest to the fat body (L1 distance transform of the bitmap).  Per-sample results do not depend on which
 // list a sample travels in, so every ray the exact path renders non-zero is rendered bit-identically, and every other ray is 0
-// with the exact mask -- PROVIDED the two Lipschitz assumptions hold (and no fat-body root lies outside [-L, L]^3): they are
+// with the exact mask -- PROVIDED the two Lipschitz assumptions hold and no point of the fat body lies outside [-L, L]^3 (a
+// selected fine point in a boundary cell invalidates the bitmap: the body may continue where nothing was looked at): they are
 // checked where they can be (tests/test_tiered.py renders both ways and compares bits; ArahCounters.n_tier_* count the work).
 // An occupancy that overflowed its buffers marks itself invalid: every sample then counts as marked (one phase, the old path's work).
 #pragma once
@@ -142,7 +143,11 @@ __global__ void k_occ_cells(FrameDev fr, const float* __restrict__ csdf, int nc,
         info->overflow = 1;
         return;
     }
-    cell_lip[slot] = lip;
+    // a cell on the lattice's own boundary travels with a negative sign: a SELECTED fine point in it means the fat body may continue
+    // outside [-L, L]^3, where nothing was looked at (k_occ_select then drops the bitmap for this frame).  The coarse test alone
+    // says little there: far from the body the emitted SIREN is steep and many boundary cells are refined for their slope only.
+    const bool edge = cx == 0 || cy == 0 || cz == 0 || cx == m - 1 || cy == m - 1 || cz == m - 1;
+    cell_lip[slot] = edge ? -lip : lip;
     const float fs = step / (float)kOccF;
     const float x0 = -L + step * (float)cx, y0 = -L + step * (float)cy, z0 = -L + step * (float)cz;
     for (int j = 0; j < kOccF3; ++j) {
@@ -176,7 +181,9 @@ __global__ void k_occ_select(FrameDev fr, int nc, float L, OccInfo* info, const 
         const float step = 2.0f * L / (float)(nc - 1) / (float)kOccF;
         const float half = step * 0.8660254f;
         const float s = fsdf[i];
-        keep = !(s - cell_lip[i / kOccF3] * half > band_n);   // (a NaN value selects)
+        const float cl = cell_lip[i / kOccF3];
+        keep = !(s - fabsf(cl) * half > band_n);   // (a NaN value selects)
+        if (keep && cl < 0.f) info->valid = 0;     // assumption (iii) cannot be checked: the body reaches the lattice's boundary
         raw = unnormalize_pt(bc, V3{fnorm[(size_t)i * 3], fnorm[(size_t)i * 3 + 1], fnorm[(size_t)i * 3 + 2]});
     }
     const unsigned long long mk = __ballot(keep);
