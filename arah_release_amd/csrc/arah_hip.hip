@@ -4504,11 +4504,14 @@ static OccBuf carve_occ(void* base) {
     o.csdf = c.take<float>((size_t)kOccNc * kOccNc * kOccNc);
     o.cpts = c.take<float>((size_t)kOccNc * kOccNc * kOccNc * 3);
     o.cell_lip = c.take<float>(kOccMaxCells);
+    o.cell_stretch = c.take<float>(kOccMaxCells);
     o.fnorm = c.take<float>((size_t)kOccMaxFine * 3);
     o.fsdf = c.take<float>(kOccMaxFine);
     o.iota = c.take<int>(kOccMaxFine);
     o.sel_raw = c.take<float>((size_t)kOccMaxFine * 3);
     o.sel_bar = c.take<float>((size_t)kOccMaxFine * 3);
+    o.sel_idx = c.take<int>(kOccMaxFine);
+    o.sel_of = c.take<int>(kOccMaxFine);
     o.bytes = align_up(c.off, 256);
     return o;
 }
@@ -4540,13 +4543,16 @@ int arah_prepare_occupancy(const ArahFrame* f, void* occ_buf, size_t occ_bytes, 
     LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(kOccMaxFine, kTile)),
                   dim3(kThreads), kLdsSdfFwd, s, fd, (const float*)o.fnorm, (const int*)o.iota, (const int*)&o.info->n_fine, 0,
                   o.fsdf, (float*)nullptr, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, 0);
+    hipMemsetAsync(o.sel_of, 0xff, sizeof(int) * (size_t)kOccMaxFine, s);
     hipLaunchKernelGGL(k_occ_select, dim3((kOccMaxFine + 255) / 256), dim3(256), 0, s, fd, kOccNc, kOccL, o.info,
-                       (const float*)o.cell_lip, (const float*)o.fnorm, (const float*)o.fsdf, o.sel_raw);
+                       (const float*)o.cell_lip, (const float*)o.fnorm, (const float*)o.fsdf, o.sel_raw, o.sel_idx, o.sel_of);
     hipLaunchKernelGGL(k_skin_eval, dim3(grid_for(kOccMaxFine, kTile)), dim3(kThreads), kLdsSkin, s, fd, (const float*)o.sel_raw,
                        kOccMaxFine, (float*)nullptr, o.sel_bar, (float*)nullptr, &w.ctr->n_skin_fwd, (const int*)&o.info->n_sel, 1);
+    hipLaunchKernelGGL(k_occ_cell_stretch, dim3((kOccMaxCells + 3) / 4), dim3(256), 0, s, fd, kOccNc, kOccL, o.info,
+                       (const int*)o.sel_of, (const float*)o.sel_bar, o.cell_stretch);
     hipMemsetAsync(o.bits, 0, sizeof(unsigned) * (kOccMaxVox / 32), s);
     hipLaunchKernelGGL(k_occ_mark, dim3((kOccMaxFine + 255) / 256), dim3(256), 0, s, fd, kOccNc, kOccL, o.info,
-                       (const float*)o.sel_bar, o.bits);
+                       (const float*)o.sel_bar, (const int*)o.sel_idx, (const float*)o.cell_stretch, o.bits);
     // the distance transform walks lines of the bitmap's box: its dimensions live on the device, the launches cover the
     // largest box the buffer can hold per pair of axes (lines beyond the box return at once)
     const int max_lines = kOccMaxVox / 4;   // a box with fewer than 4 voxels along an axis does not occur (>= 0.16 m / voxel)

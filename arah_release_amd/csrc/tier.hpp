@@ -18,8 +18,10 @@
 //   3. the SDF on the f^3 sub-lattice of every refined cell; sub-points with sdf <= band + Lc * half_diagonal_fine are SELECTED:
 //      every y in F is within half_diagonal_fine of a selected sub-point;
 //   4. selected points are skinned forward (the skinning MLP itself, exact engine) and every voxel of the posed-space bitmap whose
-//      centre lies within kOccLipPose * half_diagonal_fine + voxel half-diagonal of an image is marked: every x in p(F) falls into
-//      a marked voxel if p is kOccLipPose-Lipschitz (a rigid blend has constant 1; measured on the synthetic subject: 1.1).
+//      centre lies within Lp * half_diagonal_fine + voxel half-diagonal of an image is marked, Lp = max(kOccLipPoseMin,
+//      kOccLipSlack x the stretch MEASURED between the cell's own selected points): every x in p(F) falls into a marked voxel if
+//      p is Lp-Lipschitz over the fine point's cube (a rigid blend has constant 1; most cells of the synthetic subject measure
+//      1.0-1.2, a few where the softmax tree switches bones within a centimetre up to 3.4).
 // Samples in unmarked voxels are "far".  A ray that converged in loops A+B, and every sample in a marked voxel, goes through the
 // exact kernels (phase 1).  A non-surface ray is PROMOTED -- all its remaining samples evaluated exactly (phase 2) -- when one of its
 // phase-1 samples has density > 0 (delta chains and the (1 - alpha + 1e-7) factors of IDR:379-390 need every valid sample), or when
@@ -42,7 +44,7 @@ constexpr int kOccMaxFine = kOccMaxCells * kOccF3;
 constexpr int kOccMaxVox = 1 << 22;         // bitmap voxels (512 KB of bits, 4 MB of distances)
 constexpr float kOccVoxel = 0.015f;         // metres; grows when the body's box would need more than kOccMaxVox voxels
 constexpr float kOccLipMin = 1.5f, kOccLipSlack = 1.25f;
-constexpr float kOccLipPose = 2.0f;
+constexpr float kOccLipPoseMin = 1.5f;     // floor of the forward skinning's per-cell constant (a rigid blend stretches by 1)
 
 struct OccInfo {                 // head of the occupancy buffer (device)
     float origin[3];
@@ -53,7 +55,7 @@ struct OccInfo {                 // head of the occupancy buffer (device)
     int n_cells, n_fine, n_sel;  // refined cells, fine points (clamped), selected points
     int overflow;
     float band_m;                // kTierBand * beta (metres) the bitmap was built for
-    int pad[1];
+    float lip_pose;              // steepest |p(a) - p(b)| / |a - b| over adjacent selected fine points (assumption ii, measured)
 };
 
 struct OccBuf {                  // carved view of the caller's occupancy buffer
@@ -62,12 +64,15 @@ struct OccBuf {                  // carved view of the caller's occupancy buffer
     uint8_t* dist;               // [kOccMaxVox] L1 distance (voxels, saturated at 255) to the nearest marked voxel
     float* csdf;                 // [kOccNc^3] coarse lattice SDF (normalised units)
     float* cpts;                 // [kOccNc^3][3]
-    float* cell_lip;             // [kOccMaxCells]
+    float* cell_lip;             // [kOccMaxCells] the SDF's constant of a refined cell (negative: the cell sits on the lattice's boundary)
+    float* cell_stretch;         // [kOccMaxCells] measured stretch of the forward skinning over the cell's selected points
     float* fnorm;                // [kOccMaxFine][3]
     float* fsdf;                 // [kOccMaxFine]
     int* iota;                   // [kOccMaxFine]
     float* sel_raw;              // [kOccMaxFine][3] raw canonical coordinates of the selected points
     float* sel_bar;              // [kOccMaxFine][3] their forward-skinned images (without the translation)
+    int* sel_idx;                // [kOccMaxFine] fine index of a selected point
+    int* sel_of;                 // [kOccMaxFine] selected slot of a fine point, -1 if not selected
     size_t bytes;
 };
 
@@ -105,6 +110,7 @@ __global__ void k_occ_begin(FrameDev fr, const GridInfo* __restrict__ grid, OccI
     info->n_vox = nv;
     info->valid = nv <= kOccMaxVox ? 1 : 0;
     info->n_cells = info->n_fine = info->n_sel = info->overflow = 0;
+    info->lip_pose = 0.f;
     const float beta = fminf(fmaxf(fabsf(load_beta(fr)), 1e-6f), 1e6f);
     info->band_m = kTierBand * beta;
 }
@@ -169,7 +175,8 @@ __global__ void k_occ_fix(OccInfo* info) {
 
 // ---- 3. select the fine points that may lie within half a fine diagonal of the fat body
 __global__ void k_occ_select(FrameDev fr, int nc, float L, OccInfo* info, const float* __restrict__ cell_lip,
-                             const float* __restrict__ fnorm, const float* __restrict__ fsdf, float* __restrict__ sel_raw) {
+                             const float* __restrict__ fnorm, const float* __restrict__ fsdf, float* __restrict__ sel_raw,
+                             int* __restrict__ sel_idx, int* __restrict__ sel_of) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = info->n_fine;
     const BodyConst bc = load_bc(fr);
@@ -196,18 +203,63 @@ __global__ void k_occ_select(FrameDev fr, int nc, float L, OccInfo* info, const 
         sel_raw[o * 3] = raw.x;
         sel_raw[o * 3 + 1] = raw.y;
         sel_raw[o * 3 + 2] = raw.z;
+        sel_idx[o] = i;
+        sel_of[i] = (int)o;
+    }
+}
+
+// The forward skinning's constant, MEASURED per refined cell on its own selected fine points (one wave per cell, lane = fine point,
+// every pair of the cell): the steepest |p(a) - p(b)| / |a - b|.  The dilation radius of the cell's images is max(kOccLipPoseMin,
+// kOccLipSlack x that) half-diagonals.  On the synthetic subject 99 % of the cells measure <= 1.6 and 4-11 of 4 200, where the
+// hierarchical softmax switches bones within a centimetre, 2-10: a fixed constant of 2 was not a bound there (it held by the other
+// margins), a fixed 10 would have swollen the band everywhere.  The steepest value of the frame is kept in the header.
+// (The SDF's constant stays the coarse cell's own slope x kOccLipSlack, floor kOccLipMin.  Raising it by the slopes between the
+// fine points was tried: far outside the body the emitted SIREN is steep (slopes of 10-15 between [-1, 1]^3 and the lattice's
+// boundary), boundary cells then select fine points and the bitmap drops itself in a third of the frames -- 12.9 -> 15.8 ms.)
+__global__ __launch_bounds__(256) void k_occ_cell_stretch(FrameDev fr, int nc, float L, OccInfo* info, const int* __restrict__ sel_of,
+                                                          const float* __restrict__ sel_bar, float* __restrict__ cell_stretch) {
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (cell >= info->n_cells) return;
+    const BodyConst bc = load_bc(fr);
+    const float fs = 2.0f * L / (float)(nc - 1) / (float)kOccF * sdf_scale(bc);   // metres between adjacent fine points
+    const int o = lane < kOccF3 ? sel_of[(size_t)cell * kOccF3 + lane] : -1;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (o >= 0) {
+        px = sel_bar[(size_t)o * 3];
+        py = sel_bar[(size_t)o * 3 + 1];
+        pz = sel_bar[(size_t)o * 3 + 2];
+    }
+    const int a = lane / (kOccF * kOccF), b = (lane / kOccF) % kOccF, d = lane % kOccF;
+    float worst = 0.f;
+    for (int k = 1; k < kOccF3; ++k) {
+        const int other = (lane + k) % kOccF3;
+        const int o2 = __shfl(o, other);
+        const float qx = __shfl(px, other), qy = __shfl(py, other), qz = __shfl(pz, other);
+        const int a2 = other / (kOccF * kOccF), b2 = (other / kOccF) % kOccF, d2 = other % kOccF;
+        const float dist = fs * sqrtf((float)((a - a2) * (a - a2) + (b - b2) * (b - b2) + (d - d2) * (d - d2)));
+        if (o >= 0 && o2 >= 0)
+            worst = fmaxf(worst, sqrtf((px - qx) * (px - qx) + (py - qy) * (py - qy) + (pz - qz) * (pz - qz)) / dist);
+    }
+    for (int off = 32; off > 0; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+    if (lane == 0) {
+        cell_stretch[cell] = worst;
+        if (worst > 0.f) atomicMax(reinterpret_cast<int*>(&info->lip_pose), __float_as_int(worst));   // non-negative floats order like their bits
+        if (!(worst == worst)) info->valid = 0;
     }
 }
 
 // ---- 4. mark the voxels around the posed images of the selected points
-__global__ void k_occ_mark(FrameDev fr, int nc, float L, OccInfo* info, const float* __restrict__ sel_bar, unsigned* __restrict__ bits) {
+__global__ void k_occ_mark(FrameDev fr, int nc, float L, OccInfo* info, const float* __restrict__ sel_bar, const int* __restrict__ sel_idx,
+                           const float* __restrict__ cell_stretch, unsigned* __restrict__ bits) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= info->n_sel || !info->valid) return;
     const BodyConst bc = load_bc(fr);
     const float scale = sdf_scale(bc);
     const float half_m = 2.0f * L / (float)(nc - 1) / (float)kOccF * 0.8660254f * scale;
     const float v = info->v, inv_v = info->inv_v;
-    const float rad = (kOccLipPose * half_m + 1e-4f) * inv_v + 0.8660254f;     // voxel units, centre to point
+    const float lip_pose = fmaxf(kOccLipPoseMin, kOccLipSlack * cell_stretch[sel_idx[i] / kOccF3]);   // this cell's measured constant
+    const float rad = (lip_pose * half_m + 1e-4f) * inv_v + 0.8660254f;     // voxel units, centre to point
     // position in voxel units relative to voxel centres: centre of voxel k sits at k + 0.5
     const float px = (sel_bar[(size_t)i * 3] + bc.trans[0] - info->origin[0]) * inv_v - 0.5f;
     const float py = (sel_bar[(size_t)i * 3 + 1] + bc.trans[1] - info->origin[1]) * inv_v - 0.5f;

@@ -271,7 +271,8 @@ class Workspace:
         f = struct.unpack("5f", raw[:20])
         i = struct.unpack("9i", raw[20:56])
         return {"origin": f[:3], "voxel": f[3], "dims": i[:3], "n_vox": i[3], "valid": i[4], "n_cells": i[5], "n_fine": i[6],
-                "n_selected": i[7], "overflow": i[8], "band_m": struct.unpack("f", raw[56:60])[0]}
+                "n_selected": i[7], "overflow": i[8], "band_m": struct.unpack("f", raw[56:60])[0],
+                "lip_pose": struct.unpack("f", raw[60:64])[0]}
 
     def tier_debug(self, n_rays, n_steps):
         """(ray_tier, ray_sigma_pos) uint8 tensors of the last arah_render on this scratch."""

@@ -435,7 +435,8 @@ size_t arah_occupancy_bytes(void);
 int arah_prepare_occupancy(const ArahFrame* h_frame, void* occ_buf, size_t occ_bytes, void* workspace,
                            size_t workspace_bytes, void* stream);
 /* the 16 words at the head of an occupancy buffer: origin[3], voxel, 1/voxel, dims[3], n_vox, valid, n_cells, n_fine,
- * n_selected, overflow, band (m), pad; synchronises the stream */
+ * n_selected, overflow, band (m), steepest measured stretch of the forward skinning between adjacent selected lattice points;
+ * synchronises the stream */
 int arah_occupancy_info(const void* occ_buf, int32_t* h_out16, void* stream);
 /* after an arah_render on this workspace: ray_tier [N] (0 certified zero, 1 surface ray, 2 promoted; tiered path only) and
  * ray_sigma_pos [N] (1: some valid sample of the ray has density > 0); device pointers, either may be NULL */
