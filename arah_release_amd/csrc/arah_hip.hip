@@ -4543,6 +4543,7 @@ int arah_prepare_occupancy(const ArahFrame* f, void* occ_buf, size_t occ_bytes, 
     LAUNCH_ENGINE(fd.split, (k_sdf_eval<false, true>), (k_sdf_eval<false, false>), dim3(grid_for(kOccMaxFine, kTile)),
                   dim3(kThreads), kLdsSdfFwd, s, fd, (const float*)o.fnorm, (const int*)o.iota, (const int*)&o.info->n_fine, 0,
                   o.fsdf, (float*)nullptr, (float*)nullptr, (f32x4*)nullptr, &w.ctr->n_sdf_fwd, (unsigned long long*)nullptr, 0);
+    hipLaunchKernelGGL(k_occ_cell_slope, dim3((kOccMaxCells + 3) / 4), dim3(256), 0, s, kOccNc, kOccL, o.info, (const float*)o.fsdf, o.cell_lip);
     hipMemsetAsync(o.sel_of, 0xff, sizeof(int) * (size_t)kOccMaxFine, s);
     hipLaunchKernelGGL(k_occ_select, dim3((kOccMaxFine + 255) / 256), dim3(256), 0, s, fd, kOccNc, kOccL, o.info,
                        (const float*)o.cell_lip, (const float*)o.fnorm, (const float*)o.fsdf, o.sel_raw, o.sel_idx, o.sel_of);

@@ -216,6 +216,33 @@ __global__ void k_occ_select(FrameDev fr, int nc, float L, OccInfo* info, const 
 // (The SDF's constant stays the coarse cell's own slope x kOccLipSlack, floor kOccLipMin.  Raising it by the slopes between the
 // fine points was tried: far outside the body the emitted SIREN is steep (slopes of 10-15 between [-1, 1]^3 and the lattice's
 // boundary), boundary cells then select fine points and the bitmap drops itself in a third of the frames -- 12.9 -> 15.8 ms.)
+// The SDF's constant of an INTERIOR refined cell, raised by what its own fine points show: kOccLipSlack x the steepest
+// |sdf(a) - sdf(b)| / |a - b| over the cell's 27 fine points (a SIREN detail finer than the coarse cell).  Cells on the lattice's
+// boundary keep their coarse constant (see the note above).
+__global__ __launch_bounds__(256) void k_occ_cell_slope(int nc, float L, OccInfo* info, const float* __restrict__ fsdf,
+                                                        float* __restrict__ cell_lip) {
+    const int lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (cell >= info->n_cells) return;
+    const float fs = 2.0f * L / (float)(nc - 1) / (float)kOccF;   // normalised units: slopes are the same in metres
+    const bool on = lane < kOccF3;
+    const float mine = on ? fsdf[(size_t)cell * kOccF3 + lane] : 0.f;
+    const int a = lane / (kOccF * kOccF), b = (lane / kOccF) % kOccF, d = lane % kOccF;
+    float worst = 0.f;
+    for (int o = 1; o < kOccF3; ++o) {
+        const int other = (lane + o) % kOccF3;
+        const float v = __shfl(mine, other);
+        const int a2 = other / (kOccF * kOccF), b2 = (other / kOccF) % kOccF, d2 = other % kOccF;
+        const float dist = fs * sqrtf((float)((a - a2) * (a - a2) + (b - b2) * (b - b2) + (d - d2) * (d - d2)));
+        if (on) worst = fmaxf(worst, fabsf(v - mine) / dist);
+    }
+    for (int off = 32; off > 0; off >>= 1) worst = fmaxf(worst, __shfl_xor(worst, off));
+    if (lane == 0) {
+        const float cl = cell_lip[cell];
+        if (cl > 0.f) cell_lip[cell] = fmaxf(cl, kOccLipSlack * worst);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_occ_cell_stretch(FrameDev fr, int nc, float L, OccInfo* info, const int* __restrict__ sel_of,
                                                           const float* __restrict__ sel_bar, float* __restrict__ cell_stretch) {
     const int lane = threadIdx.x & 63;

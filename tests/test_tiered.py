@@ -88,7 +88,7 @@ def test_tiers_equal_the_exact_path_on_the_reference_fixtures(scene, fname, name
     res = _both_ways(model, inputs, S)
     c = _assert_same(res, fname)
     assert res["tiered"]["occ"]["valid"] == 1 and res["tiered"]["occ"]["overflow"] == 0
-    assert 0.9 < res["tiered"]["occ"]["lip_pose"] < 8.0, res["tiered"]["occ"]   # the forward skinning's stretch, measured per cell (most 1.0-1.2, the steepest 2-3.4)
+    assert 0.9 < res["tiered"]["occ"]["lip_pose"] < 32.0, res["tiered"]["occ"]   # the forward skinning's stretch, measured per cell (most 1.0-1.2, the steepest 2-10.4 where the softmax tree switches bones; a sanity range, the dilation follows the measurement)
     assert c["n_tier_samples_skipped"] > 0
 
 
