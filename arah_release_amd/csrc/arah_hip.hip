@@ -4417,6 +4417,115 @@ int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int
     return check_launch();
 }
 
+// ---- column sums over the sample axis (training step): y[c] = sum_r s[r] a[r][c], s = 1 when null ---------------------
+// The bias gradients of the tall layers (sum over 1.2e5 samples of a 25 .. 256-wide delta) and, with s = the upstream gradient
+// and a = the 65 792 x 256 weight matrix of a hypernetwork head, the head's input gradient g W (the GEMM library runs that
+// batch-1 product at 0.5 TB/s, torch's reduction a 25-wide sum at 0.04).  One pass at HBM speed: a workgroup reduces kColRows
+// rows into partial[block][n_cols] (fixed order), k_colsum_finish adds the partials up in block order: deterministic.
+constexpr int kColRows = 128;
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, long long lda, int n, long long n_rows,
+                                                const float* __restrict__ scale, float* __restrict__ partial) {
+    __shared__ float red[256 * 4];
+    const long long r0 = (long long)blockIdx.x * kColRows, r1 = min(r0 + (long long)kColRows, n_rows);
+    const int t = threadIdx.x;
+    const bool vec = (n & 3) == 0 && (lda & 3) == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0;
+    if (vec) {
+        const int n4 = n >> 2;
+        for (int c0 = 0; c0 < n4; c0 += 256) {
+            const int C = min(n4 - c0, 256), RL = 256 / C;   // C column quads side by side, RL rows at a time
+            const int c = t % C, rl = t / C;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            if (rl < RL)
+                for (long long r = r0 + rl; r < r1; r += RL) {
+                    const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a + r * lda) + c0 + c);
+                    const float sc = scale ? scale[r] : 1.0f;
+                    acc += v * sc;
+                }
+            reinterpret_cast<f32x4*>(red)[t] = acc;
+            __syncthreads();
+            if (t < C) {
+                f32x4 sum = reinterpret_cast<f32x4*>(red)[t];
+                for (int k = 1; k < RL; ++k) sum += reinterpret_cast<f32x4*>(red)[k * C + t];
+                reinterpret_cast<f32x4*>(partial + (size_t)blockIdx.x * n)[c0 + t] = sum;
+            }
+            __syncthreads();
+        }
+        return;
+    }
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int C = min(n - c0, 256), RL = 256 / C;
+        const int c = t % C, rl = t / C;
+        float acc = 0.f;
+        if (rl < RL)
+            for (long long r = r0 + rl; r < r1; r += RL) acc = fmaf(a[r * lda + c0 + c], scale ? scale[r] : 1.0f, acc);
+        red[t] = acc;
+        __syncthreads();
+        if (t < C) {
+            float sum = red[t];
+            for (int k = 1; k < RL; ++k) sum += red[k * C + t];
+            partial[(size_t)blockIdx.x * n + c0 + t] = sum;
+        }
+        __syncthreads();
+    }
+}
+// sixteen columns x sixteen row lanes per workgroup: lane (rl, c) adds partial[rl], partial[rl + 16], ... of its column, the sixteen
+// lane sums are added in lane order -- a fixed order, and ~60 dependent additions per thread instead of ~1000
+__global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ partial, int blocks, int n, float* __restrict__ y) {
+    __shared__ float red[256];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+    float s = 0.f;
+    if (c < n)
+        for (int b = rl; b < blocks; b += 16) s += partial[(size_t)b * n + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && c < n) {
+        float t = red[threadIdx.x];
+        for (int k = 1; k < 16; ++k) t += red[k * 16 + threadIdx.x];
+        y[c] = t;
+    }
+}
+
+int32_t arah_colsum_blocks(int64_t n_rows) { return n_rows > 0 ? (int32_t)((n_rows + kColRows - 1) / kColRows) : 0; }
+
+int arah_colsum(const float* a, int64_t lda, int32_t n_cols, int64_t n_rows, const float* scale, float* partial, float* y,
+                void* stream) {
+    if (!a || !partial || !y || n_cols < 1 || lda < n_cols || n_rows < 0) return ARAH_E_BADARG;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (n_rows == 0) {
+        hipMemsetAsync(y, 0, sizeof(float) * (size_t)n_cols, s);
+        return check_launch();
+    }
+    const int blocks = arah_colsum_blocks(n_rows);
+    hipLaunchKernelGGL(k_colsum, dim3(blocks), dim3(256), 0, s, a, (long long)lda, n_cols, (long long)n_rows, scale, partial);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((n_cols + 15) / 16), dim3(256), 0, s, (const float*)partial, blocks, n_cols, y);
+    return check_launch();
+}
+
+// ---- inverses of P 3 x 3 matrices (the Jacobians of the re-attachment, IDR:315-334: torch.inverse there) -----------------
+// inv[p] = (scale * m[p])^-1 by cofactors; the library's batched LU (factor + two substitutions + a row swap kernel) takes
+// 0.5 ms for the 1.2e5 well-conditioned matrices of a training step.
+__global__ void k_inverse3x3(const float* __restrict__ m, int n, float scale, float* __restrict__ inv) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float T[16], R[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[r * 4 + c] = m[(size_t)p * 9 + r * 3 + c] * scale;
+    T[3] = T[7] = T[11] = T[12] = T[13] = T[14] = 0.f;
+    T[15] = 1.f;
+    inv3_of44(T, R);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) inv[(size_t)p * 9 + k] = R[k];
+}
+
+int arah_inverse3x3(const float* m, int32_t n, float scale, float* inv, void* stream) {
+    if (!m || !inv || n < 0) return ARAH_E_BADARG;
+    if (n == 0) return ARAH_OK;
+    hipLaunchKernelGGL(k_inverse3x3, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), m, n, scale, inv);
+    return check_launch();
+}
+
 // ---- the wide output layers of the SDF hypernetwork (hyperlayers.py:418-465) ----------------------------
 // y[r] = W[r, :] . x + b0[r] (+ b1[r]): a 256 -> 65 792 linear layer per emitted 256 x 256 SDF layer, 67 MB of weights that
 // are read once per frame -- 337 MB for the five hidden layers, a pure HBM stream.  The GEMM library runs these batch-1

@@ -115,7 +115,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
+           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_colsum_blocks", "arah_colsum", "arah_inverse3x3", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
            "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes",
            "arah_occupancy_bytes", "arah_prepare_occupancy", "arah_occupancy_info", "arah_tier_debug", "arah_debug_samples",
            "arah_sdf_grid_band_scratch_bytes", "arah_sdf_grid_band"]
@@ -143,6 +143,7 @@ def load_library():
     lib.arah_marching_cubes_scratch_bytes.argtypes = [C.c_int32]
     lib.arah_occupancy_bytes.restype = C.c_size_t
     lib.arah_sdf_grid_band_scratch_bytes.restype = C.c_size_t
+    lib.arah_colsum_blocks.argtypes = [C.c_int64]
     for name in EXPORTS:
         getattr(lib, name)  # AttributeError if the symbol is missing
     _lib = lib
@@ -780,6 +781,17 @@ def shade_composite(frame, ws, sampling, dirs, z, pts, T, mask):
 KIN_PAD = {COLOR_NO_VIEW_DIR: 272, COLOR_IDR: 304}   # colour input [feat(256) | x(3) | n(3) | PE(view)(27)] padded to 16
 
 
+def _grouped(groups, n, width, device, inner=None):
+    """(groups[, inner], roundup(n, 64), width) floats whose padding rows are zero: the operand streams of products over the sample
+    axis that travel together (see tall.gram_grouped).  The kernels write rows [0, n) of each slice."""
+    n_pad = (n + 63) // 64 * 64
+    shape = (groups, n_pad, width) if inner is None else (groups, inner, n_pad, width)
+    buf = torch.empty(*shape, device=device)
+    if n_pad > n:
+        buf[..., n:, :].zero_()
+    return buf
+
+
 def _train_in(x, T, view, view_orig, rotate_normal, ray_augm, g_s=None, g_rgb=None):
     t = ArahTrainIn()
     t.n, t.rotate_normal, t.ray_augm = int(x.shape[0]), int(bool(rotate_normal)), int(bool(ray_augm))
@@ -804,14 +816,27 @@ def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_aug
     tin = _train_in(x, T, view, vo, rotate_normal, ray_augm)
     kept = None
     if keep:
+        # the 256-wide activations sit next to each other, padded to a multiple of 64 rows with zeros: the weight-gradient
+        # products of the backward then run as ONE batched split-K product per group (tall.gram_grouped), all views
+        cc = _grouped(4, n, 256, x.device)
         kept = {"cin": torch.empty(n, KIN_PAD[frame.color_mode], device=x.device),
-                "c": [torch.empty(n, w, device=x.device) for w in (256, 256, 128, 256, 256)], "rgb4": rgb4}
+                "c": [cc[0, :n], cc[2, :n], torch.empty(n, 128, device=x.device), cc[1, :n], cc[3, :n]], "rgb4": rgb4, "cc": cc}
         tin.tap_cin = _ptr(kept["cin"])
         for i, t in enumerate(kept["c"]):
             tin.tap_c[i] = _ptr(t).value
     _check(lib.arah_shade_train_forward(C.byref(frame.handle), C.byref(tin), _ptr(sdf), _ptr(rgb4), _ptr(buf),
                                         C.c_size_t(buf.numel()), _stream()), "arah_shade_train_forward")
     return (sdf, rgb4[:, :3], kept) if keep else (sdf, rgb4[:, :3])
+
+
+def _sdf_streams(n, dev):
+    """Operand streams of the SIREN's weight gradients, grouped for tall.gram_grouped: `avv` (6, 2, n_pad, 256) holds adj v_k and
+    adj vd_k of layer k next to each other, `hh` (5, 2, n_pad, 256) their partners h_k and hd_k (k = 1..5), `h0` (2, n_pad, 4) the
+    first layer's h_0 = x and hd_0 = nt.  dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1} is then ONE product over 2 n_pad rows."""
+    avv, hh, h0 = _grouped(6, n, 256, dev, inner=2), _grouped(5, n, 256, dev, inner=2), _grouped(2, n, 4, dev)
+    return {"h": [h0[0, :n]] + [hh[k, 0, :n] for k in range(5)],
+            "hd": [h0[1, :n]] + [hh[k, 1, :n] for k in range(5)] + [torch.empty(n, 256, device=dev)],
+            "av": [avv[k, 0, :n] for k in range(6)], "avd": [avv[k, 1, :n] for k in range(6)], "avv": avv, "hh": hh, "h0": h0}
 
 
 @_guarded
@@ -840,9 +865,8 @@ def sdf_normal_backward(frame, ws, x, g_s, g_n):
     n, dev = x.shape[0], x.device
     buf = ws.ensure(1, 1)
     E = lambda *shape: torch.empty(*shape, device=dev)
-    st = {"gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256), "feat": E(n, 256),
-          "h": [E(n, 4)] + [E(n, 256) for _ in range(5)], "hd": [E(n, 4)] + [E(n, 256) for _ in range(6)],
-          "av": [E(n, 256) for _ in range(6)], "avd": [E(n, 256) for _ in range(6)]}
+    st = {"gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256), "feat": E(n, 256)}
+    st.update(_sdf_streams(n, dev))
     g = ArahTrainGrads()
     for k in ("gx4", "film_freq", "film_phase"):
         setattr(g, k, _ptr(st[k]))
@@ -874,12 +898,16 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
     buf = ws.ensure(1, 1)
     kin = KIN_PAD[frame.color_mode]
     E = lambda *shape: torch.empty(*shape, device=dev)
+    if kept:
+        cc = kept["cc"]
+    else:
+        cc = _grouped(4, n, 256, dev)
+    dd = _grouped(4, n, 256, dev)     # delta_1, delta_4, delta_0, delta_3: the order of their partners in `cc` (c_1, c_4, c_2, c_5)
     st = {"sdf": E(n), "rgb4": E(n, 4), "gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256),
-          "h": [E(n, 4)] + [E(n, 256) for _ in range(5)], "hd": [E(n, 4)] + [E(n, 256) for _ in range(6)],
-          "av": [E(n, 256) for _ in range(6)], "avd": [E(n, 256) for _ in range(6)],
           "cin": kept["cin"] if kept else E(n, kin),
-          "c": kept["c"] if kept else [E(n, w) for w in (256, 256, 128, 256, 256)],
-          "d": [E(n, w) for w in (256, 256, 128, 256, 256)] + [E(n, 4)]}
+          "c": kept["c"] if kept else [cc[0, :n], cc[2, :n], E(n, 128), cc[1, :n], cc[3, :n]],
+          "d": [dd[2, :n], dd[0, :n], E(n, 128), dd[3, :n], dd[1, :n], E(n, 4)], "cc": cc, "dd": dd}
+    st.update(_sdf_streams(n, dev))
     g = ArahTrainGrads()
     for k in ("sdf", "rgb4", "gx4", "film_freq", "film_phase", "cin"):
         setattr(g, k, _ptr(st[k]))
@@ -968,6 +996,39 @@ def gram_skinny(a, b):
                                     C.c_void_p(b.data_ptr()), C.c_int32(b.stride(0)),
                                     C.c_int32(n), C.c_int32(P), _ptr(partial), _stream()), "arah_gram_skinny")
     return partial.sum(0)
+
+
+def colsum(a, scale=None):
+    """y[c] = sum_r scale[r] a[r, c] for a (R, n) fp32 with unit column stride (row stride free), scale (R,) or None: (n,).
+    One pass at HBM speed with a fixed summation order (arah_colsum)."""
+    lib = load_library()
+    dev = _same_device(a, scale)
+    if a.dtype != torch.float32 or a.dim() != 2 or a.stride(1) != 1:
+        raise ValueError("colsum: (R, n) float32 with unit column stride required")
+    R, n = a.shape
+    sc = None if scale is None else _f32(scale).reshape(-1)
+    if sc is not None and sc.numel() != R:
+        raise ValueError("colsum: one scale per row")
+    with _on_device(dev):
+        y = torch.empty(n, device=dev)
+        partial = torch.empty(max(1, int(lib.arah_colsum_blocks(C.c_int64(R)))), n, device=dev)
+        _check(lib.arah_colsum(C.c_void_p(a.data_ptr()), C.c_int64(a.stride(0) if R > 1 else n), C.c_int32(n), C.c_int64(R),
+                               _ptr(sc), _ptr(partial), _ptr(y), _stream()), "arah_colsum")
+    return y
+
+
+def inverse3x3(m, scale=1.0):
+    """(scale * m)^-1 for m (P, 3, 3) fp32 by cofactors (arah_inverse3x3); no autograd."""
+    lib = load_library()
+    mm = _f32(m)
+    dev = _same_device(mm)
+    if mm.dim() != 3 or mm.shape[1:] != (3, 3):
+        raise ValueError("inverse3x3: (P, 3, 3) required")
+    with _on_device(dev):
+        out = torch.empty_like(mm)
+        _check(lib.arah_inverse3x3(_ptr(mm), C.c_int32(mm.shape[0]), C.c_float(float(scale)), _ptr(out), _stream()),
+               "arah_inverse3x3")
+    return out
 
 
 @_guarded

@@ -100,6 +100,28 @@ class _HyperHead(nn.Module):
         return self.net(x)
 
 
+class _WideHead(torch.autograd.Function):
+    """weight @ hidden + bias + init for ONE hidden vector and a wide output layer (256 -> in*out + out, 67 MB of weights), with
+    gradients: both directions are HBM streams of the weight matrix -- arah_gemv_rows forward, arah_colsum (rows scaled by the
+    upstream gradient) for the input gradient, where the GEMM library's batch-1 products run at 0.9 and 0.5 TB/s."""
+
+    @staticmethod
+    def forward(ctx, hidden, weight, bias, init):
+        from . import hip
+        ctx.save_for_backward(hidden, weight)
+        return hip.gemv_rows(weight, hidden, bias, init).reshape(*hidden.shape[:-1], -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip
+        hidden, weight = ctx.saved_tensors
+        g1 = g.reshape(-1).contiguous()
+        gh = hip.colsum(weight.detach(), g1).reshape(hidden.shape) if ctx.needs_input_grad[0] else None
+        gw = torch.outer(g1, hidden.detach().reshape(-1)) if ctx.needs_input_grad[1] else None
+        gb = g1.reshape(-1) if ctx.needs_input_grad[2] else None
+        return gh, gw, gb, None
+
+
 class HyperLinear(nn.Module):
     """Emits one linear layer (W, b) of the SDF MLP from the pose condition."""
 
@@ -120,7 +142,11 @@ class HyperLinear(nn.Module):
             w, b = p.split([nw, self.out_ch], dim=-1)
             return w.reshape(*p.shape[:-1], self.out_ch, self.in_ch), b.reshape(*p.shape[:-1], 1, self.out_ch)
         if hidden is not None:
-            p = head[2](hidden) + self.hypo_params_init
+            if (hidden.is_cuda and hidden.numel() == hidden.shape[-1] and head[2].out_features >= 4096
+                    and hidden.dtype == torch.float32 and os.environ.get("ARAH_HYPER_GEMV", "1") != "0"):
+                p = _WideHead.apply(hidden, head[2].weight, head[2].bias, self.hypo_params_init)   # training, one condition vector
+            else:
+                p = head[2](hidden) + self.hypo_params_init
             nw = self.in_ch * self.out_ch
             w, b = p.split([nw, self.out_ch], dim=-1)
             return w.reshape(*p.shape[:-1], self.out_ch, self.in_ch), b.reshape(*p.shape[:-1], 1, self.out_ch)

@@ -407,6 +407,21 @@ class IDHRNetwork(nn.Module):
                                  # hip.PRECISION_FP32 / PRECISION_SPLIT_F16 = this renderer's own choice (bench.py's passes)
         self._precision = None   # becomes hip.PRECISION_FP32 once the range guard has fired: overrides `precision`
 
+    def _regulariser_probe(self, input, frame, sdf_network, B, n_reg, dev):
+        """The regulariser queries (IDR:104-128) through the training kernel without its colour half: value and gradient in one
+        launch, the second-order path of the eikonal term in one more (training.SdfNormal) -- an autograd SIREN is ~100 launches
+        forward and ~150 backward for the same numbers.  Uses the scratch of the CURRENT stream.
+        -> off-surface sdf (B, n_reg, 1), eikonal gradients (B n_reg, 3), inside sdf or None."""
+        eik = ((draw_uniform((B, n_reg, 3), dev, "eikonal") - 0.5) * 2).reshape(-1, 3)
+        pts_in = input["points_inside"].reshape(-1, 3) if "points_inside" in input else eik[:0]
+        probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3), pts_in], dim=0)
+        sdf_probe, n_probe = training.sdf_normal_hip(frame, self.ray_tracer.workspace(dev), sdf_network, probe)
+        uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
+        grad_eik = n_probe[:B * n_reg]
+        inside_sdf = sdf_probe[2 * B * n_reg:].reshape(input["points_inside"].shape[:-1] + (1,)).squeeze(0) \
+            if "points_inside" in input else None
+        return uniform_sdf, grad_eik, inside_sdf
+
     def forward_train(self, input):
         """Training forward (IDR:42-248): HIP kernels for the ray tracer (no_grad, like the reference), autograd
         for loop D and the regulariser queries (training.py)."""
@@ -416,15 +431,19 @@ class IDHRNetwork(nn.Module):
         B, N, _ = ray_dirs.shape
         dev = ray_dirs.device
         pred_weights = None
+        use_hip_shading = os.environ.get("ARAH_TRAIN_AUTOGRAD", "0") != "1"
+        # (Round 6 tried the skinning-weight query of the loss and the regulariser queries on a side stream next to the ray
+        # tracer's dependent chains: no gain -- 23.4-23.5 ms per step either way, and 12 ms more CPU in the waits between the
+        # streams of the backward; removed.)
         if "points_skinning" in input:
             pred_weights = training.query_weights(input["points_skinning"], cmin, cmax, center, self.skinning_model)
         # one packed frame per step serves the ray tracer (loops A-C) and the hand-written loop-D op
-        use_hip_shading = os.environ.get("ARAH_TRAIN_AUTOGRAD", "0") != "1"
         frame = None
         if ray_dirs.is_cuda:   # (CPU: only reachable with a stubbed ray tracer, e.g. the gloo DDP test; autograd loop D)
             frame = build_frame(sdf_network, self.skinning_model, self.rendering_network, self.deviation_network,
                                 pose_cond, input["smpl_verts"], input["skinning_weights"], input["bone_transforms"],
                                 input["trans"], cmin, cmax, center, body_tables=input.get("_body_tables"))
+        n_reg = 1024
         with torch.no_grad():
             xn, _, _, s_pts, s_z, s_T, s_mask = self.ray_tracer(
                 sdf_network, self.skinning_model, cam_loc=cam_loc, ray_directions=ray_dirs,
@@ -433,20 +452,10 @@ class IDHRNetwork(nn.Module):
                 skinning_weights=input["skinning_weights"], vol_feat=input["vol_feat"],
                 bone_transforms=input["bone_transforms"], trans=input["trans"], coord_min=cmin, coord_max=cmax,
                 center=center, eval_mode=False, frame=frame)
-        n_reg = 1024
-        eik = ((draw_uniform((B, n_reg, 3), dev, "eikonal") - 0.5) * 2).reshape(-1, 3)
         if frame is not None and use_hip_shading and os.environ.get("ARAH_TRAIN_PROBE_OP", "1") != "0":
-            # the regulariser queries (IDR:104-128) through the training kernel without its colour half: value and gradient
-            # in one launch, the second-order path of the eikonal term in one more (training.SdfNormal) -- the autograd
-            # SIREN below is ~100 launches forward and ~150 backward for the same numbers
-            pts_in = input["points_inside"].reshape(-1, 3) if "points_inside" in input else eik[:0]
-            probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3), pts_in], dim=0)
-            sdf_probe, n_probe = training.sdf_normal_hip(frame, self.ray_tracer.workspace(dev), sdf_network, probe)
-            uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
-            grad_eik = n_probe[:B * n_reg]
-            inside_sdf = sdf_probe[2 * B * n_reg:].reshape(input["points_inside"].shape[:-1] + (1,)).squeeze(0) \
-                if "points_inside" in input else None
+            uniform_sdf, grad_eik, inside_sdf = self._regulariser_probe(input, frame, sdf_network, B, n_reg, dev)
         else:
+            eik = ((draw_uniform((B, n_reg, 3), dev, "eikonal") - 0.5) * 2).reshape(-1, 3)
             inside_sdf = sdf_network(input["points_inside"]).squeeze(0) if "points_inside" in input else None
             probe = torch.cat([eik, input["points_uniform"].reshape(-1, 3)], dim=0).requires_grad_(True)
             sdf_probe = sdf_network(probe).squeeze(0)

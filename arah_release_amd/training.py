@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .tall import gram, mv3
+from .tall import gram, gram_grouped, mv3
 
 
 # ------------------------------------------------------------------------------------------------
@@ -116,6 +116,36 @@ def input_jacobian(y, x):
 # ------------------------------------------------------------------------------------------------
 # loop D with gradients (IDR:261-396, self.training branches)
 # ------------------------------------------------------------------------------------------------
+def colsum(a):
+    """a.sum(0) for a (P, n) stream of the training step: one pass at HBM speed on the device (hip.colsum), torch elsewhere."""
+    if a.is_cuda and a.dtype == torch.float32:
+        from . import hip
+        return hip.colsum(a)
+    return a.sum(0)
+
+
+def _siren_grads(st, g_sdf, feat, sdf_w, sdf_b, freq, phase):
+    """Gradients of the emitted SIREN's 7 weights, 7 biases, FiLM frequencies and phases from the operand streams of the training
+    kernel (hip.shade_train_backward / sdf_normal_backward).  dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1}: the two pairs of a
+    layer lie next to each other (hip._sdf_streams), so a layer is ONE product over 2 n rows and layers 2..6 ONE batched split-K
+    launch.  db_k = sum adj v_k needs no pass over the samples at all: adj v_k = 30 f_k zb_k and the kernel already reduces
+    d phi_k = sum 30 zb_k (train.hpp, step 3), so db_k = f_k * d phi_k."""
+    avv, hh, h0 = st["avv"], st["hh"], st["h0"]
+    G, _, R, W = avv.shape
+    grads = []
+    n_in = sdf_w[0].shape[-1]
+    grads.append(gram(h0.reshape(2 * R, 4)[:, :n_in], avv[0].reshape(2 * R, W)).t().reshape(sdf_w[0].shape))
+    hidden = gram_grouped(avv[1:].reshape(G - 1, 2 * R, W), hh.reshape(G - 1, 2 * R, W))
+    grads += [hidden[k].reshape(sdf_w[k + 1].shape) for k in range(G - 1)]
+    grads.append((gram(g_sdf.reshape(-1, 1), feat) + colsum(st["hd"][6]).unsqueeze(0)).reshape(sdf_w[6].shape))
+    db = st["film_phase"] * freq.reshape(st["film_phase"].shape)
+    grads += [db[k].reshape(sdf_b[k].shape) for k in range(6)]
+    grads.append(g_sdf.sum().reshape(sdf_b[6].shape))
+    grads.append(st["film_freq"].reshape(freq.shape))
+    grads.append(st["film_phase"].reshape(phase.shape))
+    return grads
+
+
 class ShadeSamples(torch.autograd.Function):
     """Per-sample part of loop D as ONE custom op on the HIP kernels (csrc/train.hpp): SDF value, normal, colour in
     the forward; in the backward the kernel recomputes the forward, sweeps the colour MLP and the SIREN backwards
@@ -151,19 +181,8 @@ class ShadeSamples(torch.autograd.Function):
                                       kept=ctx.kept)
         sdf_w, sdf_b = params[0:7], params[7:14]
         col_w, col_b, pose = params[16:22], params[22:28], params[28]
-        grads = []
-        # ---- SIREN: dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1}
-        for k in range(6):
-            n_in = sdf_w[k].shape[-1]
-            grads.append((gram(st["av"][k], st["h"][k][:, :n_in]) + gram(st["avd"][k], st["hd"][k][:, :n_in]))
-                         .reshape(sdf_w[k].shape))
         feat = st["cin"][:, :256]
-        grads.append((gram(g_sdf.reshape(-1, 1), feat) + st["hd"][6].sum(0, keepdim=True)).reshape(sdf_w[6].shape))
-        for k in range(6):
-            grads.append(st["av"][k].sum(0).reshape(sdf_b[k].shape))
-        grads.append(g_sdf.sum().reshape(sdf_b[6].shape))
-        grads.append(st["film_freq"].reshape(params[14].shape))
-        grads.append(st["film_phase"].reshape(params[15].shape))
+        grads = _siren_grads(st, g_sdf, feat, sdf_w, sdf_b, params[14], params[15])
         # ---- colour MLP: dW_l = delta_l^T X_l; stream columns are [feat | x | n | PE(view) | 0]
         idr = meta["mode"] == "idr"
         n_pose = meta["n_pose"]
@@ -177,16 +196,19 @@ class ShadeSamples(torch.autograd.Function):
             parts += [m[:, 259:262], m[:, :256]]
             return parts
 
-        s0, s3 = d[0].sum(0), d[3].sum(0)
+        # the four 256-wide deltas travel as one buffer (hip.shade_train_backward: dd = delta_1, delta_4, delta_0, delta_3; cc = c_1,
+        # c_4, c_2, c_5): their column sums are one reduction, delta_1^T c_1 and delta_4^T c_4 one batched product
+        s1, s4, s0, s3 = (colsum(st["dd"][i]) for i in range(4))   # padding rows are zero
+        g14 = gram_grouped(st["dd"][0:2], st["cc"][0:2])
         m0 = to_reference_columns(gram(d[0], cin))
         m3 = to_reference_columns(gram(d[3], cin))
         if n_pose:
             m0.append(torch.outer(s0, pose.reshape(-1)))
             m3.append(torch.outer(s3, pose.reshape(-1)))
         m3.append(gram(d[3], c[2]))
-        gw = [torch.cat(m0, dim=1), gram(d[1], c[0]), gram(d[2], c[1]), torch.cat(m3, dim=1), gram(d[4], c[3]),
+        gw = [torch.cat(m0, dim=1), g14[0], gram(d[2], c[1]), torch.cat(m3, dim=1), g14[1],
               gram(d[5][:, :3], c[4])]
-        gb = [s0, d[1].sum(0), d[2].sum(0), s3, d[4].sum(0), d[5][:, :3].sum(0)]
+        gb = [s0, s1, colsum(d[2]), s3, s4, colsum(d[5][:, :3])]
         grads += [g.reshape(w.shape) for g, w in zip(gw, col_w)]
         grads += [g.reshape(b.shape) for g, b in zip(gb, col_b)]
         if n_pose:
@@ -218,17 +240,7 @@ class SdfNormal(torch.autograd.Function):
         g_sdf, g_n = g_sdf.contiguous(), g_n.contiguous()
         st = hip.sdf_normal_backward(ctx.meta["frame"], ctx.meta["ws"], x, g_sdf, g_n)
         sdf_w, sdf_b = params[0:7], params[7:14]
-        grads = []
-        for k in range(6):   # dW_k = adj(v_k)^T h_{k-1} + adj(vd_k)^T hd_{k-1}
-            n_in = sdf_w[k].shape[-1]
-            grads.append((gram(st["av"][k], st["h"][k][:, :n_in]) + gram(st["avd"][k], st["hd"][k][:, :n_in]))
-                         .reshape(sdf_w[k].shape))
-        grads.append((gram(g_sdf.reshape(-1, 1), st["feat"]) + st["hd"][6].sum(0, keepdim=True)).reshape(sdf_w[6].shape))
-        for k in range(6):
-            grads.append(st["av"][k].sum(0).reshape(sdf_b[k].shape))
-        grads.append(g_sdf.sum().reshape(sdf_b[6].shape))
-        grads.append(st["film_freq"].reshape(params[14].shape))
-        grads.append(st["film_phase"].reshape(params[15].shape))
+        grads = _siren_grads(st, g_sdf, st["feat"], sdf_w, sdf_b, params[14], params[15])
         return (None, st["gx4"][:, :3]) + tuple(grads)
 
 
@@ -327,8 +339,13 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
                 x_hat = unnormalize_canonical_points(pd, coord_min, coord_max, center)
                 x_lbs, _ = forward_skinning(x_hat, coord_min, coord_max, center, idhr.skinning_model, bone_transforms)
                 span = (coord_max.reshape(-1)[0] - coord_min.reshape(-1)[0]) * 1.1 / 2.0     # d x_hat / d pi
-                J = hip.skin_jacobian(frame, ws, x_hat[0]) * span
-                Jinv = torch.linalg.inv(J).unsqueeze(0)
+                J = hip.skin_jacobian(frame, ws, x_hat[0])
+                if os.environ.get("ARAH_TRAIN_INV3", "1") != "0":
+                    # (J span)^-1 = J^-1 / span: cofactors in one launch (the batched LU of torch.linalg.inv is four kernels and
+                    # 0.5 ms for these 1.2e5 well-conditioned matrices); span stays on the device
+                    Jinv = (hip.inverse3x3(J) / span).unsqueeze(0)
+                else:
+                    Jinv = torch.linalg.inv(J * span).unsqueeze(0)
                 pi = pd - mv3(Jinv, x_lbs - x_lbs.detach())
             elif idhr.train_skinning_net:
                 # x_hat is a root of LBS(x_hat) = x_bar found without a graph; re-attach it with the implicit

@@ -376,6 +376,20 @@ int arah_gemv_rows(const float* W, int32_t n_rows, int32_t n_cols, const float* 
 int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int32_t ldb, int32_t n, int32_t n_rows,
                      float* partial, void* stream);
 
+/* y[c] = sum over rows r of scale[r] * a[r*lda + c] (scale NULL: 1), c < n_cols: the bias gradients of the training step's tall
+ * layers (sums of per-sample deltas over ~1.2e5 samples) and, with scale = the upstream gradient g and a = a hypernetwork head's
+ * weight matrix [in*out + out][256], the head's input gradient g W -- the reference leaves both to autograd (sum / mm backward
+ * of hyperlayers.py:418-465 and of the skinning decoder).  partial: arah_colsum_blocks(n_rows) * n_cols floats of scratch; the
+ * partial sums are added in block order (deterministic).  One pass over `a` at HBM speed, no host synchronisation. */
+int32_t arah_colsum_blocks(int64_t n_rows);
+int arah_colsum(const float* a, int64_t lda, int32_t n_cols, int64_t n_rows, const float* scale, float* partial, float* y,
+                void* stream);
+
+/* inv[p] = (scale * m[p])^-1 for n row-major 3 x 3 matrices (cofactors): the Jacobians d x_bar / d x_hat of the implicit
+ * re-attachment of the canonical points to the skinning network (implicit_differentiable_renderer.py:315-334, torch.inverse
+ * there).  A singular matrix gives non-finite entries, as torch.inverse does on the device. */
+int arah_inverse3x3(const float* m, int32_t n, float scale, float* inv, void* stream);
+
 /* Mesh queries of the training data path (zju_mocap.py:461-543): for every query point the closest point of the triangle
  * mesh -- squared distance, face (lowest index on ties), the point, barycentric weights of the face's three vertices
  * (igl.point_mesh_squared_distance + igl.barycentric_coordinates_tri) -- and containment exactly as

@@ -1357,6 +1357,47 @@ def test_gemv_rows_against_torch():
 
 
 @gpu
+def test_colsum_inverse3x3_and_the_wide_head_op():
+    """Round 6's helpers of the training step: arah_colsum (column sums / g W at HBM speed, any width, strided rows) against
+    float64 sums; arah_inverse3x3 against torch.linalg.inv; the wide hypernetwork head as one op (nets._WideHead: gemv_rows
+    forward, colsum backward) against F.linear's autograd; tall.gram_grouped against a float64 bmm."""
+    from arah_release_amd import hip, nets, tall
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for R, n in ((1, 25), (127, 25), (100003, 25), (100003, 256), (4097, 304), (65792, 256), (513, 7)):
+        a = torch.randn(R, n + 3, generator=g).to(dev)[:, :n]          # row stride n + 3
+        sc = torch.randn(R, generator=g).to(dev)
+        for scale in (None, sc):
+            ref = (a.double() * (1.0 if scale is None else scale.double()[:, None])).sum(0)
+            got = hip.colsum(a, scale).double()
+            assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max() + R ** 0.5), (R, n, scale is None)
+        ac = a.contiguous()
+        assert float((hip.colsum(ac).double() - ac.double().sum(0)).abs().max()) <= 1e-5 * float(R ** 0.5 + 1)
+    m = torch.randn(5000, 3, 3, generator=g).to(dev) * 0.2 + torch.eye(3, device=dev)
+    ref = torch.linalg.inv(m.double() * 0.55)
+    got = hip.inverse3x3(m, 0.55).double()
+    assert float(((got - ref).abs() / (ref.abs().amax((1, 2), keepdim=True))).max()) <= 2e-5
+    # the wide head
+    W = (torch.randn(65792, 256, generator=g) * 0.02).to(dev).requires_grad_(True)
+    b = torch.randn(65792, generator=g).to(dev).requires_grad_(True)
+    init = torch.randn(1, 65792, generator=g).to(dev)
+    h = torch.randn(1, 256, generator=g).to(dev).requires_grad_(True)
+    up = torch.randn(1, 65792, generator=g).to(dev)
+    out = nets._WideHead.apply(h, W, b, init)
+    gh, gW, gb = torch.autograd.grad(out, (h, W, b), up)
+    ref_out = torch.nn.functional.linear(h.double(), W.double(), b.double()) + init.double()
+    rh, rW, rb = torch.autograd.grad(ref_out, (h, W, b), up.double())
+    for got, ref in ((out, ref_out), (gh, rh), (gW, rW), (gb, rb)):
+        assert got.shape == ref.shape
+        assert float((got.double() - ref.double()).abs().max()) <= 2e-5 * float(ref.abs().max() + 1e-9)
+    # grouped split-K products (zero padding rows)
+    a3 = torch.randn(3, 2 * 6464, 256, generator=g).to(dev)
+    b3 = torch.randn(3, 2 * 6464, 128, generator=g).to(dev)
+    ref = torch.bmm(a3.double().transpose(1, 2), b3.double())
+    assert float((tall.gram_grouped(a3, b3).double() - ref).abs().max()) <= 2e-4 * float(ref.abs().max())
+
+
+@gpu
 def test_gram_skinny_and_split_k_gram():
     """Weight-gradient products of the training step: the one-pass skinny kernel and the batched split-K product
     against a float64 matmul (column slices of wider streams, ragged row counts)."""

@@ -43,6 +43,17 @@ def main():
     t1 = time.perf_counter()
     print(json.dumps({"graph": os.environ.get("ARAH_TRAIN_HYPERNET_GRAPH", "0"), "ms_per_step": 1e3 * (t1 - t0) / steps,
                       "host_cpu_ms_per_step_until_last_enqueue": 1e3 * (c1 - c0) / steps, "steps": steps}))
+    if os.environ.get("TRAIN_HOST_CPROFILE"):   # where the Python side of the step goes (the autograd engine's thread is not seen)
+        import cProfile, pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for k in range(warm, warm + steps):
+            step(batches[k])
+        pr.disable()
+        torch.cuda.synchronize()
+        for key in ("tottime", "cumulative"):
+            print("==== cProfile of %d steps, sorted by %s" % (steps, key))
+            pstats.Stats(pr).strip_dirs().sort_stats(key).print_stats(70)
 
 
 if __name__ == "__main__":
