@@ -4422,7 +4422,7 @@ int arah_gram_skinny(const float* a, int32_t lda, int32_t m, const float* b, int
 // and a = the 65 792 x 256 weight matrix of a hypernetwork head, the head's input gradient g W (the GEMM library runs that
 // batch-1 product at 0.5 TB/s, torch's reduction a 25-wide sum at 0.04).  One pass at HBM speed: a workgroup reduces kColRows
 // rows into partial[block][n_cols] (fixed order), k_colsum_finish adds the partials up in block order: deterministic.
-constexpr int kColRows = 128;
+constexpr int kColRows = 256;
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, long long lda, int n, long long n_rows,
                                                 const float* __restrict__ scale, float* __restrict__ partial) {
     __shared__ float red[256 * 4];
@@ -4468,19 +4468,19 @@ __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ a, lon
         __syncthreads();
     }
 }
-// sixteen columns x sixteen row lanes per workgroup: lane (rl, c) adds partial[rl], partial[rl + 16], ... of its column, the sixteen
-// lane sums are added in lane order -- a fixed order, and ~60 dependent additions per thread instead of ~1000
+// eight columns x thirty-two row lanes per workgroup: lane (rl, c) adds partial[rl], partial[rl + 32], ... of its column, the
+// lane sums are added in lane order -- a fixed order, and ~15 dependent additions per thread instead of ~500
 __global__ __launch_bounds__(256) void k_colsum_finish(const float* __restrict__ partial, int blocks, int n, float* __restrict__ y) {
     __shared__ float red[256];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 8 + (threadIdx.x & 7), rl = threadIdx.x >> 3;
     float s = 0.f;
     if (c < n)
-        for (int b = rl; b < blocks; b += 16) s += partial[(size_t)b * n + c];
+        for (int b = rl; b < blocks; b += 32) s += partial[(size_t)b * n + c];
     red[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x < 16 && c < n) {
+    if (threadIdx.x < 8 && c < n) {
         float t = red[threadIdx.x];
-        for (int k = 1; k < 16; ++k) t += red[k * 16 + threadIdx.x];
+        for (int k = 1; k < 32; ++k) t += red[k * 8 + threadIdx.x];
         y[c] = t;
     }
 }
@@ -4497,7 +4497,7 @@ int arah_colsum(const float* a, int64_t lda, int32_t n_cols, int64_t n_rows, con
     }
     const int blocks = arah_colsum_blocks(n_rows);
     hipLaunchKernelGGL(k_colsum, dim3(blocks), dim3(256), 0, s, a, (long long)lda, n_cols, (long long)n_rows, scale, partial);
-    hipLaunchKernelGGL(k_colsum_finish, dim3((n_cols + 15) / 16), dim3(256), 0, s, (const float*)partial, blocks, n_cols, y);
+    hipLaunchKernelGGL(k_colsum_finish, dim3((n_cols + 7) / 8), dim3(256), 0, s, (const float*)partial, blocks, n_cols, y);
     return check_launch();
 }
 
@@ -4523,6 +4523,124 @@ int arah_inverse3x3(const float* m, int32_t n, float scale, float* inv, void* st
     if (!m || !inv || n < 0) return ARAH_E_BADARG;
     if (n == 0) return ARAH_OK;
     hipLaunchKernelGGL(k_inverse3x3, dim3((n + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), m, n, scale, inv);
+    return check_launch();
+}
+
+// ---- hierarchical softmax of the training step's skinning queries, with its backward (utils/utils.py:138-181) -------------
+// w = hsoftmax(scale * logits): a thread per point, the recursion of pointwise.hpp's hsoftmax written as a table of SPLITS
+// (parent keeps w (1 - gate), child gets w gate) so that the reverse sweep walks the same table backwards.  On autograd the
+// recursion is a gather of 240 factors per point and nine products (26 element-wise launches, a one-hot GEMM each way, ~1 ms
+// of GPU time per step for the 1.2e5 re-attached samples); here one launch each way, 12 MB in and 12 MB out.
+struct HsSplit {
+    unsigned char parent, child, gate;
+};
+__device__ constexpr HsSplit kHsA[8] = {{1, 4, 4}, {2, 5, 5}, {3, 6, 6}, {4, 7, 7}, {5, 8, 8}, {6, 9, 9}, {7, 10, 10}, {8, 11, 11}};
+__device__ constexpr HsSplit kHsB[9] = {{12, 15, 15}, {13, 16, 16}, {14, 17, 17}, {16, 18, 18}, {17, 19, 19},
+                                        {18, 20, 20}, {19, 21, 21}, {20, 22, 22}, {21, 23, 23}};
+
+extern "C++" {
+template <bool BWD>
+__global__ __launch_bounds__(128) void k_hsoftmax_train(const float* __restrict__ logits, int n, float scale,
+                                                        const float* __restrict__ g_w, float* __restrict__ out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    float sg[25], w[24], keep[18];   // keep: the parent's weight before each split (reverse sweep)
+    float xs[6];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) {
+        const float x = logits[(size_t)p * 25 + i] * scale;
+        sg[i] = sigm(x);
+        if (i >= 1 && i <= 3) xs[i - 1] = x;
+        if (i >= 12 && i <= 14) xs[i - 9] = x;
+    }
+    float h[3], c[3];
+    softmax3<float>(xs[0], xs[1], xs[2], h[0], h[1], h[2]);
+    softmax3<float>(xs[3], xs[4], xs[5], c[0], c[1], c[2]);
+    w[0] = 1.0f - sg[0];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[1 + k] = sg[0] * h[k];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const HsSplit s = kHsA[q];
+        keep[q] = w[s.parent];
+        w[s.child] = w[s.parent] * sg[s.gate];
+        w[s.parent] = w[s.parent] * (1.0f - sg[s.gate]);
+    }
+    const float w9 = w[9], t = w9 * sg[24];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) w[12 + k] = t * c[k];
+    w[9] = w9 * (1.0f - sg[24]);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const HsSplit s = kHsB[q];
+        keep[8 + q] = w[s.parent];
+        w[s.child] = w[s.parent] * sg[s.gate];
+        w[s.parent] = w[s.parent] * (1.0f - sg[s.gate]);
+    }
+    if (!BWD) {
+#pragma unroll
+        for (int k = 0; k < 24; ++k) out[(size_t)p * 24 + k] = w[k];
+        return;
+    }
+    float a[24], gs[25];   // adjoints of the weights (of their CURRENT versions while walking back) and of the gates
+#pragma unroll
+    for (int k = 0; k < 24; ++k) a[k] = g_w[(size_t)p * 24 + k];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) gs[i] = 0.f;
+#pragma unroll
+    for (int q = 8; q >= 0; --q) {
+        const HsSplit s = kHsB[q];
+        gs[s.gate] += keep[8 + q] * (a[s.child] - a[s.parent]);
+        a[s.parent] = a[s.child] * sg[s.gate] + a[s.parent] * (1.0f - sg[s.gate]);
+    }
+    float gc[3], at = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gc[k] = a[12 + k] * t;
+        at += a[12 + k] * c[k];
+    }
+    gs[24] += w9 * (at - a[9]);
+    a[9] = at * sg[24] + a[9] * (1.0f - sg[24]);
+#pragma unroll
+    for (int q = 7; q >= 0; --q) {
+        const HsSplit s = kHsA[q];
+        gs[s.gate] += keep[q] * (a[s.child] - a[s.parent]);
+        a[s.parent] = a[s.child] * sg[s.gate] + a[s.parent] * (1.0f - sg[s.gate]);
+    }
+    float gh[3], a0 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gh[k] = a[1 + k] * sg[0];
+        a0 += a[1 + k] * h[k];
+    }
+    gs[0] += a0 - a[0];
+    float gx[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) gx[i] = gs[i] * sg[i] * (1.0f - sg[i]);
+    const float dh = gh[0] * h[0] + gh[1] * h[1] + gh[2] * h[2], dc = gc[0] * c[0] + gc[1] * c[1] + gc[2] * c[2];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        gx[1 + k] += h[k] * (gh[k] - dh);
+        gx[12 + k] += c[k] * (gc[k] - dc);
+    }
+#pragma unroll
+    for (int i = 0; i < 25; ++i) out[(size_t)p * 25 + i] = gx[i] * scale;
+}
+}   // extern "C++"
+
+int arah_hsoftmax_train_forward(const float* logits, int32_t n, float scale, float* weights, void* stream) {
+    if (!logits || !weights || n < 0) return ARAH_E_BADARG;
+    if (n == 0) return ARAH_OK;
+    hipLaunchKernelGGL(k_hsoftmax_train<false>, dim3((n + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), logits, n,
+                       scale, (const float*)nullptr, weights);
+    return check_launch();
+}
+
+int arah_hsoftmax_train_backward(const float* logits, int32_t n, float scale, const float* g_weights, float* g_logits, void* stream) {
+    if (!logits || !g_weights || !g_logits || n < 0) return ARAH_E_BADARG;
+    if (n == 0) return ARAH_OK;
+    hipLaunchKernelGGL(k_hsoftmax_train<true>, dim3((n + 127) / 128), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), logits, n,
+                       scale, g_weights, g_logits);
     return check_launch();
 }
 

@@ -115,7 +115,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_colsum_blocks", "arah_colsum", "arah_inverse3x3", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
+           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_colsum_blocks", "arah_colsum", "arah_inverse3x3", "arah_hsoftmax_train_forward", "arah_hsoftmax_train_backward", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
            "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes",
            "arah_occupancy_bytes", "arah_prepare_occupancy", "arah_occupancy_info", "arah_tier_debug", "arah_debug_samples",
            "arah_sdf_grid_band_scratch_bytes", "arah_sdf_grid_band"]
@@ -1015,6 +1015,30 @@ def colsum(a, scale=None):
         _check(lib.arah_colsum(C.c_void_p(a.data_ptr()), C.c_int64(a.stride(0) if R > 1 else n), C.c_int32(n), C.c_int64(R),
                                _ptr(sc), _ptr(partial), _ptr(y), _stream()), "arah_colsum")
     return y
+
+
+def hsoftmax_train_forward(logits, scale):
+    """(n, 25) raw logits -> (n, 24) weights = hierarchical_softmax(scale * logits) (arah_hsoftmax_train_forward); no autograd."""
+    lib = load_library()
+    x = _f32(logits)
+    dev = _same_device(x)
+    with _on_device(dev):
+        w = torch.empty(x.shape[0], 24, device=dev)
+        _check(lib.arah_hsoftmax_train_forward(_ptr(x), C.c_int32(x.shape[0]), C.c_float(float(scale)), _ptr(w), _stream()),
+               "arah_hsoftmax_train_forward")
+    return w
+
+
+def hsoftmax_train_backward(logits, scale, g_w):
+    """d L / d logits (n, 25) for upstream gradients g_w (n, 24) on hierarchical_softmax(scale * logits)."""
+    lib = load_library()
+    x, g = _f32(logits), _f32(g_w)
+    dev = _same_device(x, g)
+    with _on_device(dev):
+        gx = torch.empty_like(x)
+        _check(lib.arah_hsoftmax_train_backward(_ptr(x), C.c_int32(x.shape[0]), C.c_float(float(scale)), _ptr(g), _ptr(gx),
+                                                _stream()), "arah_hsoftmax_train_backward")
+    return gx
 
 
 def inverse3x3(m, scale=1.0):

@@ -90,12 +90,33 @@ def hierarchical_softmax(x):
     return out.reshape(*lead, 24)
 
 
+class _HSoftmaxOp(torch.autograd.Function):
+    """hierarchical_softmax(scale * logits) as one launch each way (hip.hsoftmax_train_forward / _backward, csrc: k_hsoftmax_train)
+    for the skinning queries of a training step on the device; first-order autograd only."""
+
+    @staticmethod
+    def forward(ctx, logits, scale):
+        from . import hip
+        x = logits.reshape(-1, 25).contiguous()
+        ctx.save_for_backward(x)
+        ctx.scale = scale
+        return hip.hsoftmax_train_forward(x, scale).reshape(*logits.shape[:-1], 24)
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip
+        (x,) = ctx.saved_tensors
+        return hip.hsoftmax_train_backward(x, ctx.scale, g.reshape(-1, 24).contiguous()).reshape(*g.shape[:-1], 25), None
+
+
 def query_weights(x_hat, coord_min, coord_max, center, skinning_model):
     """(B,N,3) canonical points -> (B,N,24) skinning weights (root_finding_utils.py:54-113, 25-logit branch)."""
     logits = skinning_model.decode_w(normalize_canonical_points(x_hat, coord_min, coord_max, center),
                                      c=torch.empty(x_hat.shape[0], 0, device=x_hat.device))
     if logits.shape[-1] != 25:
         raise ValueError("Wrong output size of skinning network. Expected 25, got %d." % logits.shape[-1])
+    if logits.is_cuda and logits.dtype == torch.float32 and os.environ.get("ARAH_TRAIN_HSOFTMAX_OP", "1") != "0":
+        return _HSoftmaxOp.apply(logits, 20.0)
     return hierarchical_softmax(logits * 20.0)
 
 

@@ -385,6 +385,13 @@ int32_t arah_colsum_blocks(int64_t n_rows);
 int arah_colsum(const float* a, int64_t lda, int32_t n_cols, int64_t n_rows, const float* scale, float* partial, float* y,
                 void* stream);
 
+/* Hierarchical softmax of the skinning queries of a training step with its backward (utils/utils.py:138-181, called from
+ * root_finding_utils.py:54-113 with the 25 logits x 20): weights [n][24] = hsoftmax(scale * logits [n][25]);
+ * g_logits [n][25] = d L / d logits for upstream gradients g_weights [n][24] (the forward is recomputed).  The reference runs the
+ * recursion on autograd. */
+int arah_hsoftmax_train_forward(const float* logits, int32_t n, float scale, float* weights, void* stream);
+int arah_hsoftmax_train_backward(const float* logits, int32_t n, float scale, const float* g_weights, float* g_logits, void* stream);
+
 /* inv[p] = (scale * m[p])^-1 for n row-major 3 x 3 matrices (cofactors): the Jacobians d x_bar / d x_hat of the implicit
  * re-attachment of the canonical points to the skinning network (implicit_differentiable_renderer.py:315-334, torch.inverse
  * there).  A singular matrix gives non-finite entries, as torch.inverse does on the device. */

@@ -1398,6 +1398,32 @@ def test_colsum_inverse3x3_and_the_wide_head_op():
 
 
 @gpu
+def test_hsoftmax_train_op_against_the_torch_recursion():
+    """training._HSoftmaxOp (one launch each way) against training.hierarchical_softmax on autograd in float64: weights and the
+    gradient of the logits, saturated gates and ties included."""
+    from arah_release_amd import training
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(21)
+    x = torch.randn(4099, 25, generator=g) * 0.4
+    x[:64] *= 10.0          # saturated gates (logits x 20 up to +-200)
+    x[64:80] = 0.0          # ties in both softmaxes
+    up = torch.randn(4099, 24, generator=g)
+    xd = x.double().to(dev).requires_grad_(True)
+    ref = training.hierarchical_softmax(xd * 20.0)
+    (ref_g,) = torch.autograd.grad(ref, xd, up.double().to(dev))
+    xf = x.to(dev).requires_grad_(True)
+    got = training._HSoftmaxOp.apply(xf, 20.0)
+    (got_g,) = torch.autograd.grad(got, xf, up.to(dev))
+    assert got.shape == ref.shape and got_g.shape == ref_g.shape
+    assert float((got.double() - ref).abs().max()) <= 2e-6
+    assert float((got.sum(-1) - 1.0).abs().max()) <= 1e-5
+    assert float((got_g.double() - ref_g).abs().max()) <= 2e-5 * float(ref_g.abs().max())
+    # and through query_weights' switch
+    lead = training._HSoftmaxOp.apply(xf.reshape(1, -1, 25), 20.0)
+    assert lead.shape == (1, 4099, 24) and torch.equal(lead[0], got)
+
+
+@gpu
 def test_gram_skinny_and_split_k_gram():
     """Weight-gradient products of the training step: the one-pass skinny kernel and the batched split-K product
     against a float64 matmul (column slices of wider streams, ragged row counts)."""
