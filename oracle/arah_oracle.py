@@ -356,23 +356,41 @@ def trace_rays(fr, o, d, near, far, eval_mode=True):
 
 
 # ----------------------------------------------------------------------------- sampling + loop C
+def perturb_z_vals(z, t_rand, fix_idx=None):
+    """Stratified jitter inside the intervals between neighbouring samples (RT:298-311).  t_rand: the uniform draws the
+    reference takes from torch.rand (same shape as z); fix_idx: a column that stays at its interval's midpoint (RT:305-307)."""
+    mids = 0.5 * (z[..., 1:] + z[..., :-1])
+    upper = torch.cat([mids, z[..., -1:]], dim=-1)
+    lower = torch.cat([z[..., :1], mids], dim=-1)
+    t = t_rand.clone()
+    if fix_idx is not None:
+        t[..., fix_idx] = 0.5
+    return lower + (upper - lower) * t
+
+
 def sample_depths(conv, start, end, near, n_steps, n_near, n_far, jitter=None):
-    """Depth samples per ray (RT:313-350), eval mode (``jitter`` is None): returns z (N,S), mask (N,S)."""
-    if jitter is not None:
-        raise NotImplementedError("training-time stratified jitter is not part of the oracle yet")
+    """Depth samples per ray (RT:313-350): returns z (N,S), mask (N,S).  ``jitter`` None: eval mode.  Training mode
+    (RT:319-320, 332-333, 344-345): jitter = (rand_steps (N,S), rand_near (N,n_near+1), rand_far (N,n_far)), the three
+    torch.rand draws of the reference in its order; the surface sample itself (column n_near // 2) is not perturbed."""
     N = start.shape[0]
     lin = torch.linspace(0.0, 1.0, n_steps, dtype=torch.float32)
     z = start[:, None] + (end - start)[:, None] * lin
+    if jitter is not None:
+        z = perturb_z_vals(z, jitter[0])
     mask = torch.ones(N, n_steps, dtype=torch.bool)
     if n_near > 0 or n_far > 0:
         lin_s = torch.linspace(0.0, 1.0, n_near + 1, dtype=torch.float32)
         zs = start[:, None] - SURFACE_RANGE + SURFACE_RANGE * 2 * lin_s
+        if jitter is not None:
+            zs = perturb_z_vals(zs, jitter[1], fix_idx=n_near // 2)
         n_c = n_near + 1
         block = zs
         if n_far > 0:
             lin_f = torch.linspace(0.0, 1.0, n_far, dtype=torch.float32)
             span = torch.maximum(start - SURFACE_RANGE - near, torch.tensor(1e-5))
             zf = near[:, None] + span[:, None] * lin_f
+            if jitter is not None:
+                zf = perturb_z_vals(zf, jitter[2])
             block = torch.sort(torch.cat([zs, zf], dim=-1), dim=-1)[0]
             n_c = n_near + 1 + n_far
         z[conv, :n_c] = block[conv]

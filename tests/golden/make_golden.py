@@ -20,6 +20,7 @@ Fixtures:
   f7_forward_<cfg>.npz whole MetaAvatarRender.forward(eval=True) dict for small frames
   f8_train_step_*.npz  training forward + IDHRLoss + backward: outputs, loss terms, per-parameter gradient norms,
                        and the reference's recorded torch.rand draws
+  f19_jitter_depths.npz the training-time depth sampler (perturb_z_vals / ray_sampler's z_vals) with its draws -- `make_golden.py f19`
 """
 import os
 import sys
@@ -851,7 +852,48 @@ def make_f18():
          normal_cano_back=out["normal_cano_back"].numpy().astype(np.float32))
 
 
+def make_f19():
+    """F19: the training-time depth sampler alone (ray_tracing.py:298-350: perturb_z_vals + ray_sampler's z_vals) -- the
+    reference's BodyRayTracing.ray_sampler called with its canonicalisation stubbed out (generate_point_samples_opt is F5's
+    business), its three torch.rand draws recorded.  Rays with and without a surface hit, a surface closer to the near bound
+    than the surface range (the 1e-5 floor of RT:346), two sampling configurations."""
+    from im2mesh.metaavatar_render.renderer.ray_tracing import BodyRayTracing
+    out = {}
+    for tag, (S, n_near, n_far) in (("s64", (64, 16, 16)), ("s32", (32, 8, 8))):
+        g = torch.Generator().manual_seed(77 + S)
+        N = 257
+        near = 2.0 + torch.rand(1, N, generator=g)
+        far = near + 0.5 + torch.rand(1, N, generator=g)
+        conv = torch.rand(1, N, generator=g) > 0.4
+        surf = near + (far - near) * torch.rand(1, N, generator=g)
+        surf[0, :8] = near[0, :8] + 0.01                      # closer to the near bound than the 5 cm surface range
+        start = torch.where(conv, surf, near)
+        tracer = BodyRayTracing(n_steps=S, near_surface_vol_samples=n_near, far_surface_vol_samples=n_far)
+        tracer.generate_point_samples_opt = lambda *a, **k: (None, None, None)
+        draws, orig = [], torch.rand
+
+        def recording_rand(*a, **k):
+            t = orig(*a, **k)
+            draws.append(t.detach().clone())
+            return t
+
+        torch.manual_seed(4321 + S)
+        torch.rand = recording_rand
+        try:
+            _, _, _, z = tracer.ray_sampler(None, None, None, conv, None, torch.stack([start, far], dim=-1),
+                                            torch.stack([near, far], dim=-1), torch.ones_like(conv), *([None] * 11), eval_mode=False)
+        finally:
+            torch.rand = orig
+        assert [tuple(d.shape) for d in draws] == [(1, N, S), (1, N, n_near + 1), (1, N, n_far)], [tuple(d.shape) for d in draws]
+        out.update({tag + ".conv": conv[0], tag + ".start": start[0], tag + ".end": far[0], tag + ".near": near[0],
+                    tag + ".rand_steps": draws[0][0], tag + ".rand_near": draws[1][0], tag + ".rand_far": draws[2][0],
+                    tag + ".z": z[0], tag + ".cfg": torch.tensor([S, n_near, n_far])})
+    save("f19_jitter_depths.npz", **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "f19":
+        return make_f19()
     if len(sys.argv) > 1 and sys.argv[1] == "f18":
         return make_f18()
     if len(sys.argv) > 1 and sys.argv[1] == "f7full":

@@ -1398,6 +1398,36 @@ def test_colsum_inverse3x3_and_the_wide_head_op():
 
 
 @gpu
+@pytest.mark.parametrize("tag", ["s64", "s32"])
+def test_training_time_depth_jitter_against_reference(scene, tag):
+    """arah_sample_canonicalize with the three draws of the training path (rand_*): its depths against the reference's own
+    z_vals for the same draws (f19, ray_tracing.py:298-350)."""
+    from arah_release_amd import config, hip, renderer
+    g = golden("f19_jitter_depths.npz")
+    S, n_near, n_far = [int(v) for v in g[tag + ".cfg"]]
+    dev = torch.device("cuda:0")
+    model, cfg = config.build_synthetic_model("zju377_mono", S, n_near, n_far, device=dev)
+    inputs = scene.make_inputs(64, 64, frame_idx=0, device=dev)
+    t = lambda k: torch.from_numpy(np.asarray(g[tag + "." + k])).to(dev)
+    N = t("start").shape[0]
+    with torch.no_grad():
+        dec = model.sdf_decoder({"coords": torch.zeros(1, 1, 3, device=dev), "rots": inputs["rots"][:1],
+                                 "Jtrs": inputs["Jtrs"][:1], "latent": model.latent(inputs["geo_latent_code_idx"])})
+        pose_cond = dict(inputs["pose_cond"])
+        pose_cond["latent_code"] = model.latent(pose_cond["latent_code_idx"])
+        frame = renderer.build_frame(dec["decoder"], model.skinning_model, model.color_decoder, model.deviation_decoder,
+                                     pose_cond, inputs["smpl_verts"], inputs["skinning_weights"], inputs["bone_transforms"],
+                                     inputs["trans"], inputs["coord_min"], inputs["coord_max"], inputs["center"])
+    samp = hip.Sampling(dev, S, n_near, n_far, cfg["model"]["cano_view_dirs"], False)
+    dirs = inputs["ray_dirs"][0][:N].contiguous()
+    near_far = torch.stack([t("near"), t("end")], dim=-1).contiguous()
+    z, _, _, _ = hip.sample_canonicalize(frame, hip.Workspace(dev), samp, inputs["cam_loc"][:1], dirs, near_far,
+                                         t("conv").to(torch.uint8), t("start"), t("end"),
+                                         rand=(t("rand_steps"), t("rand_near"), t("rand_far")))
+    np.testing.assert_allclose(z.cpu().numpy(), g[tag + ".z"], rtol=0, atol=2e-6)
+
+
+@gpu
 def test_hsoftmax_train_op_against_the_torch_recursion():
     """training._HSoftmaxOp (one launch each way) against training.hierarchical_softmax on autograd in float64: weights and the
     gradient of the logits, saturated gates and ties included."""

@@ -202,3 +202,24 @@ def test_f7_full_frames_on_a_ray_subset(scene, fname, n_sub, name):
     assert (hit == hit_ref).mean() >= 0.995
     both = hit & hit_ref
     assert (np.abs(out["points_cam"].numpy()[both] - g["points_cam"][sel][both]).max(-1) <= 2e-4).mean() >= 0.999
+
+
+@pytest.mark.parametrize("tag", ["s64", "s32"])
+def test_f19_training_time_depth_jitter(tag):
+    """The oracle's stratified jitter (perturb_z_vals / the training branches of ray_sampler, RT:298-350) against the
+    reference's own z_vals for its own recorded torch.rand draws (f19: rays with and without a surface hit, surfaces closer
+    to the near bound than the surface range)."""
+    g = golden("f19_jitter_depths.npz")
+    S, n_near, n_far = [int(v) for v in g[tag + ".cfg"]]
+    t = lambda k: torch.from_numpy(np.asarray(g[tag + "." + k]))
+    z, mask = O.sample_depths(t("conv").bool(), t("start"), t("end"), t("near"), S, n_near, n_far,
+                              jitter=(t("rand_steps"), t("rand_near"), t("rand_far")))
+    ref = g[tag + ".z"]
+    assert z.shape == ref.shape
+    np.testing.assert_allclose(z.numpy(), ref, rtol=0, atol=1e-6)
+    conv = g[tag + ".conv"].astype(bool)
+    assert bool(mask[~conv].all()) and int(mask[conv].sum(-1).unique()) == n_near + 1 + n_far
+    # eval mode is the same call without draws and differs from it
+    z0, _ = O.sample_depths(t("conv").bool(), t("start"), t("end"), t("near"), S, n_near, n_far)
+    assert float((z0 - z).abs().max()) > 1e-3
+
