@@ -784,7 +784,10 @@ KIN_PAD = {COLOR_NO_VIEW_DIR: 272, COLOR_IDR: 304}   # colour input [feat(256) |
 def _grouped(groups, n, width, device, inner=None):
     """(groups[, inner], roundup(n, 64), width) floats whose padding rows are zero: the operand streams of products over the sample
     axis that travel together (see tall.gram_grouped).  The kernels write rows [0, n) of each slice."""
-    n_pad = (n + 63) // 64 * 64
+    # a step's sample count moves by a few hundred from frame to frame: rounded up to 8192 / 2048 rows the gigabyte-sized groups
+    # come in one or two sizes and torch's allocator hands the same blocks out again (rounded to 64 only, every other step of
+    # bench.py's training line paid a 35 ms device allocation)
+    n_pad = (n + 8191) // 8192 * 8192 if n >= 65536 else ((n + 2047) // 2048 * 2048 if n >= 16384 else (n + 63) // 64 * 64)
     shape = (groups, n_pad, width) if inner is None else (groups, inner, n_pad, width)
     buf = torch.empty(*shape, device=device)
     if n_pad > n:

@@ -434,9 +434,9 @@ class IDHRNetwork(nn.Module):
         use_hip_shading = os.environ.get("ARAH_TRAIN_AUTOGRAD", "0") != "1"
         # (Round 6 tried the skinning-weight query of the loss and the regulariser queries on a side stream next to the ray
         # tracer's dependent chains: no gain -- 23.4-23.5 ms per step either way, and 12 ms more CPU in the waits between the
-        # streams of the backward; removed.)
-        if "points_skinning" in input:
-            pred_weights = training.query_weights(input["points_skinning"], cmin, cmax, center, self.skinning_model)
+        # streams of the backward; removed.  What does pay is the ORDER on the one stream: the query's ~50 launches are issued
+        # behind the tracer's, while the GPU works through loops A-C and this thread would otherwise wait for them at the
+        # compaction below -- see further down.)
         # one packed frame per step serves the ray tracer (loops A-C) and the hand-written loop-D op
         frame = None
         if ray_dirs.is_cuda:   # (CPU: only reachable with a stubbed ray tracer, e.g. the gloo DDP test; autograd loop D)
@@ -462,6 +462,8 @@ class IDHRNetwork(nn.Module):
             uniform_sdf = sdf_probe[B * n_reg:2 * B * n_reg, :].reshape(B, n_reg, 1)
             grad_eik = torch.autograd.grad(sdf_probe, probe, torch.ones_like(sdf_probe), create_graph=True,
                                            retain_graph=True)[0][:B * n_reg]
+        if "points_skinning" in input:   # (the loss' skinning term, models/__init__.py:228-231; independent of everything above)
+            pred_weights = training.query_weights(input["points_skinning"], cmin, cmax, center, self.skinning_model)
         vol_mask = s_mask.any(-1)
         dirs_in, ray_augm = ray_dirs, False
         if "view_noise" in pose_cond:
