@@ -658,8 +658,8 @@ class GpuRuntime:
                 "ms_each_step": each,
                 "device_allocations_in_the_timed_steps": int(stats1.get("num_device_alloc", 0) - stats0.get("num_device_alloc", 0)),
                 "device_frees_in_the_timed_steps": int(stats1.get("num_device_free", 0) - stats0.get("num_device_free", 0)),
-                "host_note": "CPU time of this process until the last step was enqueued (the step is ~1100 launches, 24.9 ms of kernels, "
-                             "~27-30 ms of host time).  Earlier in round 5 this line came back at 60-65 ms every other run: the step's "
+                "host_note": "CPU time of this process until the last step was enqueued (round 6: the step is ~910 launches, 19.3 ms of "
+                             "kernels, ~22 ms of host time incl. its waits; round 5: 1100 launches, 24.9 ms of kernels).  Earlier in round 5 this line came back at 60-65 ms every other run: the step's "
                              "350 MB gradient blocks were device allocations / frees inside the timed steps when the inference passes "
                              "had left torch's allocator full of other sizes; the line now starts from an empty cache with four warm-up "
                              "steps (4 of 4 runs 24.6-25.8 ms, profiles/r05_train_host.txt)"}
