@@ -4675,6 +4675,113 @@ int arah_hsoftmax_train_backward(const float* logits, int32_t n, float scale, co
     return check_launch();
 }
 
+// ---- the hierarchical pose encoder of a training step as one launch each way (siren_modules.py:196-244) --------------------
+// 24 joints, each a 19 -> 19 -> ReLU -> 6 MLP on [own(13) | feature of the parent (6)] (the root: the global feature), walked down
+// the kinematic tree.  11 kFLOP -- and, level by level on autograd, ~70 launches forward and ~130 backward of a step whose host
+// side is its bottleneck.  One workgroup: the joints in index order (SMPL numbers parents before children), a thread per output
+// unit; the reverse sweep walks the joints backwards and hands each joint's input adjoint to its parent.
+constexpr int kPtIn = 19, kPtHid = 19, kPtOut = 6, kPtOwn = 13, kPtMaxJoints = 64;
+struct PoseTreeParents {
+    signed char p[kPtMaxJoints];
+};
+__global__ __launch_bounds__(64) void k_pose_tree_fwd(const float* __restrict__ own, const float* __restrict__ glob,
+                                                      const float* __restrict__ W1, const float* __restrict__ b1,
+                                                      const float* __restrict__ W2, const float* __restrict__ b2,
+                                                      PoseTreeParents par, int J, float* __restrict__ feats, float* __restrict__ hid) {
+    __shared__ float f[kPtMaxJoints][kPtOut], x[kPtIn], h[kPtHid];
+    const int t = threadIdx.x;
+    for (int j = 0; j < J; ++j) {
+        if (t < kPtOwn) x[t] = own[j * kPtOwn + t];
+        else if (t < kPtIn) x[t] = par.p[j] < 0 ? glob[t - kPtOwn] : f[par.p[j]][t - kPtOwn];
+        __syncthreads();
+        if (t < kPtHid) {
+            float a = b1[j * kPtHid + t];
+            for (int k = 0; k < kPtIn; ++k) a = fmaf(W1[(j * kPtHid + t) * kPtIn + k], x[k], a);
+            a = fmaxf(a, 0.f);
+            h[t] = a;
+            hid[j * kPtHid + t] = a;
+        }
+        __syncthreads();
+        if (t < kPtOut) {
+            float a = b2[j * kPtOut + t];
+            for (int k = 0; k < kPtHid; ++k) a = fmaf(W2[(j * kPtOut + t) * kPtHid + k], h[k], a);
+            f[j][t] = a;
+            feats[j * kPtOut + t] = a;
+        }
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64) void k_pose_tree_bwd(const float* __restrict__ own, const float* __restrict__ glob,
+                                                      const float* __restrict__ W1, const float* __restrict__ W2,
+                                                      PoseTreeParents par, int J, const float* __restrict__ feats,
+                                                      const float* __restrict__ hid, const float* __restrict__ g_feats,
+                                                      float* __restrict__ gW1, float* __restrict__ gb1, float* __restrict__ gW2,
+                                                      float* __restrict__ gb2, float* __restrict__ g_glob) {
+    __shared__ float adj[kPtMaxJoints][kPtOut], gg[kPtOut], x[kPtIn], h[kPtHid], dh[kPtHid], df[kPtOut];
+    const int t = threadIdx.x;
+    for (int i = t; i < J * kPtOut; i += blockDim.x) adj[i / kPtOut][i % kPtOut] = g_feats[i];
+    if (t < kPtOut) gg[t] = 0.f;
+    __syncthreads();
+    for (int j = J - 1; j >= 0; --j) {
+        if (t < kPtOwn) x[t] = own[j * kPtOwn + t];
+        else if (t < kPtIn) x[t] = par.p[j] < 0 ? glob[t - kPtOwn] : feats[par.p[j] * kPtOut + t - kPtOwn];
+        if (t < kPtHid) h[t] = hid[j * kPtHid + t];
+        if (t < kPtOut) df[t] = adj[j][t];
+        __syncthreads();
+        if (t < kPtHid) {
+            float a = 0.f;
+            for (int o = 0; o < kPtOut; ++o) a = fmaf(W2[(j * kPtOut + o) * kPtHid + t], df[o], a);
+            a = h[t] > 0.f ? a : 0.f;
+            dh[t] = a;
+            gb1[j * kPtHid + t] = a;
+            for (int o = 0; o < kPtOut; ++o) gW2[(j * kPtOut + o) * kPtHid + t] = df[o] * h[t];
+        }
+        if (t < kPtOut) gb2[j * kPtOut + t] = df[t];
+        __syncthreads();
+        if (t < kPtHid)
+            for (int k = 0; k < kPtIn; ++k) gW1[(j * kPtHid + t) * kPtIn + k] = dh[t] * x[k];
+        if (t >= kPtOwn && t < kPtIn) {      // the parent's feature was this joint's input k = t
+            float a = 0.f;
+            for (int i = 0; i < kPtHid; ++i) a = fmaf(W1[(j * kPtHid + i) * kPtIn + t], dh[i], a);
+            if (par.p[j] < 0) gg[t - kPtOwn] += a;
+            else adj[par.p[j]][t - kPtOwn] += a;
+        }
+        __syncthreads();
+    }
+    if (t < kPtOut) g_glob[t] = gg[t];
+}
+
+static int pose_tree_parents(const int32_t* parents, int32_t n_joints, PoseTreeParents& par) {
+    if (!parents || n_joints < 1 || n_joints > kPtMaxJoints) return ARAH_E_BADARG;
+    for (int j = 0; j < n_joints; ++j) {
+        if (parents[j] >= j || parents[j] < -1) return ARAH_E_BADARG;    // parents precede their children
+        par.p[j] = (signed char)parents[j];
+    }
+    return ARAH_OK;
+}
+
+int arah_pose_tree_forward(const float* own, const float* glob, const float* W1, const float* b1, const float* W2,
+                           const float* b2, const int32_t* parents_host, int32_t n_joints, float* feats, float* hidden,
+                           void* stream) {
+    if (!own || !glob || !W1 || !b1 || !W2 || !b2 || !feats || !hidden) return ARAH_E_BADARG;
+    PoseTreeParents par;
+    if (int rc = pose_tree_parents(parents_host, n_joints, par)) return rc;
+    hipLaunchKernelGGL(k_pose_tree_fwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), own, glob, W1, b1, W2, b2, par,
+                       n_joints, feats, hidden);
+    return check_launch();
+}
+
+int arah_pose_tree_backward(const float* own, const float* glob, const float* W1, const float* W2, const int32_t* parents_host,
+                            int32_t n_joints, const float* feats, const float* hidden, const float* g_feats, float* gW1,
+                            float* gb1, float* gW2, float* gb2, float* g_glob, void* stream) {
+    if (!own || !glob || !W1 || !W2 || !feats || !hidden || !g_feats || !gW1 || !gb1 || !gW2 || !gb2 || !g_glob) return ARAH_E_BADARG;
+    PoseTreeParents par;
+    if (int rc = pose_tree_parents(parents_host, n_joints, par)) return rc;
+    hipLaunchKernelGGL(k_pose_tree_bwd, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), own, glob, W1, W2, par, n_joints,
+                       feats, hidden, g_feats, gW1, gb1, gW2, gb2, g_glob);
+    return check_launch();
+}
+
 // ---- the wide output layers of the SDF hypernetwork (hyperlayers.py:418-465) ----------------------------
 // y[r] = W[r, :] . x + b0[r] (+ b1[r]): a 256 -> 65 792 linear layer per emitted 256 x 256 SDF layer, 67 MB of weights that
 // are read once per frame -- 337 MB for the five hidden layers, a pure HBM stream.  The GEMM library runs these batch-1

@@ -115,7 +115,7 @@ EXPORTS = ["arah_frame_bytes", "arah_prepare_frame", "arah_body_bytes", "arah_pr
            "arah_counters_read", "arah_sdf_eval", "arah_sdf_grid", "arah_rasterize", "arah_skin_lbs", "arah_skin_jacobian", "arah_color_eval",
            "arah_nearest_inverse_lbs", "arah_broyden3_lbs", "arah_joint_root_find", "arah_trace", "arah_sample_canonicalize",
            "arah_shade_composite", "arah_shade_points", "arah_render", "arah_shade_train_slab_bytes", "arah_shade_train_forward",
-           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_colsum_blocks", "arah_colsum", "arah_inverse3x3", "arah_hsoftmax_train_forward", "arah_hsoftmax_train_backward", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
+           "arah_shade_train_backward", "arah_composite_train_forward", "arah_composite_train_backward", "arah_gram_skinny_blocks", "arah_gram_skinny", "arah_colsum_blocks", "arah_colsum", "arah_inverse3x3", "arah_hsoftmax_train_forward", "arah_hsoftmax_train_backward", "arah_pose_tree_forward", "arah_pose_tree_backward", "arah_gemv_rows", "arah_mesh_query_scratch_bytes", "arah_mesh_query", "arah_dominant_kernel",
            "arah_skin_lbs_counted", "arah_marching_cubes_scratch_bytes", "arah_marching_cubes",
            "arah_occupancy_bytes", "arah_prepare_occupancy", "arah_occupancy_info", "arah_tier_debug", "arah_debug_samples",
            "arah_sdf_grid_band_scratch_bytes", "arah_sdf_grid_band"]
@@ -1042,6 +1042,43 @@ def hsoftmax_train_backward(logits, scale, g_w):
         _check(lib.arah_hsoftmax_train_backward(_ptr(x), C.c_int32(x.shape[0]), C.c_float(float(scale)), _ptr(g), _ptr(gx),
                                                 _stream()), "arah_hsoftmax_train_backward")
     return gx
+
+
+def _parents_array(parents):
+    arr = (C.c_int32 * len(parents))(*[int(p) for p in parents])
+    return arr
+
+
+def pose_tree_forward(own, glob, W1, b1, W2, b2, parents):
+    """own (J,13), glob (6,), stacked per-joint parameters W1 (J,19,19), b1 (J,19), W2 (J,6,19), b2 (J,6), parents (list, -1 = root)
+    -> feats (J,6), hidden (J,19) (arah_pose_tree_forward); no autograd."""
+    lib = load_library()
+    ts = [_f32(t) for t in (own, glob, W1, b1, W2, b2)]
+    dev = _same_device(*ts)
+    J = ts[0].shape[0]
+    if ts[0].shape != (J, 13) or ts[1].numel() != 6 or ts[2].shape != (J, 19, 19) or ts[3].shape != (J, 19) \
+            or ts[4].shape != (J, 6, 19) or ts[5].shape != (J, 6) or len(parents) != J:
+        raise ValueError("pose_tree_forward: shapes of a 13 + 6 -> 19 -> 6 tree encoder expected")
+    with _on_device(dev):
+        feats, hidden = torch.empty(J, 6, device=dev), torch.empty(J, 19, device=dev)
+        _check(lib.arah_pose_tree_forward(*[_ptr(t) for t in ts], _parents_array(parents), C.c_int32(J), _ptr(feats), _ptr(hidden),
+                                          _stream()), "arah_pose_tree_forward")
+    return feats, hidden
+
+
+def pose_tree_backward(own, glob, W1, W2, parents, feats, hidden, g_feats):
+    """-> (gW1, gb1, gW2, gb2, g_glob) for upstream gradients g_feats (J,6) (arah_pose_tree_backward)."""
+    lib = load_library()
+    own, glob, W1, W2, feats, hidden, g = [_f32(t) for t in (own, glob, W1, W2, feats, hidden, g_feats)]
+    dev = _same_device(own, glob, W1, W2, feats, hidden, g)
+    J = own.shape[0]
+    with _on_device(dev):
+        gW1, gb1 = torch.empty(J, 19, 19, device=dev), torch.empty(J, 19, device=dev)
+        gW2, gb2, gg = torch.empty(J, 6, 19, device=dev), torch.empty(J, 6, device=dev), torch.empty(6, device=dev)
+        _check(lib.arah_pose_tree_backward(_ptr(own), _ptr(glob), _ptr(W1), _ptr(W2), _parents_array(parents), C.c_int32(J),
+                                           _ptr(feats), _ptr(hidden), _ptr(g), _ptr(gW1), _ptr(gb1), _ptr(gW2), _ptr(gb2), _ptr(gg),
+                                           _stream()), "arah_pose_tree_backward")
+    return gW1, gb1, gW2, gb2, gg
 
 
 def inverse3x3(m, scale=1.0):

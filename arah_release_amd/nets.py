@@ -247,6 +247,26 @@ class HyperFCFiLM(nn.Module):
         return [h.reshape(*cond.shape[:-1], -1) for h in x.unbind(0)]
 
 
+class _PoseTree(torch.autograd.Function):
+    """The tree of per-joint MLPs of HierarchicalPoseEncoder for ONE frame as one launch each way (hip.pose_tree_forward /
+    _backward).  apply(own (J,13) [no gradient], glob (6,), W1 (J,19,19), b1 (J,19), W2 (J,6,19), b2 (J,6), parents) -> (J,6)."""
+
+    @staticmethod
+    def forward(ctx, own, glob, W1, b1, W2, b2, parents):
+        from . import hip
+        feats, hidden = hip.pose_tree_forward(own, glob, W1, b1, W2, b2, parents)
+        ctx.save_for_backward(own, glob, W1, W2, feats, hidden)
+        ctx.parents = parents
+        return feats
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import hip
+        own, glob, W1, W2, feats, hidden = ctx.saved_tensors
+        gW1, gb1, gW2, gb2, gg = hip.pose_tree_backward(own, glob, W1, W2, ctx.parents, feats, hidden, g.contiguous())
+        return None, gg.reshape(glob.shape), gW1, gb1, gW2, gb2, None
+
+
 class HierarchicalPoseEncoder(nn.Module):
     """LEAP-style encoder: (rots (B,24,9), Jtrs (B,24,3)) -> (B,144)
     (reference siren_modules.py:196-244)."""
@@ -301,6 +321,13 @@ class HierarchicalPoseEncoder(nn.Module):
         b1 = torch.stack([self.layers[j][0].bias for j in range(Jn)]).unsqueeze(1)
         W2 = torch.stack([self.layers[j][2].weight for j in range(Jn)])        # (J, 6, 19)
         b2 = torch.stack([self.layers[j][2].bias for j in range(Jn)]).unsqueeze(1)
+        if (B == 1 and rots.is_cuda and torch.is_grad_enabled() and not own.requires_grad and own.dtype == torch.float32
+                and Jn <= 64 and os.environ.get("ARAH_POSE_TREE_OP", "1") != "0"):
+            # a training step on the device: the whole tree as one launch each way (round 6; the level-by-level form below is
+            # ~70 launches and ~130 in backward of a step that is bound by its host side)
+            feats = _PoseTree.apply(own[:, 0].contiguous(), glob.reshape(-1), W1, b1.squeeze(1), W2, b2.squeeze(1),
+                                    tuple(int(p) for p in self.parents))
+            return feats.reshape(1, -1)
         feats = [None] * Jn
         levels = self._levels()
         sizes = [len(l) for l in levels]

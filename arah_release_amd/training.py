@@ -335,9 +335,36 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
     ridx, sidx = converge_mask.nonzero(as_tuple=True)
     flat = ridx * S + (converge_mask.cumsum(-1) - 1)[ridx, sidx]             # k-th valid sample of a ray -> slot k
     pts = points[ridx, sidx]
-    Tf = transforms_fwd[ridx, sidx]
-    vd = view_dirs[ridx]
-    vd0 = view_dirs_orig[ridx]
+    n_valid = pts.shape[0]
+    far = None
+    from .nets import SingleVarianceNetwork
+    if (frame is not None and n_valid > 0 and isinstance(idhr.deviation_network, SingleVarianceNetwork)
+            and os.environ.get("ARAH_TRAIN_LAZY", "1") != "0"):
+        # Round 6: the per-sample networks run only where a gradient can flow.  A valid sample with metric sdf s > 0 has density
+        # ib * (1/2 - 1/2 (1 - e)), e = exp(-s ib) (IDR:366-368).  Once s ib > 103.98 that exponential is EXACTLY 0 in fp32 (below
+        # the smallest denormal), and so is every term it feeds: the density and its derivatives with respect to s and to beta
+        # (both carry the factor e), hence alpha, the sample's weight, the gradient of its colour (weight x upstream) and of its
+        # SDF value -- the sample's whole contribution to the forward AND to every parameter gradient is exactly zero, whatever
+        # its normal and colour are.  (The eval forward's lazy shading stops at 17.3 beta, where the VALUE rounds to zero; the
+        # derivative needs the exponential itself to vanish.)  One SDF forward over the valid samples (0.2 ms) finds them: 76-87 %
+        # of a training view's samples at beta = 1e-3 (`tools/probes/train_far_samples.py`); the hand-written op, the
+        # re-attachment to the skinning network and their weight-gradient products then see the other 13-24 %.  The far samples
+        # still take part in the compositing with their SDF value (delta chains, the 1e-7 factors), exactly as before.
+        # kFarCut = 110 leaves a margin for the difference between this pass's SDF value and the shading kernel's own (the same
+        # f16-split trunk).  A learned beta that grows widens the band by itself; ARAH_TRAIN_LAZY=0 shades every valid sample.
+        from . import hip
+        with torch.no_grad():
+            s_pre = hip.sdf_eval(frame, ws, pts)[0]
+            to_m = (coord_max.reshape(-1)[0] - coord_min.reshape(-1)[0]) * (1.1 / 2.0)
+            ib_pre = torch.reciprocal(torch.linalg.norm(idhr.deviation_network.variance).clip(1e-6, 1e6))
+            kidx = (~(s_pre * to_m * ib_pre > 110.0)).nonzero().squeeze(1)          # (a NaN value stays)
+        if kidx.numel() < n_valid:
+            far = (kidx, s_pre)
+            pts = pts[kidx]
+    sub = (lambda t: t[far[0]]) if far is not None else (lambda t: t)
+    Tf = sub(transforms_fwd[ridx, sidx])
+    vd = sub(view_dirs[ridx])
+    vd0 = sub(view_dirs_orig[ridx])
     if idhr.cano_view_dirs:
         Rb = torch.linalg.inv(Tf).detach()[:, :3, :3]
         vin = mv3(Rb, -vd)
@@ -392,9 +419,13 @@ def shade_composite_train(idhr, sdf_network, points, z_vals, transforms_fwd, con
                 vi = torch.where(back[:, None], vi0, vi)
         sdf_all.append((sdf / 2.0 * 1.1 * (coord_max.squeeze() - coord_min.squeeze())).squeeze(0))
         rgb_all.append(idhr.rendering_network(pi.squeeze(0), normal.squeeze(0), vi, feat, pose_cond))
-    sdf_v = torch.cat(sdf_all, dim=0)
-    rgb_v = torch.cat(rgb_all, dim=0)
-    from .nets import SingleVarianceNetwork
+    sdf_v = torch.cat(sdf_all, dim=0) if sdf_all else pts.new_zeros(0, 1)
+    rgb_v = torch.cat(rgb_all, dim=0) if rgb_all else pts.new_zeros(0, 3)
+    if far is not None:   # back among all valid samples: the far ones with the pre-pass's SDF value (no graph) and a zero colour
+        kidx, s_pre = far
+        sdf_far = (s_pre / 2.0 * 1.1 * (coord_max.squeeze() - coord_min.squeeze())).reshape(-1)
+        sdf_v = sdf_far.index_copy(0, kidx, sdf_v.reshape(-1)).unsqueeze(-1)
+        rgb_v = torch.zeros(n_valid, 3, device=dev, dtype=rgb_v.dtype).index_copy(0, kidx, rgb_v)
     if (frame is not None and isinstance(idhr.deviation_network, SingleVarianceNetwork)
             and os.environ.get("ARAH_TRAIN_COMPOSITE_OP", "1") != "0"):
         # density + compositing as one op on the compacted samples (rays own contiguous runs of them: nonzero() is row-major);

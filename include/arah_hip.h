@@ -392,6 +392,19 @@ int arah_colsum(const float* a, int64_t lda, int32_t n_cols, int64_t n_rows, con
 int arah_hsoftmax_train_forward(const float* logits, int32_t n, float scale, float* weights, void* stream);
 int arah_hsoftmax_train_backward(const float* logits, int32_t n, float scale, const float* g_weights, float* g_logits, void* stream);
 
+/* HierarchicalPoseEncoder of one frame (im2mesh/metaavatar/models/siren_modules.py:196-244) with its backward, one launch each
+ * way: n_joints MLPs 19 -> 19 -> ReLU -> 6 on [own (13: rotation 9, joint 3, bone length 1) | the parent's feature (6); the
+ * root: glob (6) = layer_0's output], walked down the kinematic tree.  own [J][13], W1 [J][19][19], b1 [J][19], W2 [J][6][19],
+ * b2 [J][6] (the per-joint nn.Linear parameters stacked, (out, in) row-major), parents_host [J] on the HOST (-1: root; parents
+ * precede children), n_joints <= 64 -> feats [J][6], hidden [J][19] (post-ReLU, kept for the backward).
+ * Backward: g_feats [J][6] -> gradients of the stacked parameters and of glob.  The reference runs the joints on autograd. */
+int arah_pose_tree_forward(const float* own, const float* glob, const float* W1, const float* b1, const float* W2,
+                           const float* b2, const int32_t* parents_host, int32_t n_joints, float* feats, float* hidden,
+                           void* stream);
+int arah_pose_tree_backward(const float* own, const float* glob, const float* W1, const float* W2, const int32_t* parents_host,
+                            int32_t n_joints, const float* feats, const float* hidden, const float* g_feats, float* gW1,
+                            float* gb1, float* gW2, float* gb2, float* g_glob, void* stream);
+
 /* inv[p] = (scale * m[p])^-1 for n row-major 3 x 3 matrices (cofactors): the Jacobians d x_bar / d x_hat of the implicit
  * re-attachment of the canonical points to the skinning network (implicit_differentiable_renderer.py:315-334, torch.inverse
  * there).  A singular matrix gives non-finite entries, as torch.inverse does on the device. */

@@ -1398,6 +1398,82 @@ def test_colsum_inverse3x3_and_the_wide_head_op():
 
 
 @gpu
+def test_pose_tree_op_against_the_level_batched_encoder(monkeypatch):
+    """nets._PoseTree (HierarchicalPoseEncoder's tree of joint MLPs as one launch each way, training on the device) against the
+    level-by-level autograd form it replaces: features and the gradients of all 98 parameters."""
+    from arah_release_amd import nets
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    enc = nets.HierarchicalPoseEncoder().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(6)
+    rots = torch.randn(1, 24, 9, generator=g).to(dev)
+    Jtrs = torch.randn(1, 24, 3, generator=g).to(dev) * 0.3
+    up = torch.randn(1, 144, generator=g).to(dev)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("ARAH_POSE_TREE_OP", mode)
+        enc.zero_grad(set_to_none=True)
+        out = enc(rots, Jtrs)
+        (out * up).sum().backward()
+        res[mode] = (out.detach().clone(), {n: p.grad.detach().clone() for n, p in enc.named_parameters()})
+    (o0, g0), (o1, g1) = res["0"], res["1"]
+    assert o1.shape == (1, 144)
+    np.testing.assert_allclose(o1.cpu().numpy(), o0.cpu().numpy(), rtol=2e-5, atol=2e-6)
+    assert len(g0) == 98 and set(g0) == set(g1)
+    for n in g0:
+        np.testing.assert_allclose(g1[n].cpu().numpy(), g0[n].cpu().numpy(), rtol=2e-4, atol=2e-6 * float(g0[n].abs().max() + 1), err_msg=n)
+
+
+@gpu
+def test_lazy_training_shading_is_exact(scene, monkeypatch):
+    """Round 6: the training step runs the per-sample networks only on valid samples with sdf / beta <= 110 (beyond it
+    exp(-sdf / beta) is exactly 0 in fp32 and with it the sample's weight and every derivative that passes through its density:
+    training.shade_composite_train).  Against ARAH_TRAIN_LAZY=0 (every valid sample through the op) on the same frame and the
+    same draws: EQUAL forward outputs and loss terms, gradients equal up to the summation order of the weight-gradient products."""
+    from arah_release_amd import config, renderer, training
+    g = golden("f8_train_step_zju313.npz")
+    dev = torch.device("cuda:0")
+    inputs0 = scene.make_inputs(int(g["H"]), int(g["W"]), frame_idx=int(g["frame_idx"]), max_rays=int(g["max_rays"]),
+                                eval_mode=False, device=dev)
+    old = renderer.draw_uniform
+    renderer.draw_uniform = lambda shape, device, tag: T(g["rand_" + tag]).reshape(shape)
+    seen = {}
+    real_apply = training.ShadeSamples.apply
+    res = {}
+    try:
+        for mode in ("0", "1"):
+            monkeypatch.setenv("ARAH_TRAIN_LAZY", mode)
+            model, cfg = config.build_synthetic_model("zju313", device=dev, training=dict(pose_input_noise=False, view_input_noise=False))
+            model.train()
+            inputs = {k: (dict(v) if isinstance(v, dict) else v) for k, v in inputs0.items()}
+            inputs["pose_cond"]["view_noise"] = T(g["view_noise"])
+
+            def counting(meta, x, *params, mode=mode):
+                seen[mode] = int(x.shape[0])
+                return real_apply(meta, x, *params)
+            monkeypatch.setattr(training.ShadeSamples, "apply", staticmethod(counting))
+            out = model(inputs)
+            losses = training.build_loss(cfg)(out, {"rgb": inputs["rgb_values"], "sampled_weights": inputs["sampled_weights"]})
+            losses["loss"].backward()
+            res[mode] = (out, losses, {n: p.grad.detach().clone() for n, p in model.named_parameters()})
+    finally:
+        renderer.draw_uniform = old
+    assert 0 < seen["1"] < 0.5 * seen["0"], seen          # most of the view's samples are far from the surface
+    (o0, l0, g0), (o1, l1, g1) = res["0"], res["1"]
+    for k in ("rgb_values", "sdf_output", "network_body_mask", "off_surface_sdf", "grad_theta", "pred_weights", "inside_sdf"):
+        assert torch.equal(o0[k], o1[k]), k
+    for k in l0:
+        assert float(l0[k].detach()) == float(l1[k].detach()), k
+    worst = 0.0
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        err = float((g0[n] - g1[n]).abs().max())
+        worst = max(worst, err / (scale + 1e-30))
+        assert err <= 2e-5 * scale + 1e-12, (n, err, scale)
+    print("lazy training shading: %d of %d valid samples through the op, worst gradient difference %.2e of a tensor's scale" % (seen["1"], seen["0"], worst))
+
+
+@gpu
 @pytest.mark.parametrize("tag", ["s64", "s32"])
 def test_training_time_depth_jitter_against_reference(scene, tag):
     """arah_sample_canonicalize with the three draws of the training path (rand_*): its depths against the reference's own
