@@ -822,8 +822,9 @@ def shade_train_forward(frame, ws, x, T, view, view_orig, rotate_normal, ray_aug
         # the 256-wide activations sit next to each other, padded to a multiple of 64 rows with zeros: the weight-gradient
         # products of the backward then run as ONE batched split-K product per group (tall.gram_grouped), all views
         cc = _grouped(4, n, 256, x.device)
-        kept = {"cin": torch.empty(n, KIN_PAD[frame.color_mode], device=x.device),
-                "c": [cc[0, :n], cc[2, :n], torch.empty(n, 128, device=x.device), cc[1, :n], cc[3, :n]], "rgb4": rgb4, "cc": cc}
+        cinp, c2p = _grouped(1, n, KIN_PAD[frame.color_mode], x.device)[0], _grouped(1, n, 128, x.device)[0]
+        kept = {"cin": cinp[:n], "c": [cc[0, :n], cc[2, :n], c2p[:n], cc[1, :n], cc[3, :n]], "rgb4": rgb4, "cc": cc,
+                "cin_pad": cinp, "c2_pad": c2p}
         tin.tap_cin = _ptr(kept["cin"])
         for i, t in enumerate(kept["c"]):
             tin.tap_c[i] = _ptr(t).value
@@ -902,14 +903,15 @@ def shade_train_backward(frame, ws, x, T, view, view_orig, rotate_normal, ray_au
     kin = KIN_PAD[frame.color_mode]
     E = lambda *shape: torch.empty(*shape, device=dev)
     if kept:
-        cc = kept["cc"]
+        cc, cinp, c2p = kept["cc"], kept["cin_pad"], kept["c2_pad"]
     else:
-        cc = _grouped(4, n, 256, dev)
+        cc, cinp, c2p = _grouped(4, n, 256, dev), _grouped(1, n, kin, dev)[0], _grouped(1, n, 128, dev)[0]
     dd = _grouped(4, n, 256, dev)     # delta_1, delta_4, delta_0, delta_3: the order of their partners in `cc` (c_1, c_4, c_2, c_5)
+    d2p = _grouped(1, n, 128, dev)[0]
     st = {"sdf": E(n), "rgb4": E(n, 4), "gx4": E(n, 4), "film_freq": E(6, 256), "film_phase": E(6, 256),
-          "cin": kept["cin"] if kept else E(n, kin),
-          "c": kept["c"] if kept else [cc[0, :n], cc[2, :n], E(n, 128), cc[1, :n], cc[3, :n]],
-          "d": [dd[2, :n], dd[0, :n], E(n, 128), dd[3, :n], dd[1, :n], E(n, 4)], "cc": cc, "dd": dd}
+          "cin": cinp[:n], "c": kept["c"] if kept else [cc[0, :n], cc[2, :n], c2p[:n], cc[1, :n], cc[3, :n]],
+          "d": [dd[2, :n], dd[0, :n], d2p[:n], dd[3, :n], dd[1, :n], E(n, 4)], "cc": cc, "dd": dd,
+          "cin_pad": cinp, "c2_pad": c2p, "d2_pad": d2p}   # the *_pad views: whole buffers, padding rows zero (no remainder product)
     st.update(_sdf_streams(n, dev))
     g = ArahTrainGrads()
     for k in ("sdf", "rgb4", "gx4", "film_freq", "film_phase", "cin"):

@@ -405,9 +405,33 @@ def _wn_linear(n_in, n_out, weight_norm):
     return lin
 
 
+_FOLD_CACHE = [None]   # inside `fold_cache()`: id(layer) -> its folded weight (one autograd node for all uses in a step)
+
+
+class fold_cache:
+    """Within this context a weight-normed layer is folded ONCE however often it is evaluated: a training step runs the skinning
+    MLP three times (the loss' query, the re-attachment, ...) and folded its five layers each time -- ten launches, seventeen in
+    backward and the additions that merge the three gradients.  Same values; the gradient is the sum autograd forms anyway."""
+
+    def __enter__(self):
+        self.prev = _FOLD_CACHE[0]
+        _FOLD_CACHE[0] = {}
+        return self
+
+    def __exit__(self, *exc):
+        _FOLD_CACHE[0] = self.prev
+        return False
+
+
 def folded_weight(lin):
     """Effective (out,in) weight of a (possibly weight-normed) linear layer: g * v / |v|_row."""
     if hasattr(lin, "weight_g"):
+        cache = _FOLD_CACHE[0]
+        if cache is not None and torch.is_grad_enabled():
+            hit = cache.get(id(lin))
+            if hit is None:
+                hit = cache[id(lin)] = torch._weight_norm(lin.weight_v, lin.weight_g, 0)
+            return hit
         # the op torch.nn.utils.weight_norm itself evaluates (fused forward and backward: one launch each, against three
         # and a dozen for g * v / |v| spelled out)
         return torch._weight_norm(lin.weight_v, lin.weight_g, 0)

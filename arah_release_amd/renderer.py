@@ -425,6 +425,11 @@ class IDHRNetwork(nn.Module):
     def forward_train(self, input):
         """Training forward (IDR:42-248): HIP kernels for the ray tracer (no_grad, like the reference), autograd
         for loop D and the regulariser queries (training.py)."""
+        from .nets import fold_cache
+        with fold_cache():   # a weight-normed layer evaluated several times in this step is folded once
+            return self._forward_train(input)
+
+    def _forward_train(self, input):
         ray_dirs, cam_loc = input["ray_dirs"], input["cam_loc"]
         sdf_network, pose_cond = input["sdf_network"], input["pose_cond"]
         cmin, cmax, center = input["coord_min"], input["coord_max"], input["center"]

@@ -221,15 +221,17 @@ class ShadeSamples(torch.autograd.Function):
         # c_4, c_2, c_5): their column sums are one reduction, delta_1^T c_1 and delta_4^T c_4 one batched product
         s1, s4, s0, s3 = (colsum(st["dd"][i]) for i in range(4))   # padding rows are zero
         g14 = gram_grouped(st["dd"][0:2], st["cc"][0:2])
-        m0 = to_reference_columns(gram(d[0], cin))
-        m3 = to_reference_columns(gram(d[3], cin))
+        # (whole padded buffers: their row count is a multiple of the split-K chunking, no remainder product)
+        dd, cc, cin_p = st["dd"], st["cc"], st["cin_pad"]
+        m0 = to_reference_columns(gram(dd[2], cin_p))
+        m3 = to_reference_columns(gram(dd[3], cin_p))
         if n_pose:
             m0.append(torch.outer(s0, pose.reshape(-1)))
             m3.append(torch.outer(s3, pose.reshape(-1)))
-        m3.append(gram(d[3], c[2]))
-        gw = [torch.cat(m0, dim=1), g14[0], gram(d[2], c[1]), torch.cat(m3, dim=1), g14[1],
+        m3.append(gram(dd[3], st["c2_pad"]))
+        gw = [torch.cat(m0, dim=1), g14[0], gram(st["d2_pad"], cc[2]), torch.cat(m3, dim=1), g14[1],
               gram(d[5][:, :3], c[4])]
-        gb = [s0, s1, colsum(d[2]), s3, s4, colsum(d[5][:, :3])]
+        gb = [s0, s1, colsum(st["d2_pad"]), s3, s4, colsum(d[5][:, :3])]
         grads += [g.reshape(w.shape) for g, w in zip(gw, col_w)]
         grads += [g.reshape(b.shape) for g, b in zip(gb, col_b)]
         if n_pose:
@@ -265,10 +267,16 @@ class SdfNormal(torch.autograd.Function):
         return (None, st["gx4"][:, :3]) + tuple(grads)
 
 
+def _first(w):
+    """w[0] of an emitted (1, out, in) weight as a VIEW whose backward is a view too (a select's backward zero-fills a new tensor
+    and copies into it: three launches per emitted tensor and op, 37 per step)."""
+    return w.reshape(w.shape[1:]) if w.shape[0] == 1 else w[0]
+
+
 def sdf_normal_hip(frame, ws, sdf_network, x):
     """x (P,3) normalised -> sdf (P,1) in normalised units, d sdf / d x (P,3); differentiable w.r.t. the emitted network."""
     n = len(sdf_network)
-    sdf_w = [sdf_network[i][0].weights[0] for i in range(n - 1)] + [sdf_network[n - 1].weights[0]]
+    sdf_w = [_first(sdf_network[i][0].weights) for i in range(n - 1)] + [_first(sdf_network[n - 1].weights)]
     sdf_b = [sdf_network[i][0].biases.reshape(-1) for i in range(n - 1)] + [sdf_network[n - 1].biases.reshape(-1)]
     freq = torch.cat([sdf_network[i][0].freq.reshape(-1) for i in range(n - 1)])
     phase = torch.cat([sdf_network[i][0].phase_shift.reshape(-1) for i in range(n - 1)])
@@ -281,7 +289,7 @@ def shade_samples_hip(idhr, frame, ws, sdf_network, x, T, view, view_orig, pose_
     from .nets import folded_weight
     rn = idhr.rendering_network
     n = len(sdf_network)
-    sdf_w = [sdf_network[i][0].weights[0] for i in range(n - 1)] + [sdf_network[n - 1].weights[0]]
+    sdf_w = [_first(sdf_network[i][0].weights) for i in range(n - 1)] + [_first(sdf_network[n - 1].weights)]
     sdf_b = [sdf_network[i][0].biases.reshape(-1) for i in range(n - 1)] + [sdf_network[n - 1].biases.reshape(-1)]
     freq = torch.cat([sdf_network[i][0].freq.reshape(-1) for i in range(n - 1)])
     phase = torch.cat([sdf_network[i][0].phase_shift.reshape(-1) for i in range(n - 1)])
@@ -495,7 +503,7 @@ class IDHRLoss(nn.Module):
 
     def forward(self, out, gt):
         dev = out["rgb_values"].device
-        zero = lambda: torch.zeros(1, device=dev)
+        zero = lambda: 0.0     # (a term that is switched off: a number, not a launch)
         hit = out["network_body_mask"][:, :2048]
         body = out["body_mask"][:, :2048]
         off = out["off_surface_mask"][:, :2048]
@@ -542,9 +550,20 @@ class IDHRLoss(nn.Module):
             terms["sdf_params"] = p.norm(dim=-1).mean() / p.size(-1)
         if self.weights["skinning"] > 0:
             terms["skinning"] = torch.abs(out["pred_weights"] - gt["sampled_weights"]).sum(-1).mean()
-        total = sum(self.weights[k] * terms[k] for k in self.TERMS)
+        # the weighted sum as ONE product with the weight vector (eight multiplications and seven additions were fifteen launches
+        # and as many in backward); the terms in the reference's order
+        live = [k for k in self.TERMS if torch.is_tensor(terms[k])]
+        if live:
+            vec = torch.stack([terms[k].reshape(()) for k in live])
+            key = (str(vec.device), vec.dtype, tuple(live))
+            if getattr(self, "_wvec_key", None) != key:     # the weights are constructor constants: on the device once
+                self._wvec = torch.tensor([float(self.weights[k]) for k in live], dtype=vec.dtype, device=vec.device)
+                self._wvec_key = key
+            total = (vec * self._wvec).sum().reshape(1)     # (1,) like the reference's sum that starts from torch.zeros(1)
+        else:
+            total = torch.zeros(1, device=dev)
         res = {"loss": total}
-        res.update({k + "_loss": v for k, v in terms.items()})
+        res.update({k + "_loss": (v if torch.is_tensor(v) else torch.zeros(1, device=dev)) for k, v in terms.items()})
         return res
 
 
