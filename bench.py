@@ -651,15 +651,15 @@ class GpuRuntime:
         stats1 = torch.cuda.memory_stats(self.dev)
         each = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
         return {"note": "ZJUMOCAP-313 training step, 1 view x 2048 rays on one GPU: HIP ray tracer (no_grad) + hand-written "
-                        "loop-D forward/backward and regulariser queries (k_shade_train) + compositing / loss / hypernetwork on "
-                        "autograd + fused Adam",
+                        "loop-D forward/backward (k_shade_train, on the samples whose density can carry a gradient: sdf / beta <= 110) and "
+                        "regulariser queries + compositing / loss / hypernetwork on autograd + fused Adam",
                 "value": 2048 * steps / dt, "unit": "rays/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
                 "host_cpu_ms_per_step": 1e3 * (c1 - c0) / steps,
                 "ms_each_step": each,
                 "device_allocations_in_the_timed_steps": int(stats1.get("num_device_alloc", 0) - stats0.get("num_device_alloc", 0)),
                 "device_frees_in_the_timed_steps": int(stats1.get("num_device_free", 0) - stats0.get("num_device_free", 0)),
-                "host_note": "CPU time of this process until the last step was enqueued (round 6: the step is ~910 launches, 19.3 ms of "
-                             "kernels, ~22 ms of host time incl. its waits; round 5: 1100 launches, 24.9 ms of kernels).  Earlier in round 5 this line came back at 60-65 ms every other run: the step's "
+                "host_note": "CPU time of this process until the last step was enqueued (round 6: the step is ~720 launches, 15 ms of "
+                             "kernels and host-bound; round 5: 1100 launches, 24.9 ms of kernels).  Earlier in round 5 this line came back at 60-65 ms every other run: the step's "
                              "350 MB gradient blocks were device allocations / frees inside the timed steps when the inference passes "
                              "had left torch's allocator full of other sizes; the line now starts from an empty cache with four warm-up "
                              "steps (4 of 4 runs 24.6-25.8 ms, profiles/r05_train_host.txt)"}
