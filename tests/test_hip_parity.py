@@ -1425,7 +1425,8 @@ def test_pose_tree_op_against_the_level_batched_encoder(monkeypatch):
 
 
 @gpu
-def test_lazy_training_shading_is_exact(scene, monkeypatch):
+@pytest.mark.parametrize("beta", [None, 2e-6, 0.05])
+def test_lazy_training_shading_is_exact(scene, monkeypatch, beta):
     """Round 6: the training step runs the per-sample networks only on valid samples with sdf / beta <= 110 (beyond it
     exp(-sdf / beta) is exactly 0 in fp32 and with it the sample's weight and every derivative that passes through its density:
     training.shade_composite_train).  Against ARAH_TRAIN_LAZY=0 (every valid sample through the op) on the same frame and the
@@ -1445,6 +1446,9 @@ def test_lazy_training_shading_is_exact(scene, monkeypatch):
             monkeypatch.setenv("ARAH_TRAIN_LAZY", mode)
             model, cfg = config.build_synthetic_model("zju313", device=dev, training=dict(pose_input_noise=False, view_input_noise=False))
             model.train()
+            if beta is not None:   # a tiny beta: (almost) every sample is far; a large one: none is
+                with torch.no_grad():
+                    model.deviation_decoder.variance.fill_(beta)
             inputs = {k: (dict(v) if isinstance(v, dict) else v) for k, v in inputs0.items()}
             inputs["pose_cond"]["view_noise"] = T(g["view_noise"])
 
@@ -1458,7 +1462,12 @@ def test_lazy_training_shading_is_exact(scene, monkeypatch):
             res[mode] = (out, losses, {n: p.grad.detach().clone() for n, p in model.named_parameters()})
     finally:
         renderer.draw_uniform = old
-    assert 0 < seen["1"] < 0.5 * seen["0"], seen          # most of the view's samples are far from the surface
+    if beta is None:
+        assert 0 < seen["1"] < 0.5 * seen["0"], seen          # most of the view's samples are far from the surface
+    elif beta > 1e-2:
+        assert seen["1"] == seen["0"], seen                    # the band is wider than the body's box: nothing to skip
+    else:
+        assert seen.get("1", 0) < 0.1 * seen["0"], seen
     (o0, l0, g0), (o1, l1, g1) = res["0"], res["1"]
     for k in ("rgb_values", "sdf_output", "network_body_mask", "off_surface_sdf", "grad_theta", "pred_weights", "inside_sdf"):
         assert torch.equal(o0[k], o1[k]), k
