@@ -480,6 +480,26 @@ class IDHRNetwork(nn.Module):
                 ray_augm = True
             else:
                 dirs_in = ray_dirs + vn
+        from .nets import SingleVarianceNetwork
+        if (frame is not None and use_hip_shading and isinstance(self.deviation_network, SingleVarianceNetwork)
+                and os.environ.get("ARAH_TRAIN_COMPOSITE_OP", "1") != "0" and os.environ.get("ARAH_TRAIN_RAY_COMPACTION", "0") != "1"):
+            # Round 6: no compaction of the RAYS.  The reference shades the rays that own a valid sample and leaves the others
+            # at zero; the compositing op gives exactly that zero (colour and accumulation) for a ray without samples, so all
+            # rays go down as they are: one device -> host round trip, seven gathers and two scatters less (~25 launches with
+            # their backward).  The samples are still compacted once, inside.
+            rgb_all, w_all = training.shade_composite_train(
+                self, sdf_network, s_pts.reshape(B * N, *s_pts.shape[2:]), s_z.reshape(B * N, -1),
+                s_T.reshape(B * N, *s_T.shape[2:]), s_mask.reshape(B * N, -1), dirs_in.reshape(B * N, 3),
+                ray_dirs.reshape(B * N, 3), pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
+                self.ray_tracer.n_steps, ray_augm=ray_augm, frame=frame, ws=self.ray_tracer.workspace(dev))
+            out = {"rgb_values": rgb_all.reshape(B, N, 3), "sdf_output": w_all.reshape(B, N), "network_body_mask": vol_mask,
+                   "body_mask": input["body_mask"], "off_surface_mask": vol_mask, "off_surface_sdf": uniform_sdf,
+                   "grad_theta": grad_eik, "surface_normals": None}
+            if pred_weights is not None:
+                out["pred_weights"] = pred_weights
+            if inside_sdf is not None:
+                out["inside_sdf"] = inside_sdf
+            return out
         vb, vr = vol_mask.nonzero(as_tuple=True)   # one compaction for the seven gathers and the two scatters
         rgb_hit, w_hit = training.shade_composite_train(
             self, sdf_network, s_pts[vb, vr], s_z[vb, vr], s_T[vb, vr], s_mask[vb, vr], dirs_in[vb, vr],
