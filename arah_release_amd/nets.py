@@ -385,7 +385,9 @@ class HyperBVPNet(nn.Module):
         if latent is None:
             raise NotImplementedError("FiLM SDF decoder needs a geometry latent code")
         decoder = self.net(cond, latent)
-        out = decoder(coords)
+        # the emitted network AT `coords` (siren_modules.py:303-316 returns it; the renderer passes one dummy point and never
+        # looks at the value): skipped when the caller says so -- 27 launches of a host-bound training step
+        out = None if model_input.get("skip_model_out") else decoder(coords)
         B = coords.shape[0]
         params = [decoder[i][0].weights.reshape(B, -1) for i in range(len(decoder) - 1)]
         params.append(decoder[-1].weights.reshape(B, -1))

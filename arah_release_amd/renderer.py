@@ -765,6 +765,8 @@ class MetaAvatarRender(nn.Module):
                 tg.broken = True
                 out = self.sdf_decoder(decoder_input)
         else:
+            if not eval and torch.is_grad_enabled():
+                decoder_input["skip_model_out"] = True     # the value of the emitted network at the dummy point is never used
             out = self.sdf_decoder(decoder_input)
         inputs.update({"loc": torch.zeros(B, 1, 3, device=dev), "sc_factor": torch.ones(B, 1, 1, device=dev),
                        "vol_feat": torch.empty(B, 0, device=dev), "sdf_network": out["decoder"]})
