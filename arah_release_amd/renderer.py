@@ -805,12 +805,14 @@ _FREE_STREAMS = {}   # streams of map_in_flight calls without an owner, per (dev
 
 def frames_in_flight(n_frames):
     """How many frames of a sequence render_sequence keeps in flight by default: every further frame hides more of the
-    kernels' tails and of the latency-bound finishers under other frames' wide kernels (512x512, 20-frame passes on one
-    MI355X: 36.4 / 35.4 / 34.7 / 34.3 ms per frame with 3 / 4 / 5 / 6 in flight), but a short sequence must still fill the
-    streams evenly (8 frames: 36.2 / 34.9 / 35.4 with 3 / 4 / 5).  Five from fifteen frames on, four below; 150
-    consecutive eight-frame passes with 4, 5 and 6 in flight came back clean and bit-identical
-    (tools/stress_streams.py, profiles/r04d_streams_soak.txt)."""
-    return max(1, min(5 if n_frames >= 15 else 4, n_frames))
+    kernels' tails and of the latency-bound finishers under other frames' wide kernels, but a short sequence must still fill the
+    streams evenly.  Round 4 (untiered frames of 35 ms): 36.4 / 35.4 / 34.7 / 34.3 ms per frame with 3 / 4 / 5 / 6 in flight on
+    20-frame passes, 36.2 / 34.9 / 35.4 with 3 / 4 / 5 on eight frames -- five from fifteen frames on, four below.  Round 6
+    (tiered frames of 13 ms, whose kernels are short): 20-frame passes 12.1 / 12.9 / 12.3 / 12.2 ms with 4 / 5 / 6 / 8 in flight
+    (three alternations on one box, within 0.05 ms of each other; why five is the slow one was not looked into), eight-frame
+    passes 12.9 / 13.0 / 13.0 / 12.8 / 13.1 with 3 / 4 / 5 / 6 / 8: FOUR for every length.  Soaks with 4, 5 and 6 in flight came
+    back clean and bit-identical (tools/stress_streams.py, profiles/r04d_streams_soak.txt, r06e_streams_soak.txt)."""
+    return max(1, min(4, n_frames))
 
 
 def render_sequence(model, frames, n_streams=None, **forward_kwargs):

@@ -316,7 +316,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight in the timed region of every pass (renderer.render_sequence: frame k on HIP stream "
                          "k mod N, own scratch each); 0 = the product's default for a sequence of --steps frames "
-                         "(renderer.frames_in_flight: four, five from fifteen frames on; soaks in profiles/r03_streams_soak.txt, "
+                         "(renderer.frames_in_flight: four; soaks in profiles/r03_streams_soak.txt, "
                          "r04d_streams_soak.txt); 1 = strictly one frame after the other (also measured, first, and reported "
                          "as 'one_frame_at_a_time')")
     ap.add_argument("--pipelined-streams", type=int, default=0,

@@ -207,9 +207,10 @@ def test_pipelined_extra_adds_its_object_and_leaves_the_line_alone():
 
 
 def test_frames_in_flight_default():
-    """renderer.frames_in_flight: never more streams than frames, four for short sequences, five from fifteen frames on."""
+    """renderer.frames_in_flight: never more streams than frames, four from four frames on (round 6: the tiered frames' optimum for
+    every sequence length; five from fifteen frames on until round 5)."""
     from arah_release_amd import renderer
-    assert [renderer.frames_in_flight(n) for n in (0, 1, 3, 4, 8, 14, 15, 20, 400)] == [1, 1, 3, 4, 4, 4, 5, 5, 5]
+    assert [renderer.frames_in_flight(n) for n in (0, 1, 3, 4, 8, 14, 15, 20, 400)] == [1, 1, 3, 4, 4, 4, 4, 4, 4]
     assert renderer.map_in_flight(lambda x: x + 1, []) == []
     assert renderer.map_in_flight(lambda x: x + 1, [1, 2, 3]) == [2, 3, 4]      # host-resident items: plain map
 

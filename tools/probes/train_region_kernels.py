@@ -16,7 +16,7 @@ def wrap(obj, attr, name):
     setattr(obj, attr, g)
 for name in sys.argv[1:]:
     mod, attr = name.rsplit(".", 1)
-    wrap({"training": training, "renderer": renderer, "hip": hip, "sdf_decoder": model.sdf_decoder, "crit": crit, "idhr": model.idhr_network}[mod], attr, name)
+    wrap({"training": training, "renderer": renderer, "hip": hip, "sdf_decoder": model.sdf_decoder, "crit": crit, "idhr": model.idhr_network, "model": model}[mod], attr, name)
 def step(inp):
     opt.zero_grad(set_to_none=True)
     training.training_step(model, crit, inp)["loss"].backward()
