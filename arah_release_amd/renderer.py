@@ -279,6 +279,7 @@ class BodyRayTracing(nn.Module):
         self.surface_vol_range = surface_vol_range
         self.sample_bg_pts = sample_bg_pts
         self.low_vram = low_vram
+        self.pending_bounds_ok = None   # training: the near <= far verdict of the last call, still on the device (see forward)
         self._ws = {}          # one caller-owned scratch per (device, stream): frames in flight on different streams
         self._sampling = {}
         # False: exact lazy shading (normals/colours only where the VolSDF density is > 0); True: shade every
@@ -333,8 +334,16 @@ class BodyRayTracing(nn.Module):
         B, N, _ = ray_directions.shape
         if N == 0:
             raise ValueError("No valid depth.")
-        if not bool((body_bounds_intersections[..., 0] <= body_bounds_intersections[..., 1]).all()):
-            raise AssertionError("near bound exceeds far bound")
+        # RT:182 asserts near <= far; the test is a device -> host round trip.  Eval: here, like the reference.  Training: the
+        # verdict is looked at behind the step's first compaction (forward_train), where the host waits for the device anyway --
+        # here it would hold the tracer's launches back until the hypernetwork has drained
+        bounds_ok = (body_bounds_intersections[..., 0] <= body_bounds_intersections[..., 1]).all()
+        if eval_mode or os.environ.get("ARAH_TRAIN_LATE_BOUNDS_CHECK", "1") == "0":
+            if not bool(bounds_ok):
+                raise AssertionError("near bound exceeds far bound")
+            self.pending_bounds_ok = None
+        else:
+            self.pending_bounds_ok = bounds_ok
         dev = ray_directions.device
         if frame is None:
             frame = build_frame(sdf_network, skinning_model, None, None, None, smpl_verts, skinning_weights,
@@ -429,6 +438,12 @@ class IDHRNetwork(nn.Module):
         with fold_cache():   # a weight-normed layer evaluated several times in this step is folded once
             return self._forward_train(input)
 
+    def _late_bounds_check(self):
+        """The ray tracer's near <= far assertion (RT:182) of a training step, behind the step's compaction."""
+        ok, self.ray_tracer.pending_bounds_ok = getattr(self.ray_tracer, "pending_bounds_ok", None), None
+        if ok is not None and not bool(ok):
+            raise AssertionError("near bound exceeds far bound")
+
     def _forward_train(self, input):
         ray_dirs, cam_loc = input["ray_dirs"], input["cam_loc"]
         sdf_network, pose_cond = input["sdf_network"], input["pose_cond"]
@@ -492,6 +507,7 @@ class IDHRNetwork(nn.Module):
                 s_T.reshape(B * N, *s_T.shape[2:]), s_mask.reshape(B * N, -1), dirs_in.reshape(B * N, 3),
                 ray_dirs.reshape(B * N, 3), pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
                 self.ray_tracer.n_steps, ray_augm=ray_augm, frame=frame, ws=self.ray_tracer.workspace(dev))
+            self._late_bounds_check()
             out = {"rgb_values": rgb_all.reshape(B, N, 3), "sdf_output": w_all.reshape(B, N), "network_body_mask": vol_mask,
                    "body_mask": input["body_mask"], "off_surface_mask": vol_mask, "off_surface_sdf": uniform_sdf,
                    "grad_theta": grad_eik, "surface_normals": None}
@@ -506,6 +522,7 @@ class IDHRNetwork(nn.Module):
             ray_dirs[vb, vr], pose_cond, input["bone_transforms"][:1], cmin[:1], cmax[:1], center[:1],
             self.ray_tracer.n_steps, ray_augm=ray_augm, frame=frame if use_hip_shading else None,
             ws=self.ray_tracer.workspace(dev) if frame is not None else None)
+        self._late_bounds_check()
         rgb = torch.zeros(B * N, 3, device=dev, dtype=xn.dtype).index_copy(0, vb * N + vr, rgb_hit).reshape(B, N, 3)
         acc = torch.zeros(B * N, device=dev).index_copy(0, vb * N + vr, w_hit.reshape(-1)).reshape(B, N)
         out = {"rgb_values": rgb, "sdf_output": acc, "network_body_mask": vol_mask, "body_mask": input["body_mask"],
