@@ -916,6 +916,12 @@ def run(args, rt):
                                                        "unit": "TFLOP/s", "frac": d_ach / peak_fwd, "avg_launch_ms": d_ms}}
             line["roofline"]["untiered_frac"] = u_ach / peak_fwd
             line["roofline"]["untiered_k_density_frac"] = d_ach / peak_fwd
+            if tiers_on:
+                line["roofline"]["frac_note"] = (
+                    "tiered frames launch this kernel twice on SHORT lists (a fifth of the untiered evaluations): a launch lasts as long "
+                    "as the chain of its slowest samples (51 dependent Broyden steps, ~2.4 ms) whatever it holds, so `frac` measures "
+                    "that chain, not the kernel -- the same kernel on the untiered list of the same frames: `untiered_frac`; the "
+                    "frame's second MFMA kernel: `k_density_frac`")
         if tiers_on:
             per = max(n_rays_local, 1)
             line["tiers"] = {"note": "tiered evaluation (csrc/tier.hpp): rays whose segment misses the posed fat body skip loops A+B; "
